@@ -1,0 +1,116 @@
+"""Deterministic synthetic whiteboard inputs (no video / dataset is available offline).
+
+Generators follow the recipes fixed in SURVEY.md section 8(d):
+  * whiteboard_rgb()      config 1/2/5: light board + illumination ramp + dark glyph strokes (RGB uint8)
+  * binary_stream()       config 3/4: persistent canvas, glyphs added over time, partial erasures,
+                          one transient blob per frame, occasional 1-px jitter, optional occluder
+  * logits_from_binary()  fp32 "FCN logits" (+-4 around the mask) so that the threshold kernel is
+                          exercised: ink (255 in the step-01 output) <=> NEGATIVE logit, because the
+                          worker inverts the thresholded sigmoid (FCN_lecturenet_binarizer.py:54).
+Pure numpy; shared by tests and bench.py.
+"""
+import numpy as np
+
+
+def _draw_glyph(canvas, x, y, gw, gh, thick, kind, value=255):
+    """kind 0: box outline, 1: L (left + bottom), 2: inverted L (top + right), 3: plus/cross."""
+    h, w = canvas.shape
+    x1, y1 = min(x + gw, w), min(y + gh, h)
+    if kind == 0:
+        canvas[y:min(y + thick, y1), x:x1] = value
+        canvas[max(y1 - thick, y):y1, x:x1] = value
+        canvas[y:y1, x:min(x + thick, x1)] = value
+        canvas[y:y1, max(x1 - thick, x):x1] = value
+    elif kind == 1:
+        canvas[y:y1, x:min(x + thick, x1)] = value
+        canvas[max(y1 - thick, y):y1, x:x1] = value
+    elif kind == 2:
+        canvas[y:min(y + thick, y1), x:x1] = value
+        canvas[y:y1, max(x1 - thick, x):x1] = value
+    else:
+        cx, cy = x + gw // 2, y + gh // 2
+        canvas[y:y1, cx:min(cx + thick, x1)] = value
+        canvas[cy:min(cy + thick, y1), x:x1] = value
+
+
+def _random_glyphs(rng, n, h, w, margin=10, min_ext=6, max_ext=28):
+    gw = rng.integers(min_ext, max_ext + 1, n)
+    gh = rng.integers(min_ext, max_ext + 1, n)
+    x = rng.integers(margin, max(margin + 1, w - margin - max_ext), n)
+    y = rng.integers(margin, max(margin + 1, h - margin - max_ext), n)
+    thick = rng.integers(2, 4, n)
+    kind = rng.integers(0, 4, n)
+    return np.stack([x, y, gw, gh, thick, kind], axis=1)
+
+
+def glyph_mask(h=1080, w=1920, n_glyphs=1500, seed=20211):
+    """uint8 {0,255} ink mask of n_glyphs strokes (config 1's synthetic *binary* frame)."""
+    rng = np.random.default_rng(seed)
+    m = np.zeros((h, w), np.uint8)
+    for g in _random_glyphs(rng, n_glyphs, h, w):
+        _draw_glyph(m, *[int(v) for v in g])
+    return m
+
+
+def whiteboard_rgb(h=1080, w=1920, n_glyphs=1500, seed=20211):
+    """RGB uint8 whiteboard-like frame + its ink mask."""
+    rng = np.random.default_rng(seed)
+    ramp = np.linspace(-10.0, 10.0, w, dtype=np.float32)[None, :, None]
+    img = 235.0 + rng.normal(0.0, 3.0, (h, w, 3)).astype(np.float32) + ramp
+    mask = np.zeros((h, w), np.uint8)
+    ink = np.zeros((h, w), np.uint8)
+    for g in _random_glyphs(rng, n_glyphs, h, w):
+        gi = [int(v) for v in g]
+        _draw_glyph(mask, *gi)
+        _draw_glyph(ink, *gi, value=int(rng.integers(20, 81)))
+    img = np.clip(img, 0, 255)
+    img[mask > 0] = ink[mask > 0][:, None]
+    return img.astype(np.uint8), mask
+
+
+def binary_stream(n_frames, h=1080, w=1920, seed=20213, glyphs_per_add=40, add_every=2, erase_every=250,
+                  jitter_p=0.02, jitter_frac=0.05, transient=True, occluder=False, max_ext=28):
+    """Yield n_frames uint8 {0,255} frames (255 = ink), a persistent board evolving in time."""
+    rng = np.random.default_rng(seed)
+    canvas = np.zeros((h, w), np.uint8)
+    glyphs = np.zeros((0, 6), np.int64)
+    next_erase = erase_every + int(rng.integers(-erase_every // 10, erase_every // 10 + 1)) if erase_every else -1
+    occ_w, occ_h, occ_speed = max(w // 6, 8), max(h // 2, 8), max(w // 240, 1)
+    for t in range(n_frames):
+        if add_every and t % add_every == 0:
+            new = _random_glyphs(rng, glyphs_per_add, h, w, max_ext=max_ext)
+            for g in new:
+                _draw_glyph(canvas, *[int(v) for v in g])
+            glyphs = np.concatenate([glyphs, new], axis=0)
+        if erase_every and t == next_erase:
+            frac = (2, 3)[int(rng.integers(0, 2))]
+            span = w // frac
+            x0 = int(rng.integers(0, w - span + 1))
+            canvas[:, x0:x0 + span] = 0
+            keep = (glyphs[:, 0] + glyphs[:, 2] <= x0) | (glyphs[:, 0] >= x0 + span)
+            glyphs = glyphs[keep]
+            next_erase = t + erase_every + int(rng.integers(-erase_every // 10, erase_every // 10 + 1))
+        frame = canvas.copy()
+        if jitter_p and len(glyphs) and rng.random() < jitter_p:
+            sel = rng.choice(len(glyphs), max(1, int(len(glyphs) * jitter_frac)), replace=False)
+            for g in glyphs[sel]:
+                x, y, gw, gh, th, kd = [int(v) for v in g]
+                frame[y:y + gh, x:x + gw] = 0
+                dx, dy = int(rng.integers(-1, 2)), int(rng.integers(-1, 2))
+                _draw_glyph(frame, max(x + dx, 0), max(y + dy, 0), gw, gh, th, kd)
+        if transient:
+            bx, by = int(rng.integers(0, max(w - 6, 1))), int(rng.integers(0, max(h - 6, 1)))
+            frame[by:by + 6, bx:bx + 6] = 255
+        if occluder:
+            ox = (t * occ_speed) % (w + occ_w) - occ_w
+            oy = (h - occ_h) // 2
+            frame[oy:oy + occ_h, max(ox, 0):max(ox + occ_w, 0)] = 0
+        yield frame
+
+
+def logits_from_binary(binary, seed=0, margin=4.0, noise=0.5):
+    """fp32 logits whose sigmoid->threshold->invert reproduces `binary` (255 = ink <=> negative logit)."""
+    rng = np.random.default_rng(seed)
+    lg = np.where(binary > 0, -margin, margin).astype(np.float32)
+    lg += (rng.random(binary.shape, dtype=np.float32) - 0.5) * (2.0 * noise)
+    return lg
