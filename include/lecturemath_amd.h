@@ -1,0 +1,111 @@
+/*
+ * lecturemath_amd.h -- C ABI of the MI355X-native LectureMath hot path (liblecturemath_hip.so, also
+ * installed under the reference's own name ./accessmath_lib.so).
+ *
+ * Plain C, plain pointers and sizes, no torch types.  "d_" parameters are DEVICE pointers (HBM,
+ * e.g. torch.Tensor.data_ptr()), "h_" parameters are host pointers.  `stream` is a hipStream_t passed
+ * as void* (NULL = default stream; from PyTorch: torch.cuda.current_stream().cuda_stream).
+ * Every int-returning function returns 0 (LM_OK) on success and an LM_ERR_* code otherwise;
+ * lm_last_error() then describes the failure.  Nothing throws across the ABI.
+ *
+ * Reference interfaces replaced (paths relative to /root/reference/ACCESS2021_release):
+ *   the five exports of accessmath_lib.c, bound with ctypes.CDLL('./accessmath_lib.so') at
+ *   AccessMath/preprocessing/content/labeler.py:24, binarizer.py:22, tools/adaptive_equalizer.py:25
+ *   + the third-party arithmetic the hot path calls around them (scipy.ndimage.label labeler.py:126,
+ *   numpy crops labeler.py:183, numpy AND/count_nonzero connected_component.py:228, torch sigmoid +
+ *   numpy threshold FCN_lecturenet.py:452-467, torch conv stack FCN_lecturenet.py:260-403).
+ */
+#ifndef LECTUREMATH_AMD_H
+#define LECTUREMATH_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LM_OK 0
+#define LM_ERR_ARG 1
+#define LM_ERR_HIP 2
+#define LM_ERR_CAPACITY 3
+#define LM_ERR_STATE 4
+
+typedef struct LmCtx LmCtx;
+typedef struct LmStream LmStream;
+
+/* ---- library ---- */
+int lm_abi_version(void);
+const char* lm_last_error(void);
+/* 1 when the library was built by hipcc for gfx950, 0 for the test-only CPU emulation build */
+int lm_is_device_build(void);
+
+/* ====================================================================================================
+ * 1. Drop-in exports: the reference's accessmath_lib.c symbols, same names / signatures / return values.
+ * ==================================================================================================== */
+
+/* accessmath_lib.c:357-359 (argtypes/restype set at labeler.py:159-165).  HOST pointers, caller-allocated
+ * outputs of length count_labels.  labels int32 H x W C-contiguous, ages fp32 H x W.  Returns 0. */
+int CC_AgeBoundaries(int* labels, float* ages, int width, int height, int count_labels,
+                     int* out_mins_y, int* out_maxs_y, int* out_mins_x, int* out_maxs_x,
+                     int* out_counts, float* output_age);
+
+/* ====================================================================================================
+ * 2. Per-frame CC path on device-resident batches.
+ * ==================================================================================================== */
+
+/* Workspace for batches of up to max_batch frames of width x height (device memory, current device). */
+LmCtx* lm_ctx_create(int width, int height, int max_batch);
+void lm_ctx_destroy(LmCtx* ctx);
+
+/* FCN_LectureNet.binarize post-processing + worker inversion (FCN_lecturenet.py:452,461-467;
+ * FCN_lecturenet_binarizer.py:54): out = 255 - (trunc(sigmoid(logit)*255) >= thr ? 255 : 0), n pixels. */
+int lm_threshold_invert(const float* d_logits, uint8_t* d_out, int64_t n, int thr, void* stream);
+
+/* scipy.ndimage.label (labeler.py:126) for n_frames frames (uint8, non-zero = foreground, contiguous
+ * [n_frames][height][width]).  d_labels (int32, same shape) may be NULL when only the CC records are
+ * wanted.  Leaves the run structures of the batch in the workspace for the calls below. */
+int lm_label_batch(LmCtx* ctx, const uint8_t* d_binary, int n_frames, int32_t* d_labels, void* stream);
+
+/* Number of labels of every frame of the last batch -> h_counts[n_frames] (synchronises the stream). */
+int lm_label_counts(LmCtx* ctx, int32_t* h_counts, void* stream);
+
+/* CC_AgeBoundaries (accessmath_lib.c:357-413) for the last labelled batch, computed from the runs.
+ * Results stay on the device; lm_cc_stats_read copies frame `frame`'s arrays (length = its label count)
+ * to host arrays in the reference's order mins_y, maxs_y, mins_x, maxs_x, counts. */
+int lm_cc_stats_batch(LmCtx* ctx, void* stream);
+int lm_cc_stats_read(LmCtx* ctx, int frame, int count_labels, int32_t* h_mins_y, int32_t* h_maxs_y,
+                     int32_t* h_mins_x, int32_t* h_maxs_x, int32_t* h_counts, void* stream);
+
+/* Host-pointer convenience: one frame in, scipy-ordered labels out; returns the label count (>= 0)
+ * or -LM_ERR_*.  Uses an internal lazily-created workspace on the current device. */
+int lm_label_host(const uint8_t* h_img, int width, int height, int32_t* h_labels);
+
+/* ====================================================================================================
+ * 3. Frame stream: CC records + temporal matching (CCStabilityEstimator.add_frame,
+ *    content/cc_stability_estimator.py:41-155), state resident in HBM.
+ * ==================================================================================================== */
+
+LmStream* lm_stream_create(LmCtx* ctx, int max_frames, int64_t max_ccs, int64_t max_crop_words, int max_uniques,
+                           double min_recall, double min_precision, int max_gap, int min_pixels);
+void lm_stream_destroy(LmStream* s);
+int lm_stream_reset(LmStream* s, void* stream);
+
+/* Push the next n_frames binary frames (device, uint8): label -> stats -> kept CCs + crops -> match.
+ * d_labels may be NULL.  Asynchronous on `stream`. */
+int lm_stream_push(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* d_labels, void* stream);
+
+/* Synchronise and read the stream's counters: out[0]=n_frames, [1]=n_cc, [2]=n_crop_words, [3]=n_unique,
+ * [4]=n_active, [5]=tempo_count, [6]=device error code. */
+int lm_stream_counters(LmStream* s, int64_t* h_out7, void* stream);
+
+/* Copy results to the host (call lm_stream_counters first to size the buffers).
+ * h_rec: n_cc x 8 int32 = cc_id, min_x, max_x, min_y, max_y, size, frame, assigned unique index.
+ * h_frame_off: n_frames + 1 int64.  h_crop_off: n_cc int64 word offsets.  h_crop: n_crop_words uint32.
+ * h_active: n_active int32.  Any pointer may be NULL to skip that part. */
+int lm_stream_read(LmStream* s, int32_t* h_rec, int64_t* h_frame_off, int64_t* h_crop_off, uint32_t* h_crop,
+                   int32_t* h_active, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LECTUREMATH_AMD_H */

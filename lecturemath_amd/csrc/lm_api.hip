@@ -1,0 +1,429 @@
+// lm_api.hip -- C-ABI entry points (include/lecturemath_amd.h) over the kernels of this directory.
+// Unity translation unit: the kernel files are included so launches see the definitions.
+#include "lm_common.h"
+#include "lm_stream.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/lecturemath_amd.h"
+
+#include "lm_cc_kernels.hip"
+#include "lm_match_kernels.hip"
+
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void lm_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* lm_last_error(void) { return g_err; }
+extern "C" int lm_abi_version(void) { return 1; }
+extern "C" int lm_is_device_build(void) { return LM_HIP_EMULATED ? 0 : 1; }
+
+static inline unsigned lm_blocks(long long work_items, int block, int max_blocks = 8192)
+{
+    long long b = (work_items + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (unsigned)b;
+}
+
+template <class T> static int lm_alloc(T** p, size_t count)
+{
+    LM_HIP(hipMalloc((void**)p, count * sizeof(T) + 64));
+    return LM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+extern "C" void lm_ctx_destroy(LmCtx* c)
+{
+    if (!c) return;
+    void* ptrs[] = {c->bits, c->starts, c->prefix, c->row_runs, c->rowoff, c->frame_runs, c->parent, c->final_label,
+                    c->n_labels, c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x, c->st_count, c->kept_label,
+                    c->kept_cropoff, c->frame_kept, c->frame_cropwords, c->stage_u8, c->stage_i32, c->stage_f32};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete c;
+}
+
+extern "C" LmCtx* lm_ctx_create(int width, int height, int max_batch)
+{
+    if (width <= 0 || height <= 0 || max_batch <= 0 || max_batch > 1024 || width > 32767 || height > 32767) {
+        lm_set_error("lm_ctx_create: bad arguments (width=%d height=%d max_batch=%d; batch <= 1024, sides <= 32767)",
+                     width, height, max_batch);
+        return nullptr;
+    }
+    LmCtx* c = new LmCtx();
+    memset(c, 0, sizeof(*c));
+    c->g.W = width;
+    c->g.H = height;
+    c->g.WW = (width + 63) / 64;
+    c->g.cap = height * ((width + 1) / 2);
+    c->max_batch = max_batch;
+    (void)hipGetDevice(&c->device);
+    const size_t R = (size_t)max_batch * height, RW = R * c->g.WW, BC = (size_t)max_batch * c->g.cap;
+    int rc = LM_OK;
+    rc |= lm_alloc(&c->bits, RW);
+    rc |= lm_alloc(&c->starts, RW);
+    rc |= lm_alloc(&c->prefix, RW);
+    rc |= lm_alloc(&c->row_runs, R);
+    rc |= lm_alloc(&c->rowoff, R);
+    rc |= lm_alloc(&c->frame_runs, (size_t)max_batch);
+    rc |= lm_alloc(&c->parent, BC);
+    rc |= lm_alloc(&c->final_label, BC);
+    rc |= lm_alloc(&c->n_labels, (size_t)max_batch);
+    rc |= lm_alloc(&c->st_min_y, BC);
+    rc |= lm_alloc(&c->st_max_y, BC);
+    rc |= lm_alloc(&c->st_min_x, BC);
+    rc |= lm_alloc(&c->st_max_x, BC);
+    rc |= lm_alloc(&c->st_count, BC);
+    rc |= lm_alloc(&c->kept_label, BC);
+    rc |= lm_alloc(&c->kept_cropoff, BC);
+    rc |= lm_alloc(&c->frame_kept, (size_t)max_batch);
+    rc |= lm_alloc(&c->frame_cropwords, (size_t)max_batch);
+    if (rc != LM_OK) {
+        lm_ctx_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// threshold
+// ------------------------------------------------------------------------------------------------
+extern "C" int lm_threshold_invert(const float* d_logits, uint8_t* d_out, int64_t n, int thr, void* stream)
+{
+    if (!d_logits || !d_out || n < 0) { lm_set_error("lm_threshold_invert: bad arguments"); return LM_ERR_ARG; }
+    if (n == 0) return LM_OK;
+    hipLaunchKernelGGL(lm_k_threshold_invert, dim3(lm_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       d_logits, d_out, (long long)n, thr);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// labelling
+// ------------------------------------------------------------------------------------------------
+extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, int32_t* d_labels, void* stream)
+{
+    if (!c || !d_binary || n_frames <= 0 || n_frames > c->max_batch) {
+        lm_set_error("lm_label_batch: bad arguments (n_frames=%d, max_batch=%d)", n_frames, c ? c->max_batch : -1);
+        return LM_ERR_ARG;
+    }
+    const LmGeom g = c->g;
+    hipStream_t st = (hipStream_t)stream;
+    const long long nrows = (long long)n_frames * g.H;
+    const int chunks = g.WW * 4;
+    hipLaunchKernelGGL(lm_k_pack, dim3(lm_blocks(nrows * chunks, 256)), dim3(256), 0, st, d_binary, (uint16_t*)c->bits, g.W,
+                       nrows, chunks);
+    hipLaunchKernelGGL(lm_k_rowscan, dim3(lm_blocks(nrows * 64, 256)), dim3(256), 0, st, c->bits, c->starts, c->prefix,
+                       c->row_runs, g.WW, nrows);
+    hipLaunchKernelGGL(lm_k_frame_rowoff, dim3(n_frames), dim3(1024), 0, st, c->row_runs, c->rowoff, c->frame_runs, c->parent,
+                       g.H, g.cap);
+    hipLaunchKernelGGL(lm_k_union, dim3(lm_blocks(nrows * g.WW, 256)), dim3(256), 0, st, c->bits, c->starts, c->prefix,
+                       c->rowoff, c->parent, g.WW, g.H, g.cap, nrows);
+    hipLaunchKernelGGL(lm_k_resolve, dim3(n_frames), dim3(1024), 0, st, c->parent, c->final_label, c->frame_runs, c->n_labels,
+                       g.cap);
+    if (d_labels) {
+        const long long quads = nrows * ((g.W + 3) / 4);
+        hipLaunchKernelGGL(lm_k_write_labels, dim3(lm_blocks(quads, 256)), dim3(256), 0, st, c->bits, c->starts, c->prefix,
+                           c->rowoff, c->final_label, d_labels, g.W, g.H, g.WW, g.cap, nrows);
+    }
+    LM_HIP(hipGetLastError());
+    c->last_batch = n_frames;
+    return LM_OK;
+}
+
+extern "C" int lm_label_counts(LmCtx* c, int32_t* h_counts, void* stream)
+{
+    if (!c || !h_counts || c->last_batch <= 0) { lm_set_error("lm_label_counts: no labelled batch"); return LM_ERR_STATE; }
+    LM_HIP(hipMemcpyAsync(h_counts, c->n_labels, (size_t)c->last_batch * sizeof(int32_t), hipMemcpyDeviceToHost,
+                          (hipStream_t)stream));
+    LM_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return LM_OK;
+}
+
+extern "C" int lm_cc_stats_batch(LmCtx* c, void* stream)
+{
+    if (!c || c->last_batch <= 0) { lm_set_error("lm_cc_stats_batch: no labelled batch"); return LM_ERR_STATE; }
+    const LmGeom g = c->g;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = c->last_batch;
+    const long long nrows = (long long)B * g.H;
+    hipLaunchKernelGGL(lm_k_stats_init, dim3(32, B), dim3(256), 0, st, c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x,
+                       c->st_count, c->n_labels, g.W, g.H, g.cap);
+    hipLaunchKernelGGL(lm_k_stats, dim3(lm_blocks(nrows * g.WW, 256)), dim3(256), 0, st, c->bits, c->starts, c->prefix,
+                       c->rowoff, c->final_label, c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x, c->st_count, g.WW, g.H,
+                       g.cap, nrows);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+extern "C" int lm_cc_stats_read(LmCtx* c, int frame, int n, int32_t* h_mins_y, int32_t* h_maxs_y, int32_t* h_mins_x,
+                                int32_t* h_maxs_x, int32_t* h_counts, void* stream)
+{
+    if (!c || frame < 0 || frame >= c->last_batch || n < 0 || n > c->g.cap) {
+        lm_set_error("lm_cc_stats_read: bad arguments");
+        return LM_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t off = (size_t)frame * c->g.cap, nb = (size_t)n * sizeof(int32_t);
+    if (n > 0) {
+        if (h_mins_y) LM_HIP(hipMemcpyAsync(h_mins_y, c->st_min_y + off, nb, hipMemcpyDeviceToHost, st));
+        if (h_maxs_y) LM_HIP(hipMemcpyAsync(h_maxs_y, c->st_max_y + off, nb, hipMemcpyDeviceToHost, st));
+        if (h_mins_x) LM_HIP(hipMemcpyAsync(h_mins_x, c->st_min_x + off, nb, hipMemcpyDeviceToHost, st));
+        if (h_maxs_x) LM_HIP(hipMemcpyAsync(h_maxs_x, c->st_max_x + off, nb, hipMemcpyDeviceToHost, st));
+        if (h_counts) LM_HIP(hipMemcpyAsync(h_counts, c->st_count + off, nb, hipMemcpyDeviceToHost, st));
+    }
+    LM_HIP(hipStreamSynchronize(st));
+    return LM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-pointer convenience + the reference's own export
+// ------------------------------------------------------------------------------------------------
+static LmCtx* g_host_ctx = nullptr;
+
+static LmCtx* lm_host_ctx(int width, int height)
+{
+    if (g_host_ctx && (g_host_ctx->g.W != width || g_host_ctx->g.H != height)) {
+        lm_ctx_destroy(g_host_ctx);
+        g_host_ctx = nullptr;
+    }
+    if (!g_host_ctx) g_host_ctx = lm_ctx_create(width, height, 1);
+    return g_host_ctx;
+}
+
+static int lm_stage(LmCtx* c, size_t px)
+{
+    if (c->stage_px >= px) return LM_OK;
+    if (c->stage_u8) (void)hipFree(c->stage_u8);
+    if (c->stage_i32) (void)hipFree(c->stage_i32);
+    if (c->stage_f32) (void)hipFree(c->stage_f32);
+    c->stage_u8 = nullptr; c->stage_i32 = nullptr; c->stage_f32 = nullptr; c->stage_px = 0;
+    if (lm_alloc(&c->stage_u8, px) || lm_alloc(&c->stage_i32, px) || lm_alloc(&c->stage_f32, px)) return LM_ERR_HIP;
+    c->stage_px = px;
+    return LM_OK;
+}
+
+extern "C" int lm_label_host(const uint8_t* h_img, int width, int height, int32_t* h_labels)
+{
+    if (!h_img || !h_labels || width <= 0 || height <= 0) { lm_set_error("lm_label_host: bad arguments"); return -LM_ERR_ARG; }
+    LmCtx* c = lm_host_ctx(width, height);
+    if (!c) return -LM_ERR_HIP;
+    const size_t px = (size_t)width * height;
+    if (lm_stage(c, px)) return -LM_ERR_HIP;
+    if (hipMemcpy(c->stage_u8, h_img, px, hipMemcpyHostToDevice) != hipSuccess) { lm_set_error("lm_label_host: H2D failed"); return -LM_ERR_HIP; }
+    int rc = lm_label_batch(c, c->stage_u8, 1, c->stage_i32, nullptr);
+    if (rc) return -rc;
+    int32_t n = 0;
+    rc = lm_label_counts(c, &n, nullptr);
+    if (rc) return -rc;
+    if (hipMemcpy(h_labels, c->stage_i32, px * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { lm_set_error("lm_label_host: D2H failed"); return -LM_ERR_HIP; }
+    return n;
+}
+
+// accessmath_lib.c:357-413.  Always returns 0 like the reference (callers ignore the value, labeler.py:166);
+// a failure is reported through lm_last_error() and leaves the outputs in their initial state.
+extern "C" int CC_AgeBoundaries(int* labels, float* ages, int width, int height, int count_labels, int* out_mins_y,
+                                int* out_maxs_y, int* out_mins_x, int* out_maxs_x, int* out_counts, float* output_age)
+{
+    if (count_labels <= 0 || width <= 0 || height <= 0) return 0;
+    LmCtx* c = lm_host_ctx(width, height);
+    const size_t px = (size_t)width * height;
+    if (!c || lm_stage(c, px)) return 0;
+    const int n = count_labels;
+    int32_t* d_out = nullptr;     // 6 arrays of n
+    if (hipMalloc((void**)&d_out, (size_t)n * 7 * sizeof(int32_t)) != hipSuccess) { lm_set_error("CC_AgeBoundaries: hipMalloc failed"); return 0; }
+    int32_t *mny = d_out, *mxy = d_out + n, *mnx = d_out + 2 * (size_t)n, *mxx = d_out + 3 * (size_t)n, *cnt = d_out + 4 * (size_t)n,
+            *ageb = d_out + 5 * (size_t)n;
+    float* agef = (float*)(d_out + 6 * (size_t)n);
+    bool ok = hipMemcpy(c->stage_i32, labels, px * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && ages) ok = hipMemcpy(c->stage_f32, ages, px * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(lm_k_ab_init, dim3(lm_blocks(n, 256)), dim3(256), 0, (hipStream_t)0, mny, mxy, mnx, mxx, cnt, ageb,
+                           width, height, n);
+        hipLaunchKernelGGL(lm_k_ab_scan, dim3(lm_blocks((long long)px, 256)), dim3(256), 0, (hipStream_t)0, c->stage_i32,
+                           ages ? c->stage_f32 : (const float*)nullptr, width, height, n, mny, mxy, mnx, mxx, cnt, ageb);
+        hipLaunchKernelGGL(lm_k_ab_finish, dim3(lm_blocks(n, 256)), dim3(256), 0, (hipStream_t)0, ageb, agef, n);
+        const size_t nb = (size_t)n * sizeof(int32_t);
+        ok = hipMemcpy(out_mins_y, mny, nb, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(out_maxs_y, mxy, nb, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(out_mins_x, mnx, nb, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(out_maxs_x, mxx, nb, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(out_counts, cnt, nb, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(output_age, agef, nb, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (!ok) lm_set_error("CC_AgeBoundaries: device copy/launch failed");
+    (void)hipFree(d_out);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stream
+// ------------------------------------------------------------------------------------------------
+extern "C" void lm_stream_destroy(LmStream* s)
+{
+    if (!s) return;
+    void* ptrs[] = {s->cc, s->assign, s->frame_cc_off, s->crop, s->uniq_cc, s->uniq_box16, s->uniq_last, s->active, s->counters,
+                    s->batch_cc_base, s->batch_word_base};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete s;
+}
+
+extern "C" int lm_stream_reset(LmStream* s, void* stream)
+{
+    if (!s) { lm_set_error("lm_stream_reset: null stream"); return LM_ERR_ARG; }
+    LM_HIP(hipMemsetAsync(s->counters, 0, sizeof(LmCounters), (hipStream_t)stream));
+    LM_HIP(hipMemsetAsync(s->frame_cc_off, 0, sizeof(long long), (hipStream_t)stream));
+    s->frames_pushed = 0;
+    return LM_OK;
+}
+
+extern "C" LmStream* lm_stream_create(LmCtx* ctx, int max_frames, int64_t max_ccs, int64_t max_crop_words, int max_uniques,
+                                      double min_recall, double min_precision, int max_gap, int min_pixels)
+{
+    if (!ctx || max_frames <= 0 || max_ccs <= 0 || max_crop_words <= 0 || max_uniques <= 0) {
+        lm_set_error("lm_stream_create: bad arguments");
+        return nullptr;
+    }
+    LmStream* s = new LmStream();
+    memset(s, 0, sizeof(*s));
+    s->ctx = ctx;
+    s->cap_frames = max_frames;
+    s->cap_cc = max_ccs;
+    s->cap_words = (unsigned long long)max_crop_words;
+    s->cap_uniq = max_uniques;
+    s->min_recall = min_recall;
+    s->min_precision = min_precision;
+    s->max_gap = max_gap;
+    s->min_pixels = min_pixels;
+    int rc = LM_OK;
+    rc |= lm_alloc(&s->cc, (size_t)max_ccs);
+    rc |= lm_alloc(&s->assign, (size_t)max_ccs);
+    rc |= lm_alloc(&s->frame_cc_off, (size_t)max_frames + 1);
+    rc |= lm_alloc(&s->crop, (size_t)max_crop_words);
+    rc |= lm_alloc(&s->uniq_cc, (size_t)max_uniques);
+    rc |= lm_alloc(&s->uniq_box16, (size_t)max_uniques);
+    rc |= lm_alloc(&s->uniq_last, (size_t)max_uniques);
+    rc |= lm_alloc(&s->active, (size_t)max_uniques);
+    rc |= lm_alloc(&s->counters, (size_t)1);
+    rc |= lm_alloc(&s->batch_cc_base, (size_t)ctx->max_batch);
+    rc |= lm_alloc(&s->batch_word_base, (size_t)ctx->max_batch);
+    if (rc == LM_OK) rc = lm_stream_reset(s, nullptr);
+    if (rc == LM_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = LM_ERR_HIP;
+    if (rc != LM_OK) {
+        lm_stream_destroy(s);
+        return nullptr;
+    }
+    return s;
+}
+
+extern "C" int lm_stream_push(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* d_labels, void* stream)
+{
+    if (!s || !d_binary || n_frames <= 0) { lm_set_error("lm_stream_push: bad arguments"); return LM_ERR_ARG; }
+    LmCtx* c = s->ctx;
+    const LmGeom g = c->g;
+    hipStream_t st = (hipStream_t)stream;
+    if (s->frames_pushed + n_frames > s->cap_frames) {
+        lm_set_error("lm_stream_push: stream holds %d frames, capacity %d", s->frames_pushed, s->cap_frames);
+        return LM_ERR_CAPACITY;
+    }
+    const size_t px = (size_t)g.W * g.H;
+    for (int done = 0; done < n_frames;) {
+        const int B = (n_frames - done < c->max_batch) ? n_frames - done : c->max_batch;
+        int rc = lm_label_batch(c, d_binary + (size_t)done * px, B, d_labels ? d_labels + (size_t)done * px : nullptr, stream);
+        if (rc) return rc;
+        rc = lm_cc_stats_batch(c, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(lm_k_select, dim3(B), dim3(1024), 0, st, c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x,
+                           c->st_count, c->n_labels, c->kept_label, c->kept_cropoff, c->frame_kept, c->frame_cropwords, g.cap,
+                           s->min_pixels);
+        hipLaunchKernelGGL(lm_k_batch_offsets, dim3(1), dim3(1024), 0, st, c->frame_kept, c->frame_cropwords, B, s->counters,
+                           s->frame_cc_off, s->batch_cc_base, s->batch_word_base, s->cap_cc, s->cap_words, s->cap_frames);
+        hipLaunchKernelGGL(lm_k_emit, dim3(64, B), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff, c->final_label,
+                           c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x, c->st_count, c->kept_label, c->kept_cropoff,
+                           c->frame_kept, s->batch_cc_base, s->batch_word_base, s->cc, s->crop, s->frames_pushed, g.WW, g.H,
+                           g.cap);
+        for (int b = 0; b < B; b++) {
+            const int f = s->frames_pushed + b;
+            hipLaunchKernelGGL(lm_k_match, dim3(128), dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, s->uniq_cc,
+                               s->uniq_box16, s->active, s->counters, s->assign, s->min_recall, s->min_precision);
+            hipLaunchKernelGGL(lm_k_update, dim3(1), dim3(1024), 0, st, s->cc, s->frame_cc_off, f, s->uniq_cc, s->uniq_box16,
+                               s->uniq_last, s->active, s->counters, s->assign, s->max_gap, s->cap_uniq);
+        }
+        LM_HIP(hipGetLastError());
+        s->frames_pushed += B;
+        done += B;
+    }
+    return LM_OK;
+}
+
+extern "C" int lm_stream_counters(LmStream* s, int64_t* out, void* stream)
+{
+    if (!s || !out) { lm_set_error("lm_stream_counters: bad arguments"); return LM_ERR_ARG; }
+    LmCounters h;
+    LM_HIP(hipMemcpyAsync(&h, s->counters, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    LM_HIP(hipStreamSynchronize((hipStream_t)stream));
+    out[0] = h.n_frames; out[1] = h.n_cc; out[2] = (int64_t)h.n_words; out[3] = h.n_uniq; out[4] = h.n_active;
+    out[5] = (int64_t)h.tempo_count; out[6] = h.error;
+    if (h.error) {
+        lm_set_error("stream capacity exceeded on device (max_ccs=%lld max_crop_words=%llu max_uniques=%d max_frames=%d)",
+                     s->cap_cc, s->cap_words, s->cap_uniq, s->cap_frames);
+        return h.error;
+    }
+    return LM_OK;
+}
+
+// pack records for the host: 8 x int32 per CC
+__global__ void __launch_bounds__(256) lm_k_pack_records(const LmCcRec* __restrict__ cc, const int32_t* __restrict__ assign,
+                                                         long long n, int32_t* __restrict__ out8, long long* __restrict__ crop_off)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const LmCcRec r = cc[i];
+        int32_t* o = out8 + i * 8;
+        o[0] = r.cc_id; o[1] = r.min_x; o[2] = r.max_x; o[3] = r.min_y; o[4] = r.max_y; o[5] = r.size; o[6] = r.frame;
+        o[7] = assign[i];
+        if (crop_off) crop_off[i] = (long long)r.crop_off;
+    }
+}
+
+extern "C" int lm_stream_read(LmStream* s, int32_t* h_rec, int64_t* h_frame_off, int64_t* h_crop_off, uint32_t* h_crop,
+                              int32_t* h_active, void* stream)
+{
+    if (!s) { lm_set_error("lm_stream_read: null stream"); return LM_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    int64_t k[7];
+    int rc = lm_stream_counters(s, k, stream);
+    if (rc) return rc;
+    const long long n_cc = k[1];
+    if ((h_rec || h_crop_off) && n_cc > 0) {
+        int32_t* d_rec = nullptr;
+        long long* d_off = nullptr;
+        LM_HIP(hipMalloc((void**)&d_rec, (size_t)n_cc * 8 * sizeof(int32_t)));
+        if (hipMalloc((void**)&d_off, (size_t)n_cc * sizeof(long long)) != hipSuccess) { (void)hipFree(d_rec); lm_set_error("lm_stream_read: hipMalloc failed"); return LM_ERR_HIP; }
+        hipLaunchKernelGGL(lm_k_pack_records, dim3(lm_blocks(n_cc, 256)), dim3(256), 0, st, s->cc, s->assign, n_cc, d_rec, d_off);
+        hipError_t e1 = hipSuccess, e2 = hipSuccess;
+        if (h_rec) e1 = hipMemcpyAsync(h_rec, d_rec, (size_t)n_cc * 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (h_crop_off) e2 = hipMemcpyAsync(h_crop_off, d_off, (size_t)n_cc * sizeof(long long), hipMemcpyDeviceToHost, st);
+        hipError_t e3 = hipStreamSynchronize(st);
+        (void)hipFree(d_rec);
+        (void)hipFree(d_off);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { lm_set_error("lm_stream_read: record copy failed"); return LM_ERR_HIP; }
+    }
+    if (h_frame_off) LM_HIP(hipMemcpyAsync(h_frame_off, s->frame_cc_off, (size_t)(k[0] + 1) * sizeof(long long), hipMemcpyDeviceToHost, st));
+    if (h_crop && k[2] > 0) LM_HIP(hipMemcpyAsync(h_crop, s->crop, (size_t)k[2] * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (h_active && k[4] > 0) LM_HIP(hipMemcpyAsync(h_active, s->active, (size_t)k[4] * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    LM_HIP(hipStreamSynchronize(st));
+    return LM_OK;
+}

@@ -1,0 +1,437 @@
+// lm_cc_kernels.hip -- per-frame connected-component path on gfx950 (hand-written HIP).
+//
+// Replaces, for a batch of frames resident in HBM:
+//   scipy.ndimage.label(content)                        AccessMath/preprocessing/content/labeler.py:126
+//   CC_AgeBoundaries(labels, ages, ...)                 accessmath_lib.c:357-413
+//   the per-CC crop loop / MIN_CC_PIXELS filter         labeler.py:171-189
+//   sigmoid -> *255 -> trunc -> >=128 -> 255-x          lecturenet_v1/FCN_lecturenet.py:452,461-467 +
+//                                                       video_worker/FCN_lecturenet_binarizer.py:54
+// (paths relative to /root/reference/ACCESS2021_release).
+//
+// Design: the frame is bit-packed once (1 B/px read), all connectivity work happens on
+// horizontal RUNS found with bit tricks on the 1-bit image (259 KB per 1080p frame, L2 resident), and
+// the int32 label image is written exactly once (4 B/px) -- the algorithmic 5 B/px of the labelling
+// roofline.  No provisional label image ever touches HBM.
+#include "lm_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// K0: fp32 logits -> inverted binary uint8 {0,255}
+// binary = ((uint8)(sigmoid(x) * 255.0f) >= thr) ? 255 : 0 ; out = 255 - binary
+// sigmoid(x) = 1 / (1 + exp(-x)) in fp32; see DESIGN.md "threshold edge" for the ulp discussion.
+// ------------------------------------------------------------------------------------------------
+LM_DEV unsigned lm_thr_px(float x, int thr)
+{
+    float s = 1.0f / (1.0f + expf(-x));
+    float v = s * 255.0f;
+    unsigned u = (unsigned)v;            // truncation, v in [0, 255]
+    return (u >= (unsigned)thr) ? 0u : 255u;   // already inverted
+}
+
+__global__ void __launch_bounds__(256) lm_k_threshold_invert(const float* __restrict__ logits,
+                                                             uint8_t* __restrict__ out, long long n, int thr)
+{
+    long long stride = (long long)gridDim.x * blockDim.x;
+    long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long n4 = n >> 2;
+    const bool aligned = ((((uintptr_t)logits) & 15) == 0) && ((((uintptr_t)out) & 3) == 0);
+    if (aligned) {
+        for (; i4 < n4; i4 += stride) {
+            float4 v = *(const float4*)(logits + i4 * 4);
+            unsigned r = lm_thr_px(v.x, thr) | (lm_thr_px(v.y, thr) << 8) | (lm_thr_px(v.z, thr) << 16) |
+                         (lm_thr_px(v.w, thr) << 24);
+            *(unsigned*)(out + i4 * 4) = r;
+        }
+        long long tail = n4 * 4 + ((long long)blockIdx.x * blockDim.x + threadIdx.x);
+        if (tail < n) out[tail] = (uint8_t)lm_thr_px(logits[tail], thr);
+    } else {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+            out[i] = (uint8_t)lm_thr_px(logits[i], thr);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: uint8 image -> bit mask. One thread per 16-pixel chunk (one 16-B load -> one 2-B store).
+// ------------------------------------------------------------------------------------------------
+LM_DEV unsigned lm_nz_nibble(unsigned d)
+{
+    // bit0 of every byte := OR of the byte's bits, then gather the four bits into a nibble
+    d |= d >> 4;
+    d |= d >> 2;
+    d |= d >> 1;
+    d &= 0x01010101u;
+    return (d * 0x01020408u) >> 24 & 0xFu;
+}
+
+__global__ void __launch_bounds__(256) lm_k_pack(const uint8_t* __restrict__ img, uint16_t* __restrict__ bits16,
+                                                 int W, long long nrows, int chunks_per_row)
+{
+    long long total = nrows * chunks_per_row;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    const bool rows_aligned = ((W & 15) == 0) && ((((uintptr_t)img) & 15) == 0);
+    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += stride) {
+        long long row = gid / chunks_per_row;
+        int ch = (int)(gid - row * chunks_per_row);
+        int x = ch * 16;
+        unsigned m = 0;
+        if (x < W) {
+            const uint8_t* p = img + row * W + x;
+            if (rows_aligned) {   // x + 16 <= W is implied by W % 16 == 0
+                uint4 v = *(const uint4*)p;
+                m = lm_nz_nibble(v.x) | (lm_nz_nibble(v.y) << 4) | (lm_nz_nibble(v.z) << 8) | (lm_nz_nibble(v.w) << 12);
+            } else {
+                int lim = W - x < 16 ? W - x : 16;
+                for (int i = 0; i < lim; i++) m |= (unsigned)(p[i] != 0) << i;
+            }
+        }
+        bits16[gid] = (uint16_t)m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: per row: run-start masks, per-word exclusive prefix of run-start counts, runs per row.
+// One wave per row (lanes = 64-bit words).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) lm_k_rowscan(const uint64_t* __restrict__ bits, uint64_t* __restrict__ starts,
+                                                    uint16_t* __restrict__ prefix, uint32_t* __restrict__ row_runs,
+                                                    int WW, long long nrows)
+{
+    const int lane = lm_lane();
+    long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long row = wave; row < nrows; row += nwaves) {
+        unsigned running = 0;
+        unsigned long long carry = 0;
+        for (int w0 = 0; w0 < WW; w0 += 64) {
+            int w = w0 + lane;
+            unsigned long long b = (w < WW) ? bits[row * WW + w] : 0ull;
+            unsigned long long prevtop = __shfl_up(b >> 63, 1);
+            if (lane == 0) prevtop = carry;
+            unsigned long long s = b & ~((b << 1) | prevtop);
+            unsigned c = (unsigned)__popcll(s);
+            unsigned incl = lm_wave_incl_scan(c);
+            if (w < WW) {
+                starts[row * WW + w] = s;
+                prefix[row * WW + w] = (uint16_t)(running + incl - c);
+            }
+            carry = __shfl(b >> 63, 63);
+            running += __shfl(incl, 63);
+        }
+        if (lane == 0) row_runs[row] = running;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: per frame: exclusive scan of runs-per-row -> rowoff (frame-relative), frame_runs; parent[i] = i.
+// One block per frame.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) lm_k_frame_rowoff(const uint32_t* __restrict__ row_runs,
+                                                          uint32_t* __restrict__ rowoff, int32_t* __restrict__ frame_runs,
+                                                          int32_t* __restrict__ parent, int H, int cap)
+{
+    const int b = blockIdx.x;
+    unsigned carry = 0;
+    for (int base = 0; base < H; base += 1024) {
+        int r = base + (int)threadIdx.x;
+        unsigned v = (r < H) ? row_runs[(long long)b * H + r] : 0u;
+        unsigned tot;
+        unsigned ex = lm_block_excl_scan<1024>(v, &tot);
+        if (r < H) rowoff[(long long)b * H + r] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) frame_runs[b] = (int32_t)carry;
+    int32_t* par = parent + (long long)b * cap;
+    for (unsigned i = threadIdx.x; i < carry; i += 1024) par[i] = (int32_t)i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: unions between vertically adjacent runs. One thread per (row, word).
+// ------------------------------------------------------------------------------------------------
+LM_DEV int lm_find(const int32_t* parent, int x)
+{
+    // stale reads are harmless: parents only ever move to smaller ids of the same set
+    int p = parent[x];
+    while (p != x) {
+        x = p;
+        p = parent[x];
+    }
+    return x;
+}
+
+LM_DEV void lm_union(int32_t* parent, int a, int b)
+{
+    for (;;) {
+        a = lm_find(parent, a);
+        b = lm_find(parent, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        int old = atomicMin(&parent[a], b);     // device-scope RMW: coherent across XCDs
+        if (old == a) return;                   // a was a root and now hangs under b
+        a = old;                                // a had been re-parented meanwhile: merge that tree with b too
+    }
+}
+
+__global__ void __launch_bounds__(256) lm_k_union(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
+                                                  const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
+                                                  int32_t* __restrict__ parent, int WW, int H, int cap, long long nrows)
+{
+    long long total = nrows * WW;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += stride) {
+        long long row = gid / WW;
+        int w = (int)(gid - row * WW);
+        int y = (int)(row % H);
+        if (y == 0) continue;
+        unsigned long long cur = bits[gid];
+        if (!cur) continue;
+        unsigned long long up = bits[gid - WW];
+        unsigned long long v = cur & up;
+        if (!v) continue;
+        unsigned long long carry = 0;
+        if (w > 0) carry = (bits[gid - 1] & bits[gid - WW - 1]) >> 63;
+        unsigned long long ps = v & ~((v << 1) | carry);   // first column of every distinct (run, upper run) contact
+        if (!ps) continue;
+        int32_t* par = parent + (row / H) * cap;
+        const unsigned long long s_cur = starts[gid], s_up = starts[gid - WW];
+        const int base_cur = (int)rowoff[row] + (int)prefix[gid] - 1;
+        const int base_up = (int)rowoff[row - 1] + (int)prefix[gid - WW] - 1;
+        while (ps) {
+            int p = __ffsll((long long)ps) - 1;
+            ps &= ps - 1;
+            unsigned long long m = lm_lowmask_incl(p);
+            int a = base_cur + __popcll(s_cur & m);
+            int b = base_up + __popcll(s_up & m);
+            lm_union(par, a, b);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: per frame: flatten the forest, number the roots in run order (== raster order of first pixel),
+// give every run its final 1-based label.  One block per frame.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) lm_k_resolve(int32_t* __restrict__ parent, int32_t* __restrict__ final_label,
+                                                     const int32_t* __restrict__ frame_runs, int32_t* __restrict__ n_labels,
+                                                     int cap)
+{
+    const int b = blockIdx.x;
+    int32_t* par = parent + (long long)b * cap;
+    int32_t* fin = final_label + (long long)b * cap;
+    const int n = frame_runs[b];
+    unsigned carry = 0;
+    for (int base = 0; base < n; base += 1024) {
+        int i = base + (int)threadIdx.x;
+        unsigned is_root = 0;
+        if (i < n) {
+            int r = lm_find(par, i);
+            par[i] = r;
+            is_root = (r == i);
+        }
+        unsigned tot;
+        unsigned ex = lm_block_excl_scan<1024>(is_root, &tot);
+        if (is_root) fin[i] = (int32_t)(carry + ex + 1);
+        carry += tot;
+    }
+    if (threadIdx.x == 0) n_labels[b] = (int32_t)carry;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        int r = par[i];
+        if (r != i) fin[i] = fin[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: write the int32 label image. One thread per 4 pixels (one 16-B store).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) lm_k_write_labels(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
+                                                         const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
+                                                         const int32_t* __restrict__ final_label, int32_t* __restrict__ labels,
+                                                         int W, int H, int WW, int cap, long long nrows)
+{
+    const int Q = (W + 3) >> 2;
+    long long total = nrows * Q;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    const bool vec = ((W & 3) == 0) && ((((uintptr_t)labels) & 15) == 0);
+    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += stride) {
+        long long row = gid / Q;
+        int q = (int)(gid - row * Q);
+        int x = q << 2;
+        int w = x >> 6, sh = x & 63;
+        long long rw = row * WW + w;
+        unsigned nib = (unsigned)(bits[rw] >> sh) & 0xFu;
+        int o[4] = {0, 0, 0, 0};
+        if (nib) {
+            const unsigned long long s = starts[rw];
+            const int32_t* fin = final_label + (row / H) * cap;
+            int id = (int)rowoff[row] + (int)prefix[rw] + __popcll(s & lm_lowmask_excl(sh)) - 1;
+            unsigned sn = (unsigned)(s >> sh) & 0xFu;
+            int lab = 0;
+            bool have = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if ((nib >> k) & 1u) {
+                    if ((sn >> k) & 1u) { id++; have = false; }
+                    if (!have) { lab = fin[id]; have = true; }
+                    o[k] = lab;
+                } else {
+                    have = false;
+                }
+            }
+        }
+        int32_t* dst = labels + row * W + x;
+        if (vec) {
+            *(int4*)dst = make_int4(o[0], o[1], o[2], o[3]);
+        } else {
+            for (int k = 0; k < 4 && x + k < W; k++) dst[k] = o[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7: per-label statistics from the runs (CC_AgeBoundaries semantics, ages all-zero on this path).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) lm_k_stats_init(int32_t* __restrict__ st_min_y, int32_t* __restrict__ st_max_y,
+                                                       int32_t* __restrict__ st_min_x, int32_t* __restrict__ st_max_x,
+                                                       int32_t* __restrict__ st_count, const int32_t* __restrict__ n_labels,
+                                                       int W, int H, int cap)
+{
+    const int b = blockIdx.y;
+    const int n = n_labels[b];
+    long long off = (long long)b * cap;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        st_min_y[off + i] = H;
+        st_max_y[off + i] = 0;
+        st_min_x[off + i] = W;
+        st_max_x[off + i] = 0;
+        st_count[off + i] = 0;
+    }
+}
+
+__global__ void __launch_bounds__(256) lm_k_stats(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
+                                                  const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
+                                                  const int32_t* __restrict__ final_label, int32_t* __restrict__ st_min_y,
+                                                  int32_t* __restrict__ st_max_y, int32_t* __restrict__ st_min_x,
+                                                  int32_t* __restrict__ st_max_x, int32_t* __restrict__ st_count, int WW, int H,
+                                                  int cap, long long nrows)
+{
+    long long total = nrows * WW;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += stride) {
+        unsigned long long rem = bits[gid];
+        if (!rem) continue;
+        long long row = gid / WW;
+        int w = (int)(gid - row * WW);
+        int y = (int)(row % H);
+        long long foff = (row / H) * cap;
+        const unsigned long long s = starts[gid];
+        const int32_t* fin = final_label + foff;
+        int id = (int)rowoff[row] + (int)prefix[gid] - 1;
+        bool next_cont = (w + 1 < WW) ? (bits[gid + 1] & 1ull) : false;
+        while (rem) {
+            int lo = __ffsll((long long)rem) - 1;
+            unsigned long long t = ~(rem >> lo);           // zeros where the piece continues
+            int len = t ? (__ffsll((long long)t) - 1) : 64;
+            if (len > 64 - lo) len = 64 - lo;
+            int hi = lo + len - 1;
+            bool is_start = (s >> lo) & 1ull;
+            id += is_start ? 1 : 0;
+            long long cc = foff + fin[id] - 1;
+            atomicAdd(&st_count[cc], len);
+            if (is_start) {
+                atomicMin(&st_min_x[cc], w * 64 + lo);
+                atomicMin(&st_min_y[cc], y);
+                atomicMax(&st_max_y[cc], y);
+            }
+            bool ends = (hi < 63) || !next_cont;
+            if (ends) atomicMax(&st_max_x[cc], w * 64 + hi);
+            rem &= ~(lm_lowmask_incl(hi));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7b: CC_AgeBoundaries from an arbitrary int32 label image (+ fp32 ages): the literal drop-in
+// entry point (labels may come from elsewhere, e.g. is_labeled=True callers, labeler.py:127-130).
+// One thread per pixel quad; out arrays pre-initialised by lm_k_ab_init.
+// Age semantics: exact for non-negative ages (the reference's sentinel is -1; the hot path passes zeros).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) lm_k_ab_init(int32_t* mny, int32_t* mxy, int32_t* mnx, int32_t* mxx, int32_t* cnt,
+                                                    int32_t* age_bits, int W, int H, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        mny[i] = H; mxy[i] = 0; mnx[i] = W; mxx[i] = 0; cnt[i] = 0;
+        age_bits[i] = 0x7fffffff;   // "no pixel seen"; float bit patterns of ages >= 0 order like ints
+    }
+}
+
+__global__ void __launch_bounds__(256) lm_k_ab_scan(const int32_t* __restrict__ labels, const float* __restrict__ ages,
+                                                    int W, int H, int n, int32_t* mny, int32_t* mxy, int32_t* mnx,
+                                                    int32_t* mxx, int32_t* cnt, int32_t* age_bits)
+{
+    long long total = (long long)W * H;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int l = labels[i];
+        if (l <= 0 || l > n) continue;   // labels above count_labels would be out of bounds in the reference; ignored here
+        int y = (int)(i / W), x = (int)(i - (long long)y * W);
+        int k = l - 1;
+        atomicMin(&mny[k], y);
+        atomicMax(&mxy[k], y);
+        atomicMin(&mnx[k], x);
+        atomicMax(&mxx[k], x);
+        atomicAdd(&cnt[k], 1);
+        float a = ages ? ages[i] : 0.0f;
+        int ab;
+        memcpy(&ab, &a, 4);
+        if (a >= 0.0f) atomicMin(&age_bits[k], ab);
+    }
+}
+
+__global__ void __launch_bounds__(256) lm_k_ab_finish(const int32_t* age_bits, float* out_age, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int ab = age_bits[i];
+        float a = -1.0f;
+        if (ab != 0x7fffffff) memcpy(&a, &ab, 4);
+        out_age[i] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8: kept-CC selection (count >= min_pixels) + crop layout. One block per frame.
+// Crop of a CC = its pixels as bit rows aligned to ABSOLUTE 32-pixel columns of the frame:
+// words (min_x>>5 .. max_x>>5) for each row min_y..max_y, so two crops AND together without shifts.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) lm_k_select(const int32_t* __restrict__ st_min_y, const int32_t* __restrict__ st_max_y,
+                                                    const int32_t* __restrict__ st_min_x, const int32_t* __restrict__ st_max_x,
+                                                    const int32_t* __restrict__ st_count, const int32_t* __restrict__ n_labels,
+                                                    int32_t* __restrict__ kept_label, uint32_t* __restrict__ kept_cropoff,
+                                                    int32_t* __restrict__ frame_kept, uint32_t* __restrict__ frame_cropwords,
+                                                    int cap, int min_pixels)
+{
+    const int b = blockIdx.x;
+    const long long off = (long long)b * cap;
+    const int n = n_labels[b];
+    unsigned kcarry = 0, wcarry = 0;
+    for (int base = 0; base < n; base += 1024) {
+        int i = base + (int)threadIdx.x;
+        unsigned keep = 0, words = 0;
+        if (i < n && st_count[off + i] >= min_pixels) {
+            keep = 1;
+            unsigned nw = (unsigned)((st_max_x[off + i] >> 5) - (st_min_x[off + i] >> 5) + 1);
+            words = nw * (unsigned)(st_max_y[off + i] - st_min_y[off + i] + 1);
+        }
+        unsigned ktot, wtot;
+        unsigned kex = lm_block_excl_scan<1024>(keep, &ktot);
+        unsigned wex = lm_block_excl_scan<1024>(words, &wtot);
+        if (keep) {
+            kept_label[off + kcarry + kex] = i;
+            kept_cropoff[off + kcarry + kex] = wcarry + wex;
+        }
+        kcarry += ktot;
+        wcarry += wtot;
+    }
+    if (threadIdx.x == 0) {
+        frame_kept[b] = (int32_t)kcarry;
+        frame_cropwords[b] = wcarry;
+    }
+}

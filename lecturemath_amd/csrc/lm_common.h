@@ -1,0 +1,133 @@
+// lm_common.h -- shared declarations of the MI355X-native LectureMath hot path (gfx950 only).
+//
+// Data layout in HBM for one batch of B binary frames of W x H pixels (rows of all frames are
+// contiguous, R = B*H rows):
+//   bits     u64 [R][WW]    bit-packed foreground (bit x&63 of word x>>6; WW = ceil(W/64)), 1 bit / px
+//   starts   u64 [R][WW]    bit set where a horizontal run of foreground begins
+//   prefix   u16 [R][WW]    number of run starts in the row left of the word
+//   rowoff   u32 [R]        number of runs in the frame above the row (frame-relative)
+//   parent   i32 [B][CAP]   union-find forest over runs (frame-relative run ids, root = smallest id)
+//   final    i32 [B][CAP]   1-based scipy-ordered label of every run
+// A "run" is a maximal horizontal segment of foreground pixels; runs are numbered in raster order,
+// so the smallest run id of a component starts at the component's first pixel in raster order and
+// numbering roots in id order reproduces scipy.ndimage.label's numbering (labeler.py:126).
+// CAP = H * ceil(W/2) is the worst case, so there is no overflow path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef LM_HIP_EMULATED
+#define LM_HIP_EMULATED 0
+#endif
+
+typedef float lm_f32x16 __attribute__((ext_vector_type(16)));
+typedef float lm_f32x4 __attribute__((ext_vector_type(4)));
+
+#define LM_OK 0
+#define LM_ERR_ARG 1
+#define LM_ERR_HIP 2
+#define LM_ERR_CAPACITY 3
+#define LM_ERR_STATE 4
+
+#define LM_HIP(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            lm_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return LM_ERR_HIP;                                                             \
+        }                                                                                  \
+    } while (0)
+
+void lm_set_error(const char* fmt, ...);
+
+struct LmGeom {
+    int W, H;
+    int WW;        // 64-bit words per row
+    int cap;       // per-frame capacity of runs / labels: H * ceil(W/2)
+};
+
+// Device workspace for the per-frame CC path (batch of up to max_batch frames).
+struct LmCtx {
+    LmGeom g;
+    int max_batch;
+    int device;
+    // run structures
+    uint64_t* bits;
+    uint64_t* starts;
+    uint16_t* prefix;
+    uint32_t* row_runs;
+    uint32_t* rowoff;
+    int32_t* frame_runs;     // [B]
+    int32_t* parent;         // [B][cap]
+    int32_t* final_label;    // [B][cap]
+    int32_t* n_labels;       // [B]
+    // per-label statistics (CC_AgeBoundaries order), [B][cap] each
+    int32_t* st_min_y;
+    int32_t* st_max_y;
+    int32_t* st_min_x;
+    int32_t* st_max_x;
+    int32_t* st_count;
+    // kept-CC selection staging, [B][cap]
+    int32_t* kept_label;     // label-1 of the k-th kept CC of the frame
+    uint32_t* kept_cropoff;  // frame-relative crop word offset
+    int32_t* frame_kept;     // [B]
+    uint32_t* frame_cropwords;  // [B]
+    int last_batch;          // frames in the most recent lm_label_batch
+    // host-pointer convenience path (drop-in entry points): staging buffers
+    uint8_t* stage_u8;
+    int32_t* stage_i32;
+    float* stage_f32;
+    size_t stage_px;
+};
+
+// ---------------------------------------------------------------- device helpers
+#if LM_HIP_EMULATED
+#define LM_DEV static inline
+#else
+#define LM_DEV __device__ __forceinline__
+#endif
+
+LM_DEV int lm_lane() { return (int)(threadIdx.x & 63); }
+
+template <class T> LM_DEV T lm_wave_incl_scan(T v)
+{
+    int lane = lm_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+template <class T> LM_DEV T lm_wave_sum(T v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// Exclusive scan across a block of BLOCK threads (BLOCK multiple of 64, <= 1024); every thread calls.
+template <int BLOCK> LM_DEV unsigned lm_block_excl_scan(unsigned v, unsigned* total)
+{
+    __shared__ unsigned wsum[BLOCK / 64];
+    __shared__ unsigned wtot;
+    const int lane = lm_lane(), wid = (int)(threadIdx.x >> 6);
+    unsigned incl = lm_wave_incl_scan(v);
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    if (wid == 0) {
+        unsigned t = (lane < BLOCK / 64) ? wsum[lane] : 0u;
+        unsigned ti = lm_wave_incl_scan(t);
+        if (lane < BLOCK / 64) wsum[lane] = ti - t;
+        if (lane == BLOCK / 64 - 1) wtot = ti;
+    }
+    __syncthreads();
+    unsigned res = wsum[wid] + incl - v;
+    *total = wtot;
+    __syncthreads();
+    return res;
+}
+
+LM_DEV uint64_t lm_lowmask_incl(int p) { return (p >= 63) ? ~0ull : ((1ull << (p + 1)) - 1ull); }
+LM_DEV uint64_t lm_lowmask_excl(int p) { return (p <= 0) ? 0ull : ((p >= 64) ? ~0ull : ((1ull << p) - 1ull)); }

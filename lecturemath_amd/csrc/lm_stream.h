@@ -1,0 +1,52 @@
+// lm_stream.h -- device-resident state of one frame stream (steps 02/03 of the pipeline).
+//
+// Everything the temporal stages need stays in HBM for the whole stream (sized for 288 GB):
+//   cc[]        one 32-byte record per kept CC of every frame, in (frame, label) order
+//   crop[]      bit-row crops of those CCs (absolute 32-px column alignment, see lm_cc_kernels.hip K8)
+//   assign[]    unique-CC index every kept CC was matched to (cc_stability_estimator.py:102,117)
+//   uniq_*      the "unique CC" table: first-seen CC, compact box for the candidate scan, last frame seen
+//   active[]    ascending list of uniques still matchable (cc_stability_estimator.py:126-145)
+#pragma once
+#include "lm_common.h"
+
+struct __attribute__((aligned(32))) LmCcRec {
+    int32_t cc_id;      // label-1 in the frame's UNFILTERED labelling (labeler.py:177-185)
+    int32_t size;
+    int16_t min_x, max_x, min_y, max_y;   // inclusive box (frames up to 32767 px per side)
+    unsigned long long crop_off;          // word offset into crop[]
+    int32_t frame;
+    int32_t pad;
+};
+
+struct LmCounters {
+    long long n_cc;
+    unsigned long long n_words;
+    unsigned long long tempo_count;   // bbox-overlapping (cur, unique) pairs tested, cc_stability_estimator.py:85
+    int n_frames;        // frames whose CCs have been emitted
+    int n_matched;       // frames that went through matching
+    int n_uniq;
+    int n_active;
+    int error;           // sticky LM_ERR_* raised on device (capacity)
+    int pad;
+};
+
+struct LmStream {
+    LmCtx* ctx;
+    long long cap_cc;
+    unsigned long long cap_words;
+    int cap_frames, cap_uniq;
+    double min_recall, min_precision;
+    int max_gap, min_pixels;
+    LmCcRec* cc;
+    int32_t* assign;
+    long long* frame_cc_off;    // [cap_frames + 1]
+    uint32_t* crop;
+    int32_t* uniq_cc;           // global cc index of the unique's first-seen CC
+    unsigned long long* uniq_box16;   // min_x | max_x<<16 | min_y<<32 | max_y<<48
+    int32_t* uniq_last;
+    int32_t* active;
+    LmCounters* counters;       // device
+    long long* batch_cc_base;   // [max_batch] staging for emit
+    unsigned long long* batch_word_base;
+    int frames_pushed;          // host-side mirror (frames are pushed in order)
+};

@@ -1,0 +1,200 @@
+"""Thin Python layer over the C ABI: device buffers (torch on the GPU), contexts and frame streams.
+
+PyTorch is plumbing only (device memory + streams); all arithmetic happens in liblecturemath_hip.so.
+With the test-only emulated library (tests/hipemu) "device" memory is host memory and numpy arrays
+stand in for torch tensors; the product never selects that path by itself (see _lib.load).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+class Backend:
+    """Allocates buffers the library can address: CUDA(HIP) tensors, or numpy for the emulated build."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.device = lib.is_device_build
+        if self.device:
+            import torch
+            if not torch.cuda.is_available():
+                raise _lib.LecturemathLibraryError("liblecturemath_hip.so needs a GPU (torch.cuda.is_available() is False)")
+            self.torch = torch
+
+    _T = {np.uint8: "uint8", np.int32: "int32", np.float32: "float32", np.int64: "int64", np.int16: "int16"}
+
+    def empty(self, shape, dtype):
+        if self.device:
+            return self.torch.empty(shape, dtype=getattr(self.torch, self._T[dtype]), device="cuda")
+        return np.empty(shape, dtype=dtype)
+
+    def from_host(self, a):
+        a = np.ascontiguousarray(a)
+        if self.device:
+            return self.torch.from_numpy(a).cuda()
+        return a.copy()
+
+    def to_host(self, x):
+        if self.device:
+            return x.cpu().numpy()
+        return np.asarray(x)
+
+    def stream(self):
+        if self.device:
+            return self.torch.cuda.current_stream().cuda_stream
+        return None
+
+    def synchronize(self):
+        if self.device:
+            self.torch.cuda.synchronize()
+
+
+class FrameLabeler:
+    """Batched scipy.ndimage.label + CC_AgeBoundaries on device frames (labeler.py:126, accessmath_lib.c:357-413)."""
+
+    def __init__(self, width, height, max_batch=1, lib=None):
+        self.lib = lib or _lib.load()
+        self.be = Backend(self.lib)
+        self.width, self.height, self.max_batch = width, height, max_batch
+        self.ctx = self.lib.lm_ctx_create(width, height, max_batch)
+        if not self.ctx:
+            raise _lib.LecturemathError(_lib.LM_ERR_HIP, self.lib.last_error())
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.lm_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def threshold_invert(self, logits, thr=128):
+        """logits: device fp32 array -> device uint8 {0,255}, already inverted (255 = ink)."""
+        out = self.be.empty(tuple(logits.shape), np.uint8)
+        n = int(np.prod(logits.shape))
+        self.lib.check(self.lib.lm_threshold_invert(_lib.ptr(logits), _lib.ptr(out), n, thr, self.be.stream()))
+        return out
+
+    def label(self, binary, want_labels=True):
+        """binary: device uint8 [B,H,W] -> (device int32 labels [B,H,W] or None, host int32 counts [B])."""
+        b = binary.shape[0]
+        assert tuple(binary.shape[1:]) == (self.height, self.width) and b <= self.max_batch
+        labels = self.be.empty((b, self.height, self.width), np.int32) if want_labels else None
+        self.lib.check(self.lib.lm_label_batch(self.ctx, _lib.ptr(binary), b, _lib.ptr(labels), self.be.stream()))
+        counts = np.zeros(b, np.int32)
+        self.lib.check(self.lib.lm_label_counts(self.ctx, counts.ctypes.data, self.be.stream()))
+        return labels, counts
+
+    def stats(self, counts):
+        """CC_AgeBoundaries arrays of every frame of the last batch: list of int32 [5, n] (mins_y, maxs_y, mins_x, maxs_x, counts)."""
+        self.lib.check(self.lib.lm_cc_stats_batch(self.ctx, self.be.stream()))
+        out = []
+        for f, n in enumerate(counts):
+            a = np.zeros((5, int(n)), np.int32)
+            rows = [a[i].ctypes.data if n else None for i in range(5)]
+            self.lib.check(self.lib.lm_cc_stats_read(self.ctx, f, int(n), *rows, self.be.stream()))
+            out.append(a)
+        return out
+
+
+def decode_crop(words, min_x, max_x, min_y, max_y):
+    """bit-row crop (absolute 32-px column alignment) -> uint8 0/255 (h, w) like ConnectedComponent.img."""
+    wx0 = min_x >> 5
+    nw = (max_x >> 5) - wx0 + 1
+    h = max_y - min_y + 1
+    w = np.asarray(words, dtype="<u4").reshape(h, nw)
+    bits = np.unpackbits(w.view(np.uint8).reshape(h, nw * 4), axis=1, bitorder="little")
+    x0 = min_x - wx0 * 32
+    return (bits[:, x0:x0 + (max_x - min_x + 1)] * 255).astype(np.uint8)
+
+
+class FrameStream:
+    """Device-resident CCStabilityEstimator.add_frame state (cc_stability_estimator.py:11-155)."""
+
+    def __init__(self, width, height, max_frames, min_recall=0.85, min_precision=0.85, max_gap=85, min_pixels=20,
+                 max_batch=16, max_ccs=None, max_crop_words=None, max_uniques=None, lib=None):
+        self.labeler = FrameLabeler(width, height, max_batch, lib)
+        self.lib, self.be = self.labeler.lib, self.labeler.be
+        self.width, self.height = width, height
+        px = width * height
+        max_ccs = max_ccs or max_frames * max(px // 256, 64)
+        max_crop_words = max_crop_words or max_frames * max(px // 8, 1024)
+        max_uniques = max_uniques or max_ccs
+        self.handle = self.lib.lm_stream_create(self.labeler.ctx, max_frames, max_ccs, max_crop_words, max_uniques,
+                                                min_recall, min_precision, max_gap, min_pixels)
+        if not self.handle:
+            raise _lib.LecturemathError(_lib.LM_ERR_HIP, self.lib.last_error())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.lm_stream_destroy(self.handle)
+            self.handle = None
+        self.labeler.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self.lib.check(self.lib.lm_stream_reset(self.handle, self.be.stream()))
+
+    def push(self, binary, labels_out=None):
+        """binary: device uint8 [n,H,W] (any n; split into batches internally). Asynchronous."""
+        self.lib.check(self.lib.lm_stream_push(self.handle, _lib.ptr(binary), int(binary.shape[0]), _lib.ptr(labels_out),
+                                               self.be.stream()))
+
+    def counters(self):
+        k = np.zeros(7, np.int64)
+        self.lib.check(self.lib.lm_stream_counters(self.handle, k.ctypes.data, self.be.stream()))
+        return dict(n_frames=int(k[0]), n_cc=int(k[1]), n_crop_words=int(k[2]), n_unique=int(k[3]), n_active=int(k[4]),
+                    tempo_count=int(k[5]))
+
+    def read(self, with_crops=True):
+        """Host copy of the stream: records, frame offsets, crops, active list."""
+        k = self.counters()
+        rec = np.zeros((max(k["n_cc"], 1), 8), np.int32)
+        foff = np.zeros(k["n_frames"] + 1, np.int64)
+        coff = np.zeros(max(k["n_cc"], 1), np.int64)
+        crop = np.zeros(max(k["n_crop_words"], 1), np.uint32) if with_crops else None
+        active = np.zeros(max(k["n_active"], 1), np.int32)
+        self.lib.check(self.lib.lm_stream_read(self.handle, rec.ctypes.data, foff.ctypes.data, coff.ctypes.data,
+                                               crop.ctypes.data if with_crops else None, active.ctypes.data, self.be.stream()))
+        return dict(k, rec=rec[:k["n_cc"]], frame_off=foff, crop_off=coff[:k["n_cc"]], crop=crop, active=active[:k["n_active"]])
+
+    def result(self, with_crops=True):
+        """Same plain-data view the oracle produces (reference attribute names):
+        unique_recs, unique_crops, unique_cc_frames, cc_idx_per_frame, tempo_count, active."""
+        r = self.read(with_crops)
+        rec, foff = r["rec"], r["frame_off"]
+        nu = r["n_unique"]
+        first = np.full(nu, -1, np.int64)
+        frames = [[] for _ in range(nu)]
+        per_frame = []
+        for f in range(r["n_frames"]):
+            lst = []
+            for c in range(foff[f], foff[f + 1]):
+                u = int(rec[c, 7])
+                if first[u] < 0:
+                    first[u] = c
+                frames[u].append((f, int(rec[c, 0]) + 1))
+                lst.append((u, int(rec[c, 0])))
+            per_frame.append(lst)
+        urec = rec[first][:, [1, 2, 3, 4, 5]].copy() if nu else np.zeros((0, 5), np.int32)
+        crops = []
+        if with_crops:
+            for u in range(nu):
+                c = first[u]
+                mnx, mxx, mny, mxy = (int(v) for v in rec[c, 1:5])
+                nwords = ((mxx >> 5) - (mnx >> 5) + 1) * (mxy - mny + 1)
+                o = int(r["crop_off"][c])
+                crops.append(decode_crop(r["crop"][o:o + nwords], mnx, mxx, mny, mxy))
+        return {"width": self.width, "height": self.height, "unique_recs": urec, "unique_crops": crops,
+                "unique_cc_frames": frames, "cc_idx_per_frame": per_frame, "tempo_count": r["tempo_count"],
+                "active": r["active"], "raw": r}

@@ -1,0 +1,98 @@
+"""Parity checks shared by the GPU tests (real HIP library) and the CPU logic tests (emulated build).
+Every check drives the product through its C ABI (lecturemath_amd.device -> ctypes) and compares with
+the committed golden fixtures (reference outputs) and/or the oracle."""
+import json
+import os
+
+import numpy as np
+
+from lecturemath_amd import device
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+STREAMS = ["accumulate_erase", "occluder_return", "short_gap_jitter"]
+
+
+def unrag(arr, off):
+    return [[tuple(int(v) for v in r) for r in arr[off[i]:off[i + 1]]] for i in range(len(off) - 1)]
+
+
+def load_stream(name):
+    g = np.load(os.path.join(GOLD, "g3_stream_%s.npz" % name))
+    spec = json.loads(bytes(g["spec"]).decode())
+    frames = (np.unpackbits(g["frames_packed"], axis=2)[:, :, :spec["w"]] * 255).astype(np.uint8)
+    return g, spec, frames
+
+
+def check_g1_frame(lib, i, g=None):
+    """labels / counts / CC_AgeBoundaries arrays of golden frame i (and of its vertical flip vs the oracle)."""
+    from oracle import cc as occ
+    g = g if g is not None else np.load(os.path.join(GOLD, "g1_label.npz"))
+    img = g["img%d" % i]
+    h, w = img.shape
+    lab = device.FrameLabeler(w, h, 2, lib)
+    try:
+        batch = np.stack([img, img[::-1].copy()])
+        labels, counts = lab.label(lab.be.from_host(batch))
+        labels = lab.be.to_host(labels)
+        assert counts[0] == int(g["n%d" % i])
+        assert labels.dtype == np.int32 and (labels[0] == g["labels%d" % i]).all()
+        l2, n2 = occ.label4(batch[1])
+        assert counts[1] == n2 and (labels[1] == l2).all()
+        st = lab.stats(counts)
+        if counts[0]:
+            assert (st[0] == g["stats%d" % i]).all()
+        if n2:
+            assert (st[1] == np.stack(occ.age_boundaries(l2, None, n2)[:5])).all()
+    finally:
+        lab.close()
+
+
+def state_equal_golden(r, g):
+    assert r["tempo_count"] == int(g["tempo_count"])
+    assert list(r["active"]) == list(g["active"])
+    assert len(r["unique_recs"]) == len(g["unique_recs"]) and (r["unique_recs"] == g["unique_recs"]).all()
+    assert r["unique_cc_frames"] == unrag(g["ucf"], g["ucf_off"])
+    assert r["cc_idx_per_frame"] == unrag(g["cipf"], g["cipf_off"])
+    got = np.concatenate([c.ravel() for c in r["unique_crops"]]) if r["unique_crops"] else np.zeros(0, np.uint8)
+    assert (got == g["unique_crops"]).all()
+
+
+def state_equal_oracle(r, o):
+    assert r["tempo_count"] == o["tempo_count"]
+    assert list(r["active"]) == list(o["active"])
+    assert len(r["unique_recs"]) == len(o["unique_recs"]) and (r["unique_recs"] == o["unique_recs"]).all()
+    assert r["unique_cc_frames"] == o["unique_cc_frames"]
+    assert r["cc_idx_per_frame"] == o["cc_idx_per_frame"]
+    for a, b in zip(r["unique_crops"], o["unique_crops"]):
+        assert a.shape == b.shape and (a == b).all()
+
+
+def run_stream(lib, frames, w, h, max_gap, max_batch=7, split=None, **kw):
+    fs = device.FrameStream(w, h, len(frames), 0.85, 0.85, max_gap, 20, max_batch=max_batch, lib=lib, **kw)
+    try:
+        dev = fs.be.from_host(frames)
+        if split:
+            fs.push(dev[:split])
+            fs.push(dev[split:])
+        else:
+            fs.push(dev)
+        return fs.result()
+    finally:
+        fs.close()
+
+
+def check_stream_golden(lib, name, max_batch=7):
+    g, spec, frames = load_stream(name)
+    r = run_stream(lib, frames, spec["w"], spec["h"], spec["gap2"], max_batch=max_batch, split=len(frames) // 2)
+    state_equal_golden(r, g)
+
+
+def check_stream_oracle(lib, frames, max_gap, max_batch=5):
+    from oracle import cc as occ
+    h, w = frames[0].shape
+    st = occ.Stability(w, h, 0.85, 0.85, max_gap)
+    for f in frames:
+        st.add_frame(f)
+    r = run_stream(lib, np.stack(frames), w, h, max_gap, max_batch=max_batch)
+    state_equal_oracle(r, st.result())
+    return r

@@ -1,0 +1,93 @@
+"""GPU parity tests proper: the gfx950 library, through the C ABI, against the reference's golden vectors
+(tests/golden, produced by running the reference) and against the oracle on seeded inputs."""
+import os
+
+import numpy as np
+import pytest
+
+import lm_checks
+from lecturemath_amd import device, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("i", range(18))
+def test_label_stats_golden(hip_lib, oracle_built, i):
+    lm_checks.check_g1_frame(hip_lib, i)
+
+
+def test_threshold_golden(hip_lib):
+    g = np.load(os.path.join(lm_checks.GOLD, "g6_threshold.npz"))
+    lab = device.FrameLabeler(96, 64, 1, hip_lib)
+    out = lab.be.to_host(lab.threshold_invert(lab.be.from_host(g["logits"])))
+    far = np.abs(g["logits"] - 0.01569) > 1e-4
+    assert (out[far] == g["expected"][far]).all()
+    # pixels within 1e-4 of the decision edge: device expf vs torch CPU sigmoid may round differently
+    assert int((out != g["expected"]).sum()) <= 4
+    lab.close()
+
+
+@pytest.mark.parametrize("name", lm_checks.STREAMS)
+def test_stream_golden(hip_lib, name):
+    lm_checks.check_stream_golden(hip_lib, name, max_batch=16)
+
+
+def test_stream_vs_oracle_random_noise(hip_lib, oracle_built):
+    rng = np.random.default_rng(11)
+    base = (rng.random((120, 200)) < 0.5)
+    frames = []
+    for t in range(12):
+        flip = rng.random(base.shape) < 0.002
+        base = base ^ flip
+        frames.append((base * 255).astype(np.uint8))
+    lm_checks.check_stream_oracle(hip_lib, frames, max_gap=3, max_batch=4)
+
+
+def test_full_size_1080p_label_vs_oracle(hip_lib, oracle_built):
+    """BASELINE.json config-1 style frame at the full 1920x1080: bit-exact labels, counts, stats."""
+    frames = np.stack([synth.glyph_mask(1080, 1920, 1500, seed=20211), synth.glyph_mask(1080, 1920, 4000, seed=7)])
+    lab = device.FrameLabeler(1920, 1080, 2, hip_lib)
+    labels, counts = lab.label(lab.be.from_host(frames))
+    labels = lab.be.to_host(labels)
+    st = lab.stats(counts)
+    for b in range(2):
+        l, n = oracle_built.label4(frames[b])
+        assert counts[b] == n and (labels[b] == l).all()
+        assert (st[b] == np.stack(oracle_built.age_boundaries(l, None, n)[:5])).all()
+    lab.close()
+
+
+def test_full_size_properties_4k(hip_lib):
+    """3840x2160 (BASELINE.json config 5 size): size-independent properties instead of the oracle:
+    relabelling the foreground mask of the labels reproduces them (idempotence), counts sum to the ink."""
+    import torch
+    f = synth.glyph_mask(2160, 3840, 6000, seed=3)
+    lab = device.FrameLabeler(3840, 2160, 1, hip_lib)
+    d = lab.be.from_host(f[None])
+    labels, counts = lab.label(d)
+    st = lab.stats(counts)[0]
+    assert int(st[4].sum()) == int((f > 0).sum())
+    again, counts2 = lab.label(((labels > 0) * 255).to(torch.uint8))
+    assert counts2[0] == counts[0] and bool((again == labels).all())
+    lab.close()
+
+
+def test_drop_in_cc_age_boundaries(hip_lib, oracle_built):
+    rng = np.random.default_rng(3)
+    img = ((rng.random((270, 480)) < 0.4) * 255).astype(np.uint8)
+    labels, n = oracle_built.label4(img)
+    ages = rng.random(img.shape).astype(np.float32)
+    outs = [np.zeros(n, np.int32) for _ in range(5)]
+    oa = np.zeros(n, np.float32)
+    rc = hip_lib.CC_AgeBoundaries(labels.ctypes.data, ages.ctypes.data, 480, 270, n, *[o.ctypes.data for o in outs], oa.ctypes.data)
+    assert rc == 0
+    for a, b in zip(outs + [oa], oracle_built.age_boundaries(labels, ages, n)):
+        assert (a == b).all()
+
+
+def test_label_host(hip_lib, oracle_built):
+    img = synth.glyph_mask(270, 480, 200, seed=9)
+    out = np.zeros(img.shape, np.int32)
+    n = hip_lib.lm_label_host(img.ctypes.data, 480, 270, out.ctypes.data)
+    l, m = oracle_built.label4(img)
+    assert n == m and (out == l).all()

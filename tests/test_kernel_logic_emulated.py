@@ -1,0 +1,69 @@
+"""CPU: kernel LOGIC of the product's HIP sources, compiled for the CPU by the test-only fiber emulator
+(tests/hipemu).  This is a development aid for a GPU-less container -- the parity tests proper are the
+gpu-marked ones, which run the same checks through the real gfx950 library."""
+import os
+
+import numpy as np
+import pytest
+
+import lm_checks
+from lecturemath_amd import device, synth
+
+
+@pytest.mark.parametrize("i", range(18))
+def test_label_stats_golden(emu_lib, oracle_built, i):
+    lm_checks.check_g1_frame(emu_lib, i)
+
+
+def test_threshold_golden(emu_lib):
+    g = np.load(os.path.join(lm_checks.GOLD, "g6_threshold.npz"))
+    lab = device.FrameLabeler(96, 64, 1, emu_lib)
+    out = lab.threshold_invert(g["logits"])
+    far = np.abs(g["logits"] - 0.01569) > 1e-4
+    assert (out[far] == g["expected"][far]).all()
+    assert int((out != g["expected"]).sum()) <= 2
+    lab.close()
+
+
+def test_stream_vs_oracle_small(emu_lib, oracle_built):
+    frames = list(synth.binary_stream(24, 96, 160, seed=5, glyphs_per_add=4, erase_every=9, jitter_p=0.4, occluder=True,
+                                      max_ext=16))
+    r = lm_checks.check_stream_oracle(emu_lib, frames, max_gap=5, max_batch=5)
+    assert len(r["unique_recs"]) > 20
+
+
+def test_stream_golden_short_gap(emu_lib):
+    lm_checks.check_stream_golden(emu_lib, "short_gap_jitter", max_batch=16)
+
+
+def test_drop_in_cc_age_boundaries(emu_lib, oracle_built):
+    rng = np.random.default_rng(3)
+    img = ((rng.random((40, 75)) < 0.45) * 255).astype(np.uint8)
+    labels, n = oracle_built.label4(img)
+    ages = rng.random(img.shape).astype(np.float32)
+    outs = [np.zeros(n, np.int32) for _ in range(5)]
+    oa = np.zeros(n, np.float32)
+    rc = emu_lib.CC_AgeBoundaries(labels.ctypes.data, ages.ctypes.data, 75, 40, n, *[o.ctypes.data for o in outs], oa.ctypes.data)
+    assert rc == 0
+    exp = oracle_built.age_boundaries(labels, ages, n)
+    for a, b in zip(outs + [oa], exp):
+        assert (a == b).all()
+
+
+def test_label_host(emu_lib, oracle_built):
+    img = synth.glyph_mask(70, 130, 30, seed=9)
+    out = np.zeros(img.shape, np.int32)
+    n = emu_lib.lm_label_host(img.ctypes.data, 130, 70, out.ctypes.data)
+    l, m = oracle_built.label4(img)
+    assert n == m and (out == l).all()
+
+
+def test_capacity_error_is_reported(emu_lib):
+    frames = np.stack(list(synth.binary_stream(6, 64, 96, seed=1, glyphs_per_add=6, erase_every=0, max_ext=12)))
+    fs = device.FrameStream(96, 64, 6, max_batch=3, max_ccs=4, max_crop_words=64, lib=emu_lib)
+    fs.push(frames)
+    from lecturemath_amd import _lib
+    with pytest.raises(_lib.LecturemathError) as e:
+        fs.counters()
+    assert e.value.code == _lib.LM_ERR_CAPACITY
+    fs.close()

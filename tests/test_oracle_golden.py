@@ -1,0 +1,92 @@
+"""CPU: the oracle reproduces every golden vector the reference produced (tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import lm_checks
+from lm_checks import GOLD
+
+
+def test_g1_label_stats_crops(oracle_built):
+    occ = oracle_built
+    g = np.load(os.path.join(GOLD, "g1_label.npz"))
+    for i in range(int(g["n"])):
+        img = g["img%d" % i]
+        labels, n = occ.label4(img)
+        assert n == int(g["n%d" % i]) and (labels == g["labels%d" % i]).all()
+        if n:
+            st = occ.age_boundaries(labels, np.zeros(img.shape, np.float32), n)
+            assert (np.stack(st[:5]) == g["stats%d" % i]).all()
+            assert (st[5] == g["ages%d" % i]).all()
+        rec, crops = occ.extract(labels, n)
+        assert (rec == g["rec%d" % i]).all()
+        flat = np.concatenate([c.ravel() for c in crops]) if crops else np.zeros(0, np.uint8)
+        assert (flat == g["crops%d" % i]).all()
+
+
+def test_g2_overlap(oracle_built):
+    occ = oracle_built
+    g = np.load(os.path.join(GOLD, "g2_overlap.npz"))
+    oa = ob = 0
+    for k, row in enumerate(g["boxes"]):
+        a, b = row[:5], row[5:]
+        na = (a[1] - a[0] + 1) * (a[3] - a[2] + 1)
+        nb = (b[1] - b[0] + 1) * (b[3] - b[2] + 1)
+        ca = g["crops_a"][oa:oa + na].reshape(a[3] - a[2] + 1, -1)
+        cb = g["crops_b"][ob:ob + nb].reshape(b[3] - b[2] + 1, -1)
+        oa += na
+        ob += nb
+        m = occ.overlap(a[:4], ca, b[:4], cb)
+        assert m / float(np.int32(a[4])) == g["recall"][k]
+        assert m / float(np.int32(b[4])) == g["precision"][k]
+
+
+@pytest.mark.parametrize("name", lm_checks.STREAMS)
+def test_g3_g4_stream(oracle_built, name):
+    from oracle import grouping as og
+    occ = oracle_built
+    g, spec, frames = lm_checks.load_stream(name)
+    st = occ.Stability(spec["w"], spec["h"], 0.85, 0.85, spec["gap2"])
+    for f in frames:
+        st.add_frame(f)
+    state = st.result()
+    lm_checks.state_equal_golden(state, g)
+    r = og.run_step03(state, max_gap=spec["gap3"])
+    assert r["n_split"] == int(g["n_split"])
+    assert state["unique_cc_frames"] == lm_checks.unrag(g["post_split_ucf"], g["post_split_ucf_off"])
+    assert state["cc_idx_per_frame"] == lm_checks.unrag(g["post_split_cipf"], g["post_split_cipf_off"])
+    assert r["stable_idxs"] == list(g["stable"])
+    assert r["total_intersections"] == int(g["total_intersections"])
+    tflat = [(a, b, np.float64(rc).view(np.int64), np.float64(p).view(np.int64))
+             for a, lst in enumerate(r["time_overlapping_cc"]) for b, rc, p in lst]
+    assert (np.asarray(tflat, np.int64).reshape(-1, 4) == g["time_ov"]).all()
+    aflat = [(a, *t) for a, lst in enumerate(r["all_overlapping_cc"]) for t in lst]
+    assert (np.asarray(aflat, np.int64).reshape(-1, 5) == g["all_ov"]).all()
+    assert [[(m,) for m in grp] for grp in r["cc_groups"]] == lm_checks.unrag(g["groups"], g["groups_off"])
+    assert sorted(r["group_idx_per_cc"].items()) == [tuple(x) for x in g["gid"]]
+    ng = len(r["cc_groups"])
+    assert [[(a,) for a in r["group_ages"][k]] for k in range(ng)] == lm_checks.unrag(g["ages"], g["ages_off"])
+    assert [[(a,) for a in fr] for fr in r["groups_per_frame"]] == lm_checks.unrag(g["gpf"], g["gpf_off"])
+    cflat = [(k, o, d["matched"], d["unmatched"], d["area_union"], d["area_intersection"])
+             for k in sorted(r["conflicts"]) for o, d in r["conflicts"][k].items()]
+    assert (np.asarray(cflat, np.float64).reshape(-1, 6) == g["conflicts"]).all()
+    assert (np.asarray([r["group_boundaries"][k] for k in range(ng)], np.int64).reshape(-1, 4) == g["bounds"]).all()
+    assert [len(r["group_images"][k]) for k in range(ng)] == list(g["gimg_count"])
+    gi = np.concatenate([im.ravel() for k in range(ng) for im in r["group_images"][k]]) if ng else np.zeros(0, np.uint8)
+    assert (gi == g["gimg"]).all()
+    clean = np.stack(r["clean_binary"])
+    assert (np.packbits(clean == 255, axis=2) == g["clean_packed"]).all()
+    other = np.argwhere((clean != 0) & (clean != 255)).astype(np.int32)
+    assert (other == g["clean_other"]).all() and (clean[(clean != 0) & (clean != 255)] == g["clean_other_val"]).all()
+
+
+def test_g6_threshold(oracle_built):
+    g = np.load(os.path.join(GOLD, "g6_threshold.npz"))
+    out = oracle_built.threshold_invert(g["logits"])
+    diff = int((out != g["expected"]).sum())
+    # libm expf vs torch's vectorised sigmoid: only pixels within 1 ulp of the 128/255 edge may differ
+    assert diff <= 2, diff
+    far = np.abs(g["logits"] - 0.01569) > 1e-4
+    assert (out[far] == g["expected"][far]).all()
