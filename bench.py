@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the hot path (binarize-threshold + CC labelling + CC records + temporal matching
+[+ grouping when built]) on a synthetic 1080p stream, per BASELINE.json (configs[2], the configuration the
+metric is quoted on: the synthetic 1080p stream on one MI355X; `--frames 10000` is its full length).
+
+A "step" is one pass of the hot path over one synthetic stream of --frames frames whose fp32 logits are
+already resident in HBM.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
+processes an independent stream of the same shape (the reference's outer loop is over independent
+lectures, console_ui_process.py:121-148), no data-path collective: weak scaling.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     the CC-labelling launch sequence (lm_label_batch: pack, rowscan, rowoff, union, resolve,
+               write_labels), HBM bound: achieved = 5 B/px * W*H * frames_per_launch / mean launch duration,
+               timed live with HIP events on the launching stream inside the timed region
+  cpu_baseline the oracle (C port of the reference path, single thread) on a bounded prefix of the same stream
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+ALGO_BYTES_PER_PX = 5           # 1 B uint8 in + 4 B int32 label out
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--frames", type=int, default=256, help="frames per stream (= per step)")
+    p.add_argument("--height", type=int, default=1080)
+    p.add_argument("--width", type=int, default=1920)
+    p.add_argument("--batch", type=int, default=32, help="frames per labelling launch")
+    p.add_argument("--cpu-frames", type=int, default=200, help="prefix of the stream timed on the CPU oracle (0 = skip)")
+    p.add_argument("--no-labels", action="store_true", help="do not materialise the int32 label image")
+    p.add_argument("--seed", type=int, default=20213)
+    return p.parse_args()
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
+    torch.cuda.set_device(local_rank)
+    from lecturemath_amd import _lib, device, synth
+    lib = _lib.load()
+    assert lib.is_device_build
+
+    H, W, F = a.height, a.width, a.frames
+    # ---- synthetic stream (host, numpy) -> logits resident in HBM
+    t0 = time.time()
+    frames_host = np.stack(list(synth.binary_stream(F, H, W, seed=a.seed + rank)))
+    mask = torch.from_numpy(frames_host).cuda()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + rank)
+    logits = torch.where(mask > 0, -4.0, 4.0).to(torch.float32)
+    logits += (torch.rand(logits.shape, generator=gen, device="cuda", dtype=torch.float32) - 0.5)
+    del mask
+    gen_s = time.time() - t0
+
+    fs = device.FrameStream(W, H, F, 0.85, 0.85, 85, 20, max_batch=a.batch, lib=lib)
+    binary = torch.empty((F, H, W), dtype=torch.uint8, device="cuda")
+    labels = None if a.no_labels else torch.empty((a.batch, H, W), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        fs.reset()
+        lib.check(lib.lm_threshold_invert(logits.data_ptr(), binary.data_ptr(), F * H * W, 128, stream))
+        for f0 in range(0, F, a.batch):
+            n = min(a.batch, F - f0)
+            # the label image of a batch is an output of the labelling kernel; the same buffer is reused per batch
+            lib.check(lib.lm_stream_push(fs.handle, binary[f0:f0 + n].data_ptr(), n,
+                                         labels.data_ptr() if labels is not None else None, stream))
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    k0 = fs.counters()      # also surfaces capacity errors before timing
+    lib.check(lib.lm_ctx_set_profiling(fs.labeler.ctx, 1))
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the labelling launch sequence (events recorded inside the timed region)
+    import ctypes
+    ms, calls, nfr = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    lib.check(lib.lm_ctx_profile_read(fs.labeler.ctx, ctypes.addressof(ms), ctypes.addressof(calls), ctypes.addressof(nfr)))
+    lib.check(lib.lm_ctx_set_profiling(fs.labeler.ctx, 0))
+    k1 = fs.counters()
+    assert k1 == k0, "steps are not reproducible: %r vs %r" % (k0, k1)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    launch_ms = ms.value / max(calls.value, 1)
+    frames_per_launch = nfr.value / max(calls.value, 1)
+    algo_bytes = ALGO_BYTES_PER_PX * W * H * frames_per_launch
+    achieved = algo_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "lm_label_batch[lm_k_pack+lm_k_rowscan+lm_k_frame_rowoff+lm_k_union+lm_k_resolve+lm_k_write_labels]",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None, "launch_ms": round(launch_ms, 4), "frames_per_launch": frames_per_launch,
+                "algorithmic_bytes_per_launch": int(algo_bytes), "label_image_written": labels is not None}
+
+    # ---- CPU baseline: the oracle (C port, 1 thread) on a prefix of the same stream
+    cpu = None
+    if a.cpu_frames > 0:
+        from oracle import cc as occ
+        n = min(a.cpu_frames, F)
+        lg = logits[:n].cpu().numpy()
+        t0 = time.perf_counter()
+        st = occ.Stability(W, H, 0.85, 0.85, 85)
+        for i in range(n):
+            st.add_frame(occ.threshold_invert(lg[i]))
+        cdt = time.perf_counter() - t0
+        cpu = {"value": round(n / cdt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "first %d frames of the same stream: threshold+invert, label, stats, crops, temporal matching "
+                         "(oracle/cc_oracle.c, single thread; host has %d cores)" % (n, os.cpu_count())}
+
+    total_frames = F * a.steps * world
+    out = {
+        "metric": "frames/sec end-to-end binarize+CC+group @1080p", "value": round(total_frames / dt, 2), "unit": "frames/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "configs[2]: synthetic %dx%d binary-board stream, %d frames/stream/GPU: fp32 logits -> "
+                               "threshold+invert -> CC label (int32 image) -> CC stats/records/crops -> temporal matching"
+                               % (W, H, F),
+                   "frames_per_step": F, "batch": a.batch, "stages_not_yet_in_timed_region": ["cc_grouping(step03)", "fcn"],
+                   "stream": {k: k1[k] for k in ("n_cc", "n_unique", "tempo_count")}, "parallelism": "independent streams per GPU"},
+        "roofline": roofline, "cpu_baseline": cpu, "gen_seconds": round(gen_s, 2),
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,6 +76,13 @@ int lm_cc_stats_batch(LmCtx* ctx, void* stream);
 int lm_cc_stats_read(LmCtx* ctx, int frame, int count_labels, int32_t* h_mins_y, int32_t* h_maxs_y,
                      int32_t* h_mins_x, int32_t* h_maxs_x, int32_t* h_counts, void* stream);
 
+/* Live timing of the labelling launch sequence (pack .. write_labels) with HIP events recorded on the
+ * caller's stream around every lm_label_batch call (also the ones lm_stream_push makes).
+ * lm_ctx_profile_read synchronises the recorded events, returns the summed milliseconds, the number of
+ * calls and the number of frames they covered since the last read, and resets the accumulators. */
+int lm_ctx_set_profiling(LmCtx* ctx, int enable);
+int lm_ctx_profile_read(LmCtx* ctx, double* h_total_ms, int64_t* h_calls, int64_t* h_frames);
+
 /* Host-pointer convenience: one frame in, scipy-ordered labels out; returns the label count (>= 0)
  * or -LM_ERR_*.  Uses an internal lazily-created workspace on the current device. */
 int lm_label_host(const uint8_t* h_img, int width, int height, int32_t* h_labels);

@@ -42,6 +42,8 @@ SIGNATURES = {
     "lm_label_counts": (ctypes.c_int, [_vp, _vp, _vp]),
     "lm_cc_stats_batch": (ctypes.c_int, [_vp, _vp]),
     "lm_cc_stats_read": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lm_ctx_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "lm_ctx_profile_read": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "lm_label_host": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
     "lm_stream_create": (_vp, [_vp, ctypes.c_int, _i64, _i64, ctypes.c_int, _f64, _f64, ctypes.c_int, ctypes.c_int]),
     "lm_stream_destroy": (None, [_vp]),

@@ -42,11 +42,79 @@ template <class T> static int lm_alloc(T** p, size_t count)
 }
 
 // ------------------------------------------------------------------------------------------------
+// live profiling (event pairs around the labelling launch sequence)
+// ------------------------------------------------------------------------------------------------
+#include <vector>
+struct LmProfile {
+    std::vector<hipEvent_t> ev;     // pairs: start, stop
+    std::vector<int> frames;
+    size_t used = 0;                // pairs in use since the last read
+};
+
+static void lm_profile_free(LmCtx* c)
+{
+    LmProfile* p = (LmProfile*)c->prof;
+    if (!p) return;
+    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+    delete p;
+    c->prof = nullptr;
+}
+
+extern "C" int lm_ctx_set_profiling(LmCtx* c, int enable)
+{
+    if (!c) { lm_set_error("lm_ctx_set_profiling: null ctx"); return LM_ERR_ARG; }
+    c->profiling = enable ? 1 : 0;
+    if (enable && !c->prof) c->prof = new LmProfile();
+    return LM_OK;
+}
+
+extern "C" int lm_ctx_profile_read(LmCtx* c, double* total_ms, int64_t* calls, int64_t* frames)
+{
+    if (!c || !total_ms || !calls || !frames) { lm_set_error("lm_ctx_profile_read: bad arguments"); return LM_ERR_ARG; }
+    *total_ms = 0.0; *calls = 0; *frames = 0;
+    LmProfile* p = (LmProfile*)c->prof;
+    if (!p) return LM_OK;
+    for (size_t i = 0; i < p->used; i++) {
+        float ms = 0.f;
+        LM_HIP(hipEventSynchronize(p->ev[2 * i + 1]));
+        LM_HIP(hipEventElapsedTime(&ms, p->ev[2 * i], p->ev[2 * i + 1]));
+        *total_ms += ms;
+        *frames += p->frames[i];
+    }
+    *calls = (int64_t)p->used;
+    p->used = 0;
+    return LM_OK;
+}
+
+static int lm_profile_mark(LmCtx* c, hipStream_t st, bool start, int n_frames)
+{
+    LmProfile* p = (LmProfile*)c->prof;
+    if (!c->profiling || !p) return LM_OK;
+    if (start) {
+        if (p->ev.size() < 2 * (p->used + 1)) {
+            hipEvent_t a, b;
+            LM_HIP(hipEventCreate(&a));
+            LM_HIP(hipEventCreate(&b));
+            p->ev.push_back(a);
+            p->ev.push_back(b);
+            p->frames.push_back(0);
+        }
+        p->frames[p->used] = n_frames;
+        LM_HIP(hipEventRecord(p->ev[2 * p->used], st));
+    } else {
+        LM_HIP(hipEventRecord(p->ev[2 * p->used + 1], st));
+        p->used++;
+    }
+    return LM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
 extern "C" void lm_ctx_destroy(LmCtx* c)
 {
     if (!c) return;
+    lm_profile_free(c);
     void* ptrs[] = {c->bits, c->starts, c->prefix, c->row_runs, c->rowoff, c->frame_runs, c->parent, c->final_label,
                     c->n_labels, c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x, c->st_count, c->kept_label,
                     c->kept_cropoff, c->frame_kept, c->frame_cropwords, c->stage_u8, c->stage_i32, c->stage_f32};
@@ -123,6 +191,7 @@ extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, i
     hipStream_t st = (hipStream_t)stream;
     const long long nrows = (long long)n_frames * g.H;
     const int chunks = g.WW * 4;
+    if (lm_profile_mark(c, st, true, n_frames)) return LM_ERR_HIP;
     hipLaunchKernelGGL(lm_k_pack, dim3(lm_blocks(nrows * chunks, 256)), dim3(256), 0, st, d_binary, (uint16_t*)c->bits, g.W,
                        nrows, chunks);
     hipLaunchKernelGGL(lm_k_rowscan, dim3(lm_blocks(nrows * 64, 256)), dim3(256), 0, st, c->bits, c->starts, c->prefix,
@@ -138,6 +207,7 @@ extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, i
         hipLaunchKernelGGL(lm_k_write_labels, dim3(lm_blocks(quads, 256)), dim3(256), 0, st, c->bits, c->starts, c->prefix,
                            c->rowoff, c->final_label, d_labels, g.W, g.H, g.WW, g.cap, nrows);
     }
+    if (lm_profile_mark(c, st, false, n_frames)) return LM_ERR_HIP;
     LM_HIP(hipGetLastError());
     c->last_batch = n_frames;
     return LM_OK;

@@ -78,6 +78,9 @@ struct LmCtx {
     int32_t* stage_i32;
     float* stage_f32;
     size_t stage_px;
+    // optional live timing of the labelling launch sequence (bench.py roofline): hipEvent pairs per call
+    int profiling;
+    void* prof;     // LmProfile*, owned
 };
 
 // ---------------------------------------------------------------- device helpers

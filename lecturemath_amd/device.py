@@ -123,7 +123,7 @@ class FrameStream:
         self.width, self.height = width, height
         px = width * height
         max_ccs = max_ccs or max_frames * max(px // 256, 64)
-        max_crop_words = max_crop_words or max_frames * max(px // 8, 1024)
+        max_crop_words = max_crop_words or max_frames * max(px // 4, 4096)
         max_uniques = max_uniques or max_ccs
         self.handle = self.lib.lm_stream_create(self.labeler.ctx, max_frames, max_ccs, max_crop_words, max_uniques,
                                                 min_recall, min_precision, max_gap, min_pixels)

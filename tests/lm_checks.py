@@ -87,12 +87,12 @@ def check_stream_golden(lib, name, max_batch=7):
     state_equal_golden(r, g)
 
 
-def check_stream_oracle(lib, frames, max_gap, max_batch=5):
+def check_stream_oracle(lib, frames, max_gap, max_batch=5, **kw):
     from oracle import cc as occ
     h, w = frames[0].shape
     st = occ.Stability(w, h, 0.85, 0.85, max_gap)
     for f in frames:
         st.add_frame(f)
-    r = run_stream(lib, np.stack(frames), w, h, max_gap, max_batch=max_batch)
+    r = run_stream(lib, np.stack(frames), w, h, max_gap, max_batch=max_batch, **kw)
     state_equal_oracle(r, st.result())
     return r

@@ -40,7 +40,7 @@ def test_stream_vs_oracle_random_noise(hip_lib, oracle_built):
         flip = rng.random(base.shape) < 0.002
         base = base ^ flip
         frames.append((base * 255).astype(np.uint8))
-    lm_checks.check_stream_oracle(hip_lib, frames, max_gap=3, max_batch=4)
+    lm_checks.check_stream_oracle(hip_lib, frames, max_gap=3, max_batch=4, max_crop_words=1 << 22, max_ccs=1 << 16)
 
 
 def test_full_size_1080p_label_vs_oracle(hip_lib, oracle_built):
