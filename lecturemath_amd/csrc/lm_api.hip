@@ -116,7 +116,7 @@ extern "C" void lm_ctx_destroy(LmCtx* c)
     if (!c) return;
     lm_profile_free(c);
     void* ptrs[] = {c->bits, c->starts, c->prefix, c->row_runs, c->rowoff, c->frame_runs, c->parent, c->final_label,
-                    c->n_labels, c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x, c->st_count, c->kept_label,
+                    c->n_labels, c->rootbits, c->wordprefix, c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x, c->st_count, c->kept_label,
                     c->kept_cropoff, c->frame_kept, c->frame_cropwords, c->stage_u8, c->stage_i32, c->stage_f32};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -149,6 +149,8 @@ extern "C" LmCtx* lm_ctx_create(int width, int height, int max_batch)
     rc |= lm_alloc(&c->parent, BC);
     rc |= lm_alloc(&c->final_label, BC);
     rc |= lm_alloc(&c->n_labels, (size_t)max_batch);
+    rc |= lm_alloc(&c->rootbits, (size_t)max_batch * ((c->g.cap + 63) / 64));
+    rc |= lm_alloc(&c->wordprefix, (size_t)max_batch * ((c->g.cap + 63) / 64));
     rc |= lm_alloc(&c->st_min_y, BC);
     rc |= lm_alloc(&c->st_max_y, BC);
     rc |= lm_alloc(&c->st_min_x, BC);
@@ -196,12 +198,18 @@ extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, i
                        nrows, chunks);
     hipLaunchKernelGGL(lm_k_rowscan, dim3(lm_blocks(nrows * 64, 256)), dim3(256), 0, st, c->bits, c->starts, c->prefix,
                        c->row_runs, g.WW, nrows);
-    hipLaunchKernelGGL(lm_k_frame_rowoff, dim3(n_frames), dim3(1024), 0, st, c->row_runs, c->rowoff, c->frame_runs, c->parent,
-                       g.H, g.cap);
-    hipLaunchKernelGGL(lm_k_union, dim3(lm_blocks(nrows * g.WW, 256)), dim3(256), 0, st, c->bits, c->starts, c->prefix,
-                       c->rowoff, c->parent, g.WW, g.H, g.cap, nrows);
-    hipLaunchKernelGGL(lm_k_resolve, dim3(n_frames), dim3(1024), 0, st, c->parent, c->final_label, c->frame_runs, c->n_labels,
-                       g.cap);
+    hipLaunchKernelGGL(lm_k_frame_rowoff, dim3(n_frames), dim3(1024), 0, st, c->row_runs, c->rowoff, c->frame_runs, g.H);
+    const int nbands = (g.H + LM_BAND_ROWS - 1) / LM_BAND_ROWS;
+    const int capw = (g.cap + 63) / 64;
+    hipLaunchKernelGGL(lm_k_band_union, dim3(nbands, n_frames), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff,
+                       c->frame_runs, c->parent, g.WW, g.H, g.cap);
+    if (nbands > 1)
+        hipLaunchKernelGGL(lm_k_seam_union, dim3(lm_blocks((long long)n_frames * (nbands - 1) * g.WW, 256)), dim3(256), 0, st,
+                           c->bits, c->starts, c->prefix, c->rowoff, c->parent, g.WW, g.H, g.cap, nbands - 1, n_frames);
+    hipLaunchKernelGGL(lm_k_flatten_flag, dim3(32, n_frames), dim3(256), 0, st, c->parent, c->frame_runs, c->rootbits, g.cap, capw);
+    hipLaunchKernelGGL(lm_k_rank, dim3(n_frames), dim3(1024), 0, st, c->rootbits, c->frame_runs, c->wordprefix, c->n_labels, capw);
+    hipLaunchKernelGGL(lm_k_apply_labels, dim3(32, n_frames), dim3(256), 0, st, c->parent, c->frame_runs, c->rootbits,
+                       c->wordprefix, c->final_label, g.cap, capw);
     if (d_labels) {
         const long long quads = nrows * ((g.W + 3) / 4);
         hipLaunchKernelGGL(lm_k_write_labels, dim3(lm_blocks(quads, 256)), dim3(256), 0, st, c->bits, c->starts, c->prefix,
@@ -228,12 +236,11 @@ extern "C" int lm_cc_stats_batch(LmCtx* c, void* stream)
     const LmGeom g = c->g;
     hipStream_t st = (hipStream_t)stream;
     const int B = c->last_batch;
-    const long long nrows = (long long)B * g.H;
     hipLaunchKernelGGL(lm_k_stats_init, dim3(32, B), dim3(256), 0, st, c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x,
                        c->st_count, c->n_labels, g.W, g.H, g.cap);
-    hipLaunchKernelGGL(lm_k_stats, dim3(lm_blocks(nrows * g.WW, 256)), dim3(256), 0, st, c->bits, c->starts, c->prefix,
-                       c->rowoff, c->final_label, c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x, c->st_count, g.WW, g.H,
-                       g.cap, nrows);
+    hipLaunchKernelGGL(lm_k_stats, dim3((g.WW + LM_ST_WORDS - 1) / LM_ST_WORDS, (g.H + LM_ST_ROWS - 1) / LM_ST_ROWS, B), dim3(256), 0,
+                       st, c->bits, c->starts, c->prefix, c->rowoff, c->final_label, c->st_min_y, c->st_max_y, c->st_min_x,
+                       c->st_max_x, c->st_count, g.WW, g.H, g.cap);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }
@@ -344,7 +351,7 @@ extern "C" int CC_AgeBoundaries(int* labels, float* ages, int width, int height,
 extern "C" void lm_stream_destroy(LmStream* s)
 {
     if (!s) return;
-    void* ptrs[] = {s->cc, s->assign, s->frame_cc_off, s->crop, s->uniq_cc, s->uniq_box16, s->uniq_last, s->active, s->counters,
+    void* ptrs[] = {s->cc, s->assign, s->frame_cc_off, s->crop, s->active_cc, s->active_box, s->active_last, s->active, s->counters, s->best_pos, s->pairs,
                     s->batch_cc_base, s->batch_word_base};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -383,10 +390,13 @@ extern "C" LmStream* lm_stream_create(LmCtx* ctx, int max_frames, int64_t max_cc
     rc |= lm_alloc(&s->assign, (size_t)max_ccs);
     rc |= lm_alloc(&s->frame_cc_off, (size_t)max_frames + 1);
     rc |= lm_alloc(&s->crop, (size_t)max_crop_words);
-    rc |= lm_alloc(&s->uniq_cc, (size_t)max_uniques);
-    rc |= lm_alloc(&s->uniq_box16, (size_t)max_uniques);
-    rc |= lm_alloc(&s->uniq_last, (size_t)max_uniques);
+    rc |= lm_alloc(&s->active_cc, (size_t)max_uniques);
+    rc |= lm_alloc(&s->active_box, (size_t)max_uniques);
+    rc |= lm_alloc(&s->active_last, (size_t)max_uniques);
     rc |= lm_alloc(&s->active, (size_t)max_uniques);
+    s->cap_pairs = 1 << 24;     // bbox-overlapping (CC, unique) pairs per frame; more raises LM_ERR_CAPACITY
+    rc |= lm_alloc(&s->best_pos, (size_t)ctx->g.cap);
+    rc |= lm_alloc(&s->pairs, (size_t)s->cap_pairs);
     rc |= lm_alloc(&s->counters, (size_t)1);
     rc |= lm_alloc(&s->batch_cc_base, (size_t)ctx->max_batch);
     rc |= lm_alloc(&s->batch_word_base, (size_t)ctx->max_batch);
@@ -427,10 +437,14 @@ extern "C" int lm_stream_push(LmStream* s, const uint8_t* d_binary, int n_frames
                            g.cap);
         for (int b = 0; b < B; b++) {
             const int f = s->frames_pushed + b;
-            hipLaunchKernelGGL(lm_k_match, dim3(128), dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, s->uniq_cc,
-                               s->uniq_box16, s->active, s->counters, s->assign, s->min_recall, s->min_precision);
-            hipLaunchKernelGGL(lm_k_update, dim3(1), dim3(1024), 0, st, s->cc, s->frame_cc_off, f, s->uniq_cc, s->uniq_box16,
-                               s->uniq_last, s->active, s->counters, s->assign, s->max_gap, s->cap_uniq);
+            hipLaunchKernelGGL(lm_k_match_scan, LM_HIP_EMULATED ? dim3(2, 2) : dim3(16, 32), dim3(256), 0, st, s->cc, s->frame_cc_off, f, s->active_box,
+                               s->active_last, s->active_cc, s->counters, s->best_pos, s->pairs, s->cap_pairs, s->max_gap);
+            hipLaunchKernelGGL(lm_k_match_eval, dim3(LM_HIP_EMULATED ? 2 : 128), dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, s->active_cc,
+                               s->counters, s->pairs, s->best_pos, s->cap_pairs, s->min_recall, s->min_precision);
+            // compact the active list every 16 frames (purely an optimisation: retirement is evaluated lazily)
+            hipLaunchKernelGGL(lm_k_update, dim3(1), dim3(1024), 0, st, s->cc, s->frame_cc_off, f, s->active, s->active_cc,
+                               s->active_box, s->active_last, s->counters, s->assign, s->best_pos, s->cap_pairs, s->max_gap,
+                               s->cap_uniq, (f & 15) == 15 ? 1 : 0);
         }
         LM_HIP(hipGetLastError());
         s->frames_pushed += B;
@@ -439,9 +453,38 @@ extern "C" int lm_stream_push(LmStream* s, const uint8_t* d_binary, int n_frames
     return LM_OK;
 }
 
+// drops retired entries from the active list so that it equals the reference's cc_active after the last frame
+__global__ void __launch_bounds__(1024) lm_k_compact_active(int32_t* __restrict__ active, int32_t* __restrict__ active_cc,
+                                                            unsigned long long* __restrict__ active_box, int32_t* __restrict__ active_last,
+                                                            LmCounters* __restrict__ cnt, int max_gap)
+{
+    if (cnt->error) return;
+    const int f = cnt->n_matched;       // index of the next frame
+    const int nA = cnt->n_active;
+    if (f <= 1) return;
+    unsigned kept = 0;
+    for (int base = 0; base < nA; base += 1024) {
+        int i = base + (int)threadIdx.x;
+        int32_t u = 0, uc = 0, ul = 0;
+        unsigned long long ub = 0;
+        unsigned keep = 0;
+        if (i < nA) {
+            u = active[i]; uc = active_cc[i]; ub = active_box[i]; ul = active_last[i];
+            keep = ((f - 1) - ul < max_gap) ? 1u : 0u;
+        }
+        unsigned tot;
+        unsigned ex = lm_block_excl_scan<1024>(keep, &tot);
+        if (keep) { active[kept + ex] = u; active_cc[kept + ex] = uc; active_box[kept + ex] = ub; active_last[kept + ex] = ul; }
+        kept += tot;
+    }
+    if (threadIdx.x == 0) cnt->n_active = (int)kept;
+}
+
 extern "C" int lm_stream_counters(LmStream* s, int64_t* out, void* stream)
 {
     if (!s || !out) { lm_set_error("lm_stream_counters: bad arguments"); return LM_ERR_ARG; }
+    hipLaunchKernelGGL(lm_k_compact_active, dim3(1), dim3(1024), 0, (hipStream_t)stream, s->active, s->active_cc, s->active_box,
+                       s->active_last, s->counters, s->max_gap);
     LmCounters h;
     LM_HIP(hipMemcpyAsync(&h, s->counters, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
     LM_HIP(hipStreamSynchronize((hipStream_t)stream));

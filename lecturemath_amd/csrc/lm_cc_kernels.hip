@@ -121,12 +121,11 @@ __global__ void __launch_bounds__(256) lm_k_rowscan(const uint64_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: per frame: exclusive scan of runs-per-row -> rowoff (frame-relative), frame_runs; parent[i] = i.
+// K3: per frame: exclusive scan of runs-per-row -> rowoff (frame-relative), frame_runs.
 // One block per frame.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) lm_k_frame_rowoff(const uint32_t* __restrict__ row_runs,
-                                                          uint32_t* __restrict__ rowoff, int32_t* __restrict__ frame_runs,
-                                                          int32_t* __restrict__ parent, int H, int cap)
+                                                          uint32_t* __restrict__ rowoff, int32_t* __restrict__ frame_runs, int H)
 {
     const int b = blockIdx.x;
     unsigned carry = 0;
@@ -139,13 +138,18 @@ __global__ void __launch_bounds__(1024) lm_k_frame_rowoff(const uint32_t* __rest
         carry += tot;
     }
     if (threadIdx.x == 0) frame_runs[b] = (int32_t)carry;
-    int32_t* par = parent + (long long)b * cap;
-    for (unsigned i = threadIdx.x; i < carry; i += 1024) par[i] = (int32_t)i;
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: unions between vertically adjacent runs. One thread per (row, word).
+// K4: union-find over runs, two levels.
+//   K4a  one workgroup per band of LM_BAND_ROWS rows: the band's forest lives in LDS (ds atomics),
+//        is flattened there and written out as global parents (band-local roots).
+//   K4b  seam rows between bands: the few remaining contacts, with device-scope atomics in L2.
+// Root of a set = its smallest run id, so roots are the runs holding each component's first pixel.
 // ------------------------------------------------------------------------------------------------
+#define LM_BAND_ROWS 64
+#define LM_BAND_LDS 8192
+
 LM_DEV int lm_find(const int32_t* parent, int x)
 {
     // stale reads are harmless: parents only ever move to smaller ids of the same set
@@ -164,78 +168,152 @@ LM_DEV void lm_union(int32_t* parent, int a, int b)
         b = lm_find(parent, b);
         if (a == b) return;
         if (a < b) { int t = a; a = b; b = t; }
-        int old = atomicMin(&parent[a], b);     // device-scope RMW: coherent across XCDs
+        int old = atomicMin(&parent[a], b);     // global: device-scope RMW, coherent across XCDs; LDS: ds_min_rtn
         if (old == a) return;                   // a was a root and now hangs under b
         a = old;                                // a had been re-parented meanwhile: merge that tree with b too
     }
 }
 
-__global__ void __launch_bounds__(256) lm_k_union(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
-                                                  const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
-                                                  int32_t* __restrict__ parent, int WW, int H, int cap, long long nrows)
+// contacts of cell (row, word w) with the row above: calls uni(a, b) with frame-relative run ids
+template <class F>
+LM_DEV void lm_cell_contacts(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
+                             const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff, long long row, int w,
+                             int WW, F uni)
 {
-    long long total = nrows * WW;
-    long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += stride) {
-        long long row = gid / WW;
-        int w = (int)(gid - row * WW);
-        int y = (int)(row % H);
-        if (y == 0) continue;
-        unsigned long long cur = bits[gid];
-        if (!cur) continue;
-        unsigned long long up = bits[gid - WW];
-        unsigned long long v = cur & up;
-        if (!v) continue;
-        unsigned long long carry = 0;
-        if (w > 0) carry = (bits[gid - 1] & bits[gid - WW - 1]) >> 63;
-        unsigned long long ps = v & ~((v << 1) | carry);   // first column of every distinct (run, upper run) contact
-        if (!ps) continue;
-        int32_t* par = parent + (row / H) * cap;
-        const unsigned long long s_cur = starts[gid], s_up = starts[gid - WW];
-        const int base_cur = (int)rowoff[row] + (int)prefix[gid] - 1;
-        const int base_up = (int)rowoff[row - 1] + (int)prefix[gid - WW] - 1;
-        while (ps) {
-            int p = __ffsll((long long)ps) - 1;
-            ps &= ps - 1;
-            unsigned long long m = lm_lowmask_incl(p);
-            int a = base_cur + __popcll(s_cur & m);
-            int b = base_up + __popcll(s_up & m);
-            lm_union(par, a, b);
-        }
+    const long long gid = row * WW + w;
+    unsigned long long cur = bits[gid];
+    if (!cur) return;
+    unsigned long long v = cur & bits[gid - WW];
+    if (!v) return;
+    unsigned long long carry = 0;
+    if (w > 0) carry = (bits[gid - 1] & bits[gid - WW - 1]) >> 63;
+    unsigned long long ps = v & ~((v << 1) | carry);   // first column of every distinct (run, upper run) contact
+    if (!ps) return;
+    const unsigned long long s_cur = starts[gid], s_up = starts[gid - WW];
+    const int base_cur = (int)rowoff[row] + (int)prefix[gid] - 1;
+    const int base_up = (int)rowoff[row - 1] + (int)prefix[gid - WW] - 1;
+    while (ps) {
+        int p = __ffsll((long long)ps) - 1;
+        ps &= ps - 1;
+        unsigned long long m = lm_lowmask_incl(p);
+        uni(base_cur + __popcll(s_cur & m), base_up + __popcll(s_up & m));
+    }
+}
+
+__global__ void __launch_bounds__(256) lm_k_band_union(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
+                                                       const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
+                                                       const int32_t* __restrict__ frame_runs, int32_t* __restrict__ parent,
+                                                       int WW, int H, int cap)
+{
+    __shared__ int32_t s_par[LM_BAND_LDS];
+    const int b = blockIdx.y;
+    const int y0 = blockIdx.x * LM_BAND_ROWS;
+    const int y1 = (y0 + LM_BAND_ROWS < H) ? y0 + LM_BAND_ROWS : H;
+    const long long row0 = (long long)b * H + y0;
+    const int base = (int)rowoff[row0];
+    const int end = (y1 < H) ? (int)rowoff[(long long)b * H + y1] : frame_runs[b];
+    const int n = end - base;
+    if (n <= 0) return;
+    int32_t* par_g = parent + (long long)b * cap;
+    const bool lds = n <= LM_BAND_LDS;          // block-uniform
+    if (lds) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) s_par[i] = i;
+    } else {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) par_g[base + i] = base + i;
+    }
+    __syncthreads();
+    const int cells = (y1 - y0 - 1) * WW;
+    for (int cell = threadIdx.x; cell < cells; cell += blockDim.x) {
+        int r = cell / WW, w = cell - r * WW;
+        long long row = row0 + 1 + r;
+        if (lds)
+            lm_cell_contacts(bits, starts, prefix, rowoff, row, w, WW, [&](int a, int c) { lm_union(s_par, a - base, c - base); });
+        else
+            lm_cell_contacts(bits, starts, prefix, rowoff, row, w, WW, [&](int a, int c) { lm_union(par_g, a, c); });
+    }
+    if (!lds) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) par_g[base + i] = base + lm_find(s_par, i);
+}
+
+__global__ void __launch_bounds__(256) lm_k_seam_union(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
+                                                       const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
+                                                       int32_t* __restrict__ parent, int WW, int H, int cap, int nseams, int B)
+{
+    // one thread per (frame, seam, word); seam k separates rows k*LM_BAND_ROWS-1 and k*LM_BAND_ROWS
+    long long total = (long long)B * nseams * WW;
+    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long long)gridDim.x * blockDim.x) {
+        int w = (int)(gid % WW);
+        long long t = gid / WW;
+        int k = (int)(t % nseams) + 1;
+        int b = (int)(t / nseams);
+        long long row = (long long)b * H + (long long)k * LM_BAND_ROWS;
+        int32_t* par = parent + (long long)b * cap;
+        lm_cell_contacts(bits, starts, prefix, rowoff, row, w, WW, [&](int a, int c) { lm_union(par, a, c); });
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5: per frame: flatten the forest, number the roots in run order (== raster order of first pixel),
-// give every run its final 1-based label.  One block per frame.
+// K5: number the roots in run order (== raster order of each component's first pixel) and give every
+// run its final 1-based label.
+//   K5a  flatten + root flags as a bit mask (one ballot per 64 runs)           grid (x, B)
+//   K5b  per frame: exclusive scan of the root-mask popcounts                  one block per frame
+//   K5c  final[i] = rank(root(i)) + 1                                          grid (x, B)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) lm_k_resolve(int32_t* __restrict__ parent, int32_t* __restrict__ final_label,
-                                                     const int32_t* __restrict__ frame_runs, int32_t* __restrict__ n_labels,
-                                                     int cap)
+__global__ void __launch_bounds__(256) lm_k_flatten_flag(int32_t* __restrict__ parent, const int32_t* __restrict__ frame_runs,
+                                                         unsigned long long* __restrict__ rootbits, int cap, int capw)
 {
-    const int b = blockIdx.x;
-    int32_t* par = parent + (long long)b * cap;
-    int32_t* fin = final_label + (long long)b * cap;
+    const int b = blockIdx.y;
     const int n = frame_runs[b];
-    unsigned carry = 0;
-    for (int base = 0; base < n; base += 1024) {
-        int i = base + (int)threadIdx.x;
-        unsigned is_root = 0;
+    int32_t* par = parent + (long long)b * cap;
+    unsigned long long* rb = rootbits + (long long)b * capw;
+    const int lane = lm_lane();
+    for (int base = (int)(blockIdx.x * blockDim.x + (threadIdx.x & ~63u)); base < n; base += (int)(gridDim.x * blockDim.x)) {
+        int i = base + lane;
+        bool flag = false;
         if (i < n) {
             int r = lm_find(par, i);
             par[i] = r;
-            is_root = (r == i);
+            flag = (r == i);
         }
+        unsigned long long m = __ballot(flag);
+        if (lane == 0) rb[base >> 6] = m;
+    }
+}
+
+__global__ void __launch_bounds__(1024) lm_k_rank(const unsigned long long* __restrict__ rootbits, const int32_t* __restrict__ frame_runs,
+                                                  uint32_t* __restrict__ wordprefix, int32_t* __restrict__ n_labels, int capw)
+{
+    const int b = blockIdx.x;
+    const int nw = (frame_runs[b] + 63) >> 6;
+    const unsigned long long* rb = rootbits + (long long)b * capw;
+    uint32_t* wp = wordprefix + (long long)b * capw;
+    unsigned carry = 0;
+    for (int base = 0; base < nw; base += 1024) {
+        int j = base + (int)threadIdx.x;
+        unsigned v = (j < nw) ? (unsigned)__popcll(rb[j]) : 0u;
         unsigned tot;
-        unsigned ex = lm_block_excl_scan<1024>(is_root, &tot);
-        if (is_root) fin[i] = (int32_t)(carry + ex + 1);
+        unsigned ex = lm_block_excl_scan<1024>(v, &tot);
+        if (j < nw) wp[j] = carry + ex;
         carry += tot;
     }
     if (threadIdx.x == 0) n_labels[b] = (int32_t)carry;
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 1024) {
+}
+
+__global__ void __launch_bounds__(256) lm_k_apply_labels(const int32_t* __restrict__ parent, const int32_t* __restrict__ frame_runs,
+                                                         const unsigned long long* __restrict__ rootbits,
+                                                         const uint32_t* __restrict__ wordprefix, int32_t* __restrict__ final_label,
+                                                         int cap, int capw)
+{
+    const int b = blockIdx.y;
+    const int n = frame_runs[b];
+    const int32_t* par = parent + (long long)b * cap;
+    const unsigned long long* rb = rootbits + (long long)b * capw;
+    const uint32_t* wp = wordprefix + (long long)b * capw;
+    int32_t* fin = final_label + (long long)b * cap;
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x)) {
         int r = par[i];
-        if (r != i) fin[i] = fin[r];
+        fin[i] = (int32_t)(wp[r >> 6] + (unsigned)__popcll(rb[r >> 6] & lm_lowmask_excl(r & 63)) + 1u);
     }
 }
 
@@ -306,45 +384,87 @@ __global__ void __launch_bounds__(256) lm_k_stats_init(int32_t* __restrict__ st_
     }
 }
 
+// One block per tile of 64 rows x 4 words (256 px wide): pieces are first combined per label in an LDS
+// hash table (ds atomics), then every (tile, label) pair costs at most five device-scope atomics.
+#define LM_ST_SLOTS 512
+#define LM_ST_ROWS 64
+#define LM_ST_WORDS 4
+
 __global__ void __launch_bounds__(256) lm_k_stats(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
                                                   const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
                                                   const int32_t* __restrict__ final_label, int32_t* __restrict__ st_min_y,
                                                   int32_t* __restrict__ st_max_y, int32_t* __restrict__ st_min_x,
                                                   int32_t* __restrict__ st_max_x, int32_t* __restrict__ st_count, int WW, int H,
-                                                  int cap, long long nrows)
+                                                  int cap)
 {
-    long long total = nrows * WW;
-    long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += stride) {
+    __shared__ int s_key[LM_ST_SLOTS], s_cnt[LM_ST_SLOTS], s_mnx[LM_ST_SLOTS], s_mxx[LM_ST_SLOTS], s_mny[LM_ST_SLOTS],
+        s_mxy[LM_ST_SLOTS];
+    const int b = blockIdx.z;
+    const long long foff = (long long)b * cap;
+    for (int i = threadIdx.x; i < LM_ST_SLOTS; i += blockDim.x) {
+        s_key[i] = 0; s_cnt[i] = 0; s_mnx[i] = 0x7fffffff; s_mxx[i] = -1; s_mny[i] = 0x7fffffff; s_mxy[i] = -1;
+    }
+    __syncthreads();
+    const int y = blockIdx.y * LM_ST_ROWS + (int)(threadIdx.x >> 2);
+    const int w = blockIdx.x * LM_ST_WORDS + (int)(threadIdx.x & 3);
+    if (y < H && w < WW) {
+        const long long row = (long long)b * H + y;
+        const long long gid = row * WW + w;
         unsigned long long rem = bits[gid];
-        if (!rem) continue;
-        long long row = gid / WW;
-        int w = (int)(gid - row * WW);
-        int y = (int)(row % H);
-        long long foff = (row / H) * cap;
-        const unsigned long long s = starts[gid];
-        const int32_t* fin = final_label + foff;
-        int id = (int)rowoff[row] + (int)prefix[gid] - 1;
-        bool next_cont = (w + 1 < WW) ? (bits[gid + 1] & 1ull) : false;
-        while (rem) {
-            int lo = __ffsll((long long)rem) - 1;
-            unsigned long long t = ~(rem >> lo);           // zeros where the piece continues
-            int len = t ? (__ffsll((long long)t) - 1) : 64;
-            if (len > 64 - lo) len = 64 - lo;
-            int hi = lo + len - 1;
-            bool is_start = (s >> lo) & 1ull;
-            id += is_start ? 1 : 0;
-            long long cc = foff + fin[id] - 1;
-            atomicAdd(&st_count[cc], len);
-            if (is_start) {
-                atomicMin(&st_min_x[cc], w * 64 + lo);
-                atomicMin(&st_min_y[cc], y);
-                atomicMax(&st_max_y[cc], y);
+        if (rem) {
+            const unsigned long long s = starts[gid];
+            const int32_t* fin = final_label + foff;
+            int id = (int)rowoff[row] + (int)prefix[gid] - 1;
+            const bool next_cont = (w + 1 < WW) ? (bits[gid + 1] & 1ull) : false;
+            while (rem) {
+                int lo = __ffsll((long long)rem) - 1;
+                unsigned long long t = ~(rem >> lo);           // zeros where the piece continues
+                int len = t ? (__ffsll((long long)t) - 1) : 64;
+                if (len > 64 - lo) len = 64 - lo;
+                int hi = lo + len - 1;
+                const bool is_start = (s >> lo) & 1ull;
+                id += is_start ? 1 : 0;
+                const int lab = fin[id];                       // 1-based
+                const bool ends = (hi < 63) || !next_cont;
+                int slot = (int)(((unsigned)lab * 2654435761u) >> 23) & (LM_ST_SLOTS - 1);
+                bool placed = false;
+                for (int tries = 0; tries < 24; tries++) {
+                    int k = atomicCAS(&s_key[slot], 0, lab);
+                    if (k == 0 || k == lab) { placed = true; break; }
+                    slot = (slot + 1) & (LM_ST_SLOTS - 1);
+                }
+                if (placed) {
+                    atomicAdd(&s_cnt[slot], len);
+                    if (is_start) {
+                        atomicMin(&s_mnx[slot], w * 64 + lo);
+                        atomicMin(&s_mny[slot], y);
+                        atomicMax(&s_mxy[slot], y);
+                    }
+                    if (ends) atomicMax(&s_mxx[slot], w * 64 + hi);
+                } else {      // table full (very dense tile): straight to L2
+                    const long long cc = foff + lab - 1;
+                    atomicAdd(&st_count[cc], len);
+                    if (is_start) {
+                        atomicMin(&st_min_x[cc], w * 64 + lo);
+                        atomicMin(&st_min_y[cc], y);
+                        atomicMax(&st_max_y[cc], y);
+                    }
+                    if (ends) atomicMax(&st_max_x[cc], w * 64 + hi);
+                }
+                rem &= ~(lm_lowmask_incl(hi));
             }
-            bool ends = (hi < 63) || !next_cont;
-            if (ends) atomicMax(&st_max_x[cc], w * 64 + hi);
-            rem &= ~(lm_lowmask_incl(hi));
         }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LM_ST_SLOTS; i += blockDim.x) {
+        const int lab = s_key[i];
+        if (!lab) continue;
+        const long long cc = foff + lab - 1;
+        atomicAdd(&st_count[cc], s_cnt[i]);
+        if (s_mnx[i] != 0x7fffffff) atomicMin(&st_min_x[cc], s_mnx[i]);
+        if (s_mny[i] != 0x7fffffff) atomicMin(&st_min_y[cc], s_mny[i]);
+        if (s_mxy[i] >= 0) atomicMax(&st_max_y[cc], s_mxy[i]);
+        if (s_mxx[i] >= 0) atomicMax(&st_max_x[cc], s_mxx[i]);
     }
 }
 

@@ -7,6 +7,7 @@
 //   prefix   u16 [R][WW]    number of run starts in the row left of the word
 //   rowoff   u32 [R]        number of runs in the frame above the row (frame-relative)
 //   parent   i32 [B][CAP]   union-find forest over runs (frame-relative run ids, root = smallest id)
+//   rootbits u64 [B][CAP/64] root flags; wordprefix u32 [B][CAP/64] their exclusive popcount scan
 //   final    i32 [B][CAP]   1-based scipy-ordered label of every run
 // A "run" is a maximal horizontal segment of foreground pixels; runs are numbered in raster order,
 // so the smallest run id of a component starts at the component's first pixel in raster order and
@@ -61,6 +62,8 @@ struct LmCtx {
     int32_t* parent;         // [B][cap]
     int32_t* final_label;    // [B][cap]
     int32_t* n_labels;       // [B]
+    unsigned long long* rootbits;   // [B][ceil(cap/64)] bit i set <=> run i is a root
+    uint32_t* wordprefix;    // [B][ceil(cap/64)] roots before word j
     // per-label statistics (CC_AgeBoundaries order), [B][cap] each
     int32_t* st_min_y;
     int32_t* st_max_y;

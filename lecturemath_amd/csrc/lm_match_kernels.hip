@@ -127,6 +127,13 @@ __global__ void __launch_bounds__(256) lm_k_emit(const uint64_t* __restrict__ bi
 // ------------------------------------------------------------------------------------------------
 // M1: match the kept CCs of frame f against the active uniques. One wave per current CC.
 // assign[c] = matched unique index, or -1 (new unique).
+//
+// Active list (ascending unique index, so scan order == the reference's sorted candidate order, :84):
+//   active[a] unique index, active_cc[a] its first-seen CC record, active_box[a] its box,
+//   active_last[a] last frame it was matched.
+// Retirement is evaluated lazily: the reference removes u after frame g when g - last_u >= max_gap
+// (:126-145, only for g >= 1); a removed unique is never touched again, so "u is a candidate at frame f"
+// <=> f <= 1 or (f-1) - last_u < max_gap.  The list is compacted only now and then (lm_k_update).
 // ------------------------------------------------------------------------------------------------
 LM_DEV bool lm_box_hit(const LmCcRec& c, unsigned long long ub)
 {
@@ -135,135 +142,259 @@ LM_DEV bool lm_box_hit(const LmCcRec& c, unsigned long long ub)
     return c.min_x <= ux1 && ux0 <= c.max_x && c.min_y <= uy1 && uy0 <= c.max_y;
 }
 
-LM_DEV int lm_pixel_overlap(const LmCcRec& a, const LmCcRec& u, const uint32_t* __restrict__ crop, int lane)
+struct LmIsect { int y0, y1, wc0, nwc, awx0, anw, uwx0, unw; };
+
+LM_DEV LmIsect lm_isect(const LmCcRec& a, const LmCcRec& u)
 {
-    int y0 = a.min_y > u.min_y ? a.min_y : u.min_y;
-    int y1 = a.max_y < u.max_y ? a.max_y : u.max_y;
-    int awx0 = a.min_x >> 5, anw = (a.max_x >> 5) - awx0 + 1;
-    int uwx0 = u.min_x >> 5, unw = (u.max_x >> 5) - uwx0 + 1;
-    int wc0 = awx0 > uwx0 ? awx0 : uwx0;
+    LmIsect s;
+    s.y0 = a.min_y > u.min_y ? a.min_y : u.min_y;
+    s.y1 = a.max_y < u.max_y ? a.max_y : u.max_y;
+    s.awx0 = a.min_x >> 5; s.anw = (a.max_x >> 5) - s.awx0 + 1;
+    s.uwx0 = u.min_x >> 5; s.unw = (u.max_x >> 5) - s.uwx0 + 1;
+    s.wc0 = s.awx0 > s.uwx0 ? s.awx0 : s.uwx0;
     int wc1 = (a.max_x >> 5) < (u.max_x >> 5) ? (a.max_x >> 5) : (u.max_x >> 5);
-    int nwc = wc1 - wc0 + 1;
-    int total = nwc * (y1 - y0 + 1);
+    s.nwc = wc1 - s.wc0 + 1;
+    return s;
+}
+
+// AND + popcount over the intersection, words idx = first, first+step, ... (step 1: one lane does it all;
+// step 64 with first = lane: the wave shares it and the caller sums the lanes)
+LM_DEV int lm_overlap_words(const LmCcRec& a, const LmCcRec& u, const LmIsect& s, const uint32_t* __restrict__ crop,
+                            int first, int step)
+{
+    const int total = s.nwc * (s.y1 - s.y0 + 1);
     int sum = 0;
-    for (int idx = lane; idx < total; idx += 64) {
-        int r = idx / nwc, j = idx - r * nwc;
-        int y = y0 + r, wc = wc0 + j;
-        unsigned wa = crop[a.crop_off + (unsigned long long)((y - a.min_y) * anw + (wc - awx0))];
-        unsigned wu = crop[u.crop_off + (unsigned long long)((y - u.min_y) * unw + (wc - uwx0))];
+    for (int idx = first; idx < total; idx += step) {
+        int r = idx / s.nwc, j = idx - r * s.nwc;
+        int y = s.y0 + r, wc = s.wc0 + j;
+        unsigned wa = crop[a.crop_off + (unsigned long long)((y - a.min_y) * s.anw + (wc - s.awx0))];
+        unsigned wu = crop[u.crop_off + (unsigned long long)((y - u.min_y) * s.unw + (wc - s.uwx0))];
         sum += __popc(wa & wu);
     }
-    return lm_wave_sum(sum);
+    return sum;
 }
 
-__global__ void __launch_bounds__(256) lm_k_match(const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
-                                                  const long long* __restrict__ frame_cc_off, int f,
-                                                  const int32_t* __restrict__ uniq_cc, const unsigned long long* __restrict__ uniq_box16,
-                                                  const int32_t* __restrict__ active, LmCounters* __restrict__ cnt,
-                                                  int32_t* __restrict__ assign, double min_recall, double min_precision)
+LM_DEV bool lm_accept(int match, int size_cur, int size_uni, double min_recall, double min_precision)
 {
-    const int lane = lm_lane();
-    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    double recall = (double)match / (double)size_cur;        // connected_component.py:239
+    double precision = (double)match / (double)size_uni;     // :240
+    return recall >= min_recall && precision >= min_precision;   // cc_stability_estimator.py:99
+}
+
+#define LM_SCAN_CCS 64      // CC boxes per tile (LDS), one active box per thread
+
+LM_DEV bool lm_box_hit_packed(unsigned long long c, unsigned long long u)
+{
+    int cx0 = (int)(c & 0xffff), cx1 = (int)((c >> 16) & 0xffff), cy0 = (int)((c >> 32) & 0xffff), cy1 = (int)(c >> 48);
+    int ux0 = (int)(u & 0xffff), ux1 = (int)((u >> 16) & 0xffff), uy0 = (int)((u >> 32) & 0xffff), uy1 = (int)(u >> 48);
+    return cx0 <= ux1 && ux0 <= cx1 && cy0 <= uy1 && uy0 <= cy1;
+}
+
+LM_DEV unsigned long long lm_pack_box(const LmCcRec& r)
+{
+    return (unsigned long long)(unsigned short)r.min_x | ((unsigned long long)(unsigned short)r.max_x << 16) |
+           ((unsigned long long)(unsigned short)r.min_y << 32) | ((unsigned long long)(unsigned short)r.max_y << 48);
+}
+
+// M1a: candidate scan = box join (current CCs of frame f) x (active uniques), tiled: a block walks its share
+// of (tile of LM_SCAN_CCS CC boxes in LDS) x (chunk of 256 active boxes, one per thread, alive-masked) twice:
+// pass 1 counts each thread's hits, ONE returning atomic per block reserves room in the frame's pair list
+// (a returning atomic on one address serialises at ~88/us on gfx950, so never one per hit), pass 2 writes
+// the pairs (cc index in frame, active position, first-seen CC of the unique).  Order is irrelevant: the
+// decision only needs the SMALLEST accepted position per CC (lm_k_match_eval's atomicMin).
+__global__ void __launch_bounds__(256) lm_k_match_scan(const LmCcRec* __restrict__ cc, const long long* __restrict__ frame_cc_off,
+                                                       int f, const unsigned long long* __restrict__ active_box,
+                                                       const int32_t* __restrict__ active_last, const int32_t* __restrict__ active_cc,
+                                                       LmCounters* __restrict__ cnt, int32_t* __restrict__ best_pos,
+                                                       int4* __restrict__ pairs, int cap_pairs, int max_gap)
+{
+    __shared__ unsigned long long s_cbox[LM_SCAN_CCS];
+    __shared__ int s_base;
     if (cnt->error) return;     // a capacity error leaves frame_cc_off unwritten: do not touch it
     const long long c0 = frame_cc_off[f], c1 = frame_cc_off[f + 1];
+    const int nC = (int)(c1 - c0);
     const int nA = cnt->n_active;
-    for (long long c = c0 + wave; c < c1; c += nwaves) {
-        const LmCcRec rec = cc[c];
-        int found = -1;
-        unsigned long long pairs = 0;
-        for (int a0 = 0; a0 < nA; a0 += 64) {
-            int a = a0 + lane;
-            int u = (a < nA) ? active[a] : -1;
-            bool hit = false;
-            if (u >= 0) hit = lm_box_hit(rec, uniq_box16[u]);
-            unsigned long long mask = __ballot(hit);
-            pairs += (unsigned long long)__popcll(mask);
-            while (found < 0 && mask) {
-                int l = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                int uu = __shfl(u, l);
-                const LmCcRec urec = cc[uniq_cc[uu]];
-                int match = lm_pixel_overlap(rec, urec, crop, lane);
-                double recall = (double)match / (double)rec.size;        // connected_component.py:239
-                double precision = (double)match / (double)urec.size;    // :240
-                if (recall >= min_recall && precision >= min_precision) found = uu;
+    unsigned mine = 0, off = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        for (int ct = blockIdx.y * LM_SCAN_CCS; ct < nC; ct += gridDim.y * LM_SCAN_CCS) {
+            const int tile = (nC - ct < LM_SCAN_CCS) ? nC - ct : LM_SCAN_CCS;
+            __syncthreads();
+            if ((int)threadIdx.x < tile) {
+                s_cbox[threadIdx.x] = lm_pack_box(cc[c0 + ct + threadIdx.x]);
+                if (pass == 0 && blockIdx.x == 0) best_pos[ct + threadIdx.x] = 0x7fffffff;
+            }
+            __syncthreads();
+            for (int a0 = blockIdx.x * 256; a0 < nA; a0 += gridDim.x * 256) {
+                const int a = a0 + (int)threadIdx.x;
+                if (a >= nA) continue;
+                if (!((f <= 1) || ((f - 1) - active_last[a] < max_gap))) continue;     // retired (lazily)
+                const unsigned long long box = active_box[a];
+                if (pass == 0) {
+                    for (int j = 0; j < tile; j++) mine += lm_box_hit_packed(s_cbox[j], box) ? 1u : 0u;
+                } else {
+                    int ucc = -1;
+                    for (int j = 0; j < tile; j++)
+                        if (lm_box_hit_packed(s_cbox[j], box)) {
+                            if (ucc < 0) ucc = active_cc[a];
+                            if ((int)off < cap_pairs) pairs[off] = make_int4(ct + j, a, ucc, 0);
+                            off++;
+                        }
+                }
             }
         }
-        if (lane == 0) {
-            assign[c] = found;
-            if (pairs) atomicAdd(&cnt->tempo_count, pairs);
+        if (pass == 0) {
+            unsigned tot;
+            unsigned ex = lm_block_excl_scan<256>(mine, &tot);
+            if (threadIdx.x == 0) {
+                s_base = tot ? atomicAdd(&cnt->n_pairs, (int)tot) : 0;
+                if (tot) atomicAdd(&cnt->tempo_count, (unsigned long long)tot);
+            }
+            __syncthreads();
+            if (tot == 0) return;       // block-uniform
+            off = (unsigned)s_base + ex;
         }
     }
 }
 
+// M1b: evaluate every candidate pair of the frame; 16 lanes share one pair.
+__global__ void __launch_bounds__(256) lm_k_match_eval(const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
+                                                       const long long* __restrict__ frame_cc_off, int f,
+                                                       const int32_t* __restrict__ active_cc, const LmCounters* __restrict__ cnt,
+                                                       const int4* __restrict__ pairs, int32_t* __restrict__ best_pos, int cap_pairs,
+                                                       double min_recall, double min_precision)
+{
+    if (cnt->error) return;
+    const long long c0 = frame_cc_off[f];
+    int np = cnt->n_pairs;
+    if (np > cap_pairs) np = cap_pairs;     // overflow is turned into LM_ERR_CAPACITY by lm_k_update
+    const int sub = (int)(threadIdx.x & 15);
+    const int group = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+    const int ngroups = (int)((gridDim.x * blockDim.x) >> 4);
+    const int np_pad = (np + 3) & ~3;       // keep whole waves in the loop (4 groups per wave) for the shuffles
+    for (int p = group; p < np_pad; p += ngroups) {
+        int m = 0;
+        LmCcRec rec, urec;
+        int4 pr = make_int4(0, 0, 0, 0);
+        const bool live = p < np;
+        if (live) {
+            pr = pairs[p];
+            rec = cc[c0 + pr.x];
+            urec = cc[pr.z];
+            const LmIsect is = lm_isect(rec, urec);
+            m = lm_overlap_words(rec, urec, is, crop, sub, 16);
+        }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) m += __shfl_xor(m, d, 16);
+        if (live && sub == 0 && lm_accept(m, rec.size, urec.size, min_recall, min_precision))
+            atomicMin(&best_pos[pr.x], pr.y);     // smallest position == smallest unique index == first match (:90-108)
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
-// M2: apply the frame's decisions: number new uniques in CC order, touch matched ones, retire.
-// One block.
+// M2: first accepted candidate per CC (ascending unique index) -> assign; then number the frame's new
+// uniques in CC order and append them to the active list; compact the list (drop retired entries, order
+// preserved) when `compact` is set.  One block.
 // ------------------------------------------------------------------------------------------------
+#define LM_UPD_ITEMS 4
+
 __global__ void __launch_bounds__(1024) lm_k_update(const LmCcRec* __restrict__ cc, const long long* __restrict__ frame_cc_off,
-                                                    int f, int32_t* __restrict__ uniq_cc, unsigned long long* __restrict__ uniq_box16,
-                                                    int32_t* __restrict__ uniq_last, int32_t* __restrict__ active,
-                                                    LmCounters* __restrict__ cnt, int32_t* __restrict__ assign, int max_gap,
-                                                    int cap_uniq)
+                                                    int f, int32_t* __restrict__ active, int32_t* __restrict__ active_cc,
+                                                    unsigned long long* __restrict__ active_box, int32_t* __restrict__ active_last,
+                                                    LmCounters* __restrict__ cnt, int32_t* __restrict__ assign,
+                                                    const int32_t* __restrict__ best_pos, int cap_pairs, int max_gap, int cap_uniq,
+                                                    int compact)
 {
     if (cnt->error) return;
     const long long c0 = frame_cc_off[f], c1 = frame_cc_off[f + 1];
     const int n = (int)(c1 - c0);
-    const int nU = cnt->n_uniq, nA = cnt->n_active;
+    const int nU = cnt->n_uniq;
+    int nA = cnt->n_active;
     __shared__ int s_overflow;
     if (threadIdx.x == 0) s_overflow = 0;
     __syncthreads();
-    unsigned carry = 0;
-    for (int base = 0; base < n; base += 1024) {
-        int i = base + (int)threadIdx.x;
-        int a = (i < n) ? assign[c0 + i] : 0;
-        unsigned isnew = (i < n && a < 0) ? 1u : 0u;
-        unsigned tot;
-        unsigned ex = lm_block_excl_scan<1024>(isnew, &tot);
-        if (i < n) {
-            if (isnew) {
-                long long idx = (long long)nU + carry + ex;
-                if (idx < cap_uniq) {
-                    const LmCcRec r = cc[c0 + i];
-                    assign[c0 + i] = (int32_t)idx;
-                    uniq_cc[idx] = (int32_t)(c0 + i);
-                    uniq_box16[idx] = (unsigned long long)(unsigned short)r.min_x | ((unsigned long long)(unsigned short)r.max_x << 16) |
-                                      ((unsigned long long)(unsigned short)r.min_y << 32) | ((unsigned long long)(unsigned short)r.max_y << 48);
-                    uniq_last[idx] = f;
-                    active[nA + carry + ex] = (int32_t)idx;
-                } else {
-                    s_overflow = 1;
+    // ---- decisions
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const int pos = best_pos[i];
+        int found = -1;
+        if (pos != 0x7fffffff) {
+            found = active[pos];
+            active_last[pos] = f;             // several CCs may hit the same unique: same value
+        }
+        assign[c0 + i] = found;
+    }
+    if (threadIdx.x == 0 && cnt->n_pairs > cap_pairs) s_overflow = 1;
+    __syncthreads();
+    // ---- optional compaction (entries that cannot be candidates at frame f + 1 any more)
+    if (compact && f >= 1) {
+        unsigned kept = 0;
+        for (int base = 0; base < nA; base += 1024 * LM_UPD_ITEMS) {
+            int32_t u[LM_UPD_ITEMS], uc[LM_UPD_ITEMS], ul[LM_UPD_ITEMS];
+            unsigned long long ub[LM_UPD_ITEMS];
+            unsigned keep[LM_UPD_ITEMS], mine = 0;
+#pragma unroll
+            for (int k = 0; k < LM_UPD_ITEMS; k++) {
+                int i = base + (int)threadIdx.x * LM_UPD_ITEMS + k;
+                keep[k] = 0;
+                if (i < nA) {
+                    u[k] = active[i]; uc[k] = active_cc[i]; ub[k] = active_box[i]; ul[k] = active_last[i];
+                    keep[k] = (f - ul[k] < max_gap) ? 1u : 0u;
                 }
-            } else {
-                uniq_last[a] = f;     // several CCs may hit the same unique: same value
+                mine += keep[k];
             }
+            unsigned tot;
+            unsigned ex = lm_block_excl_scan<1024>(mine, &tot);   // barriers inside: all reads of this pass precede its writes
+            unsigned o = kept + ex;
+#pragma unroll
+            for (int k = 0; k < LM_UPD_ITEMS; k++)
+                if (keep[k]) { active[o] = u[k]; active_cc[o] = uc[k]; active_box[o] = ub[k]; active_last[o] = ul[k]; o++; }
+            kept += tot;
+        }
+        nA = (int)kept;
+        __syncthreads();
+    }
+    // ---- new uniques, in CC order
+    unsigned carry = 0;
+    for (int base = 0; base < n; base += 1024 * LM_UPD_ITEMS) {
+        unsigned isnew[LM_UPD_ITEMS], mine = 0;
+#pragma unroll
+        for (int k = 0; k < LM_UPD_ITEMS; k++) {
+            int i = base + (int)threadIdx.x * LM_UPD_ITEMS + k;
+            isnew[k] = (i < n && assign[c0 + i] < 0) ? 1u : 0u;
+            mine += isnew[k];
+        }
+        unsigned tot;
+        unsigned ex = lm_block_excl_scan<1024>(mine, &tot);
+        unsigned o = carry + ex;
+#pragma unroll
+        for (int k = 0; k < LM_UPD_ITEMS; k++) {
+            if (!isnew[k]) continue;
+            long long ci = c0 + base + (long long)threadIdx.x * LM_UPD_ITEMS + k;
+            long long idx = (long long)nU + o;
+            if (idx < cap_uniq) {
+                const LmCcRec r = cc[ci];
+                assign[ci] = (int32_t)idx;
+                active[nA + o] = (int32_t)idx;
+                active_cc[nA + o] = (int32_t)ci;
+                active_last[nA + o] = f;
+                active_box[nA + o] =
+                    (unsigned long long)(unsigned short)r.min_x | ((unsigned long long)(unsigned short)r.max_x << 16) |
+                    ((unsigned long long)(unsigned short)r.min_y << 32) | ((unsigned long long)(unsigned short)r.max_y << 48);
+            } else {
+                s_overflow = 1;
+            }
+            o++;
         }
         carry += tot;
     }
     __syncthreads();
-    const int nA2 = nA + (int)carry;
-    unsigned kept = 0;
-    if (f > 0) {        // the reference only retires inside the t > 0 branch (cc_stability_estimator.py:126-145)
-        for (int base = 0; base < nA2; base += 1024) {
-            int i = base + (int)threadIdx.x;
-            int u = (i < nA2) ? active[i] : 0;
-            unsigned keep = (i < nA2 && (f - uniq_last[u] < max_gap)) ? 1u : 0u;
-            unsigned tot;
-            unsigned ex = lm_block_excl_scan<1024>(keep, &tot);   // barriers inside: every read of this chunk precedes its writes
-            if (keep) active[kept + ex] = u;
-            kept += tot;
-        }
-    } else {
-        kept = (unsigned)nA2;
-    }
     if (threadIdx.x == 0) {
         if (s_overflow) {
             cnt->error = LM_ERR_CAPACITY;
         } else {
             cnt->n_uniq = nU + (int)carry;
-            cnt->n_active = (int)kept;
+            cnt->n_active = nA + (int)carry;
             cnt->n_matched = f + 1;
+            cnt->n_pairs = 0;
         }
     }
 }

@@ -4,8 +4,8 @@
 //   cc[]        one 32-byte record per kept CC of every frame, in (frame, label) order
 //   crop[]      bit-row crops of those CCs (absolute 32-px column alignment, see lm_cc_kernels.hip K8)
 //   assign[]    unique-CC index every kept CC was matched to (cc_stability_estimator.py:102,117)
-//   uniq_*      the "unique CC" table: first-seen CC, compact box for the candidate scan, last frame seen
-//   active[]    ascending list of uniques still matchable (cc_stability_estimator.py:126-145)
+//   active*[]   ascending list of uniques still matchable (cc_stability_estimator.py:126-145): unique index,
+//               first-seen CC, compact box for the candidate scan, last frame matched
 #pragma once
 #include "lm_common.h"
 
@@ -27,7 +27,7 @@ struct LmCounters {
     int n_uniq;
     int n_active;
     int error;           // sticky LM_ERR_* raised on device (capacity)
-    int pad;
+    int n_pairs;         // candidate pairs of the frame being matched
 };
 
 struct LmStream {
@@ -41,10 +41,15 @@ struct LmStream {
     int32_t* assign;
     long long* frame_cc_off;    // [cap_frames + 1]
     uint32_t* crop;
-    int32_t* uniq_cc;           // global cc index of the unique's first-seen CC
-    unsigned long long* uniq_box16;   // min_x | max_x<<16 | min_y<<32 | max_y<<48
-    int32_t* uniq_last;
-    int32_t* active;
+    // active list, parallel arrays in ascending unique index
+    int32_t* active;            // unique index
+    int32_t* active_cc;         // global cc index of the unique's first-seen CC
+    unsigned long long* active_box;   // min_x | max_x<<16 | min_y<<32 | max_y<<48
+    int32_t* active_last;       // last frame the unique was matched
+    // per-frame candidate pairs (reused every frame)
+    int32_t* best_pos;          // [ctx cap] smallest accepted active-list position of the frame's i-th CC
+    int4* pairs;                // [cap_pairs] (cc index in frame, active-list position, unique's first-seen CC, 0), unordered
+    int cap_pairs;
     LmCounters* counters;       // device
     long long* batch_cc_base;   // [max_batch] staging for emit
     unsigned long long* batch_word_base;

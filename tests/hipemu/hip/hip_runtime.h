@@ -26,6 +26,8 @@ struct dim3 {
 struct uint4 { unsigned x, y, z, w; };
 struct int4 { int x, y, z, w; };
 struct uint2 { unsigned x, y; };
+struct int2 { int x, y; };
+static inline int2 make_int2(int a, int b) { return int2{a, b}; }
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
 static inline int4 make_int4(int a, int b, int c, int d) { return int4{a, b, c, d}; }

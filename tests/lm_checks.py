@@ -96,3 +96,19 @@ def check_stream_oracle(lib, frames, max_gap, max_batch=5, **kw):
     r = run_stream(lib, np.stack(frames), w, h, max_gap, max_batch=max_batch, **kw)
     state_equal_oracle(r, st.result())
     return r
+
+
+def check_label_vs_oracle(lib, img):
+    """labels, counts and CC_AgeBoundaries arrays of an arbitrary uint8 frame vs the oracle."""
+    from oracle import cc as occ
+    h, w = img.shape
+    lab = device.FrameLabeler(w, h, 1, lib)
+    try:
+        labels, counts = lab.label(lab.be.from_host(img[None]))
+        l, n = occ.label4(img)
+        assert counts[0] == n and (lab.be.to_host(labels)[0] == l).all()
+        st = lab.stats(counts)
+        if n:
+            assert (st[0] == np.stack(occ.age_boundaries(l, None, n)[:5])).all()
+    finally:
+        lab.close()

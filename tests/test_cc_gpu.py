@@ -91,3 +91,10 @@ def test_label_host(hip_lib, oracle_built):
     n = hip_lib.lm_label_host(img.ctypes.data, 480, 270, out.ctypes.data)
     l, m = oracle_built.label4(img)
     assert n == m and (out == l).all()
+
+
+def test_dense_wide_noise_band_fallback(hip_lib, oracle_built):
+    """> 8192 runs inside one 64-row band (LDS forest falls back to L2 atomics) and > 512 labels per stats tile."""
+    rng = np.random.default_rng(21)
+    img = ((rng.random((70, 1100)) < 0.5) * 255).astype(np.uint8)
+    lm_checks.check_label_vs_oracle(hip_lib, img)

@@ -67,3 +67,10 @@ def test_capacity_error_is_reported(emu_lib):
         fs.counters()
     assert e.value.code == _lib.LM_ERR_CAPACITY
     fs.close()
+
+
+def test_dense_wide_noise_band_fallback(emu_lib, oracle_built):
+    """> 8192 runs inside one 64-row band (LDS forest falls back to L2 atomics) and > 512 labels per stats tile."""
+    rng = np.random.default_rng(21)
+    img = ((rng.random((70, 1100)) < 0.5) * 255).astype(np.uint8)
+    lm_checks.check_label_vs_oracle(emu_lib, img)
