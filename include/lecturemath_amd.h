@@ -112,6 +112,39 @@ int lm_stream_counters(LmStream* s, int64_t* h_out7, void* stream);
 int lm_stream_read(LmStream* s, int32_t* h_rec, int64_t* h_frame_off, int64_t* h_crop_off, uint32_t* h_crop,
                    int32_t* h_active, void* stream);
 
+/* ====================================================================================================
+ * 4. Step 03, CC grouping in space-time (pre_ST3D_v3.0_03_cc_grouping.py:22-118 and the CCStabilityEstimator
+ *    methods it calls, content/cc_stability_estimator.py:181-681) over a finished stream.
+ * ==================================================================================================== */
+typedef struct LmGroups LmGroups;
+
+/* Runs split_stable_cc_by_gaps(max_gap, min_times), get_stable_cc_idxs(min_times),
+ * compute_overlapping_stable_cc(t_window), compute_groups(min_recall), compute_groups_temporal_information,
+ * compute_conflicting_groups, compute_group_images(img_threshold) and prepares frames_from_groups when
+ * reconstruct_tables != 0.  Box join, pixel overlaps, group images and frame rendering run on the device;
+ * the order-dependent list bookkeeping runs on the host.  Returns NULL on failure (lm_last_error). */
+LmGroups* lm_group_run(LmStream* s, int max_gap, int min_times, int t_window, double min_recall, double img_threshold,
+                       int reconstruct_tables, void* stream);
+void lm_group_destroy(LmGroups* g);
+
+/* frames_from_groups (:638-681, the encoded channel 0): frames [first, first + n) -> d_out [n][height][width] uint8 */
+int lm_group_render(LmGroups* g, int first, int n, uint8_t* d_out, void* stream);
+
+/* Host arrays owned by g (valid until lm_group_destroy): *ptr, *count (elements).  Array ids and element types:
+ *  0 UNIQ_CC i32[n_uniq]  first-seen CC record of every unique (after the split)
+ *  1 ULIST_OFF i64[n_uniq+1], 2 ULIST_CC i32   CSR of unique_cc_frames (entries are global CC indices)
+ *  3 ASSIGN i32[n_cc]  unique index of every kept CC after the split (cc_idx_per_frame)
+ *  4 STABLE i32   5 PAIR_A i32, 6 PAIR_B i32, 7 PAIR_MATCH i32  (sorted bbox-overlapping stable pairs + pixel matches)
+ *  8 TOV_OFF i64[n_uniq+1], 9 TOV_OTHER i32, 10 TOV_RECALL f64, 11 TOV_PRECISION f64       time_overlapping_cc
+ * 12 AOV_OFF i64[n_uniq+1], 13 AOV_OTHER i32, 14 AOV_MATCHED i32, 15 AOV_SIZE_OTHER i32, 16 AOV_SIZE_SELF i32   all_overlapping_cc
+ * 17 GRP_OFF i64[n_groups+1], 18 GRP_MEMBERS i32 (cc_groups), 19 GID i32[n_uniq] (group_idx_per_cc, -1 = none)
+ * 20 AGES_OFF i64[n_groups+1], 21 AGES i32 (group_ages), 22 GPF_OFF i64[n_frames+1], 23 GPF i32 (groups_per_frame)
+ * 24 CONF_G1 i32, 25 CONF_G2 i32, 26 CONF_MATCHED i64, 27 CONF_UNMATCHED i64, 28 CONF_UNION i64, 29 CONF_INTER f64
+ * 30 BOUNDS i32[n_groups][4] (min_x, max_x, min_y, max_y)
+ * 31 GIMG_OFF i64[n_items+1] byte offsets, 32 GIMG_ITEM_OFF i64[n_groups+1] first item of a group, 33 GIMG u8 (copied on demand)
+ * 34 SCALARS i64[6]: n_split, total_intersections, n_groups, n_uniq, n_frames, group image bytes */
+int lm_group_array(LmGroups* g, int which, const void** ptr, int64_t* count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,10 @@ SIGNATURES = {
     "lm_stream_push": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "lm_stream_counters": (ctypes.c_int, [_vp, _vp, _vp]),
     "lm_stream_read": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lm_group_run": (_vp, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f64, _f64, ctypes.c_int, _vp]),
+    "lm_group_destroy": (None, [_vp]),
+    "lm_group_render": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    "lm_group_array": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
 }
 
 

@@ -11,6 +11,7 @@
 
 #include "lm_cc_kernels.hip"
 #include "lm_match_kernels.hip"
+#include "lm_group.hip"
 
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";

@@ -1,0 +1,672 @@
+// lm_group.hip -- step 03 (CC grouping in space-time) over a finished device-resident stream.
+//
+// Replaces pre_ST3D_v3.0_03_cc_grouping.py:22-118 and the CCStabilityEstimator methods it calls
+// (AccessMath/preprocessing/content/cc_stability_estimator.py, paths relative to
+// /root/reference/ACCESS2021_release):
+//   split_stable_cc_by_gaps :181-228, get_stable_cc_idxs :230-236            host (list bookkeeping)
+//   compute_overlapping_stable_cc :245-306   box self-join + pixel overlaps    DEVICE (lm_k_selfjoin, lm_k_pair_overlap)
+//                                            recall/precision/time window      host (float64, same expressions)
+//   compute_groups :308-413                  order-dependent list merging      host (sequential by definition)
+//   compute_groups_temporal_information :415-444, compute_conflicting_groups :446-500   host
+//   compute_group_images :575-636            accumulate crops x counts, /max, >= thr   DEVICE (lm_k_gimg_max, lm_k_gimg_write)
+//   frames_from_groups :638-681              uint8 wrap-around compositing of channel 0   DEVICE (lm_k_render_frames)
+// The dead work of the reference is not reproduced: rebuilt_binary_images (result unused,
+// 03_cc_grouping.py:41) and the channel-1/2 painting that is never encoded (:661-671,678).
+#include "lm_stream.h"
+
+#include <algorithm>
+#include <unordered_map>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------
+// G1: box self-join of the stable uniques (pairs k1 < k2 in the stable list, i.e. idx1 < idx2).
+// Thread = one "column" box k2, block tile = 256 "row" boxes k1 in LDS.  Count / reserve / fill.
+// ------------------------------------------------------------------------------------------------
+#define LM_SJ_TILE 256
+
+__global__ void __launch_bounds__(256) lm_k_selfjoin(const unsigned long long* __restrict__ box, int n, int* __restrict__ n_pairs,
+                                                     int2* __restrict__ pairs, int cap_pairs)
+{
+    __shared__ unsigned long long s_box[LM_SJ_TILE];
+    __shared__ int s_base;
+    unsigned mine = 0, off = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        for (int rt = blockIdx.y * LM_SJ_TILE; rt < n; rt += gridDim.y * LM_SJ_TILE) {
+            const int tile = (n - rt < LM_SJ_TILE) ? n - rt : LM_SJ_TILE;
+            __syncthreads();
+            if ((int)threadIdx.x < tile) s_box[threadIdx.x] = box[rt + threadIdx.x];
+            __syncthreads();
+            for (int c0 = blockIdx.x * 256; c0 < n; c0 += gridDim.x * 256) {
+                if (c0 + 255 <= rt) continue;               // every column of the chunk <= every row of the tile
+                const int k2 = c0 + (int)threadIdx.x;
+                if (k2 >= n) continue;
+                const unsigned long long b2 = box[k2];
+                int lim = k2 - rt;                          // rows k1 = rt + j with k1 < k2
+                if (lim > tile) lim = tile;
+                for (int j = 0; j < lim; j++) {
+                    if (!lm_box_hit_packed(s_box[j], b2)) continue;
+                    if (pass == 0) {
+                        mine++;
+                    } else {
+                        if ((int)off < cap_pairs) pairs[off] = make_int2(rt + j, k2);
+                        off++;
+                    }
+                }
+            }
+        }
+        if (pass == 0) {
+            unsigned tot;
+            unsigned ex = lm_block_excl_scan<256>(mine, &tot);
+            if (threadIdx.x == 0) s_base = tot ? atomicAdd(n_pairs, (int)tot) : 0;
+            __syncthreads();
+            if (tot == 0) return;
+            off = (unsigned)s_base + ex;
+        }
+    }
+}
+
+// G2: pixel overlap of every pair; 16 lanes share one pair.
+__global__ void __launch_bounds__(256) lm_k_pair_overlap(const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
+                                                         const int32_t* __restrict__ su_cc, const int2* __restrict__ pairs, int np,
+                                                         int32_t* __restrict__ match)
+{
+    const int sub = (int)(threadIdx.x & 15);
+    const int group = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+    const int ngroups = (int)((gridDim.x * blockDim.x) >> 4);
+    const int np_pad = (np + 3) & ~3;
+    for (int p = group; p < np_pad; p += ngroups) {
+        int m = 0;
+        const bool live = p < np;
+        if (live) {
+            const int2 pr = pairs[p];
+            const LmCcRec a = cc[su_cc[pr.x]], u = cc[su_cc[pr.y]];
+            const LmIsect is = lm_isect(a, u);
+            m = lm_overlap_words(a, u, is, crop, sub, 16);
+        }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) m += __shfl_xor(m, d, 16);
+        if (live && sub == 0) match[p] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// G3: group images.  Item = (group, age segment); its image covers the group's box.  For every item the
+// host lists the members present in the segment with the number of frame entries they have in it.
+// Work unit = (item, 64x64 tile of its box): accumulate (crop bit) * count into an LDS int32 tile.
+//   pass A (lm_k_gimg_max)    per-item maximum of the accumulated mask
+//   pass B (lm_k_gimg_write)  recompute and write  ((double)v / (double)max >= thr) ? 255 : 0
+// ------------------------------------------------------------------------------------------------
+struct LmGimgItem {
+    int32_t x0, y0, w, h;        // group box origin and size
+    int32_t mem_off, mem_cnt;    // slice of the member list
+    long long img_off;           // byte offset of the item's (h x w) uint8 image
+};
+struct LmGimgMember { int32_t cc; int32_t count; };
+struct LmGimgUnit { int32_t item; int16_t tx, ty; };
+
+#define LM_GT 64   // tile side
+
+LM_DEV void lm_gimg_accumulate(const LmGimgItem& it, int tx, int ty, const LmGimgMember* __restrict__ members,
+                               const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop, int* s_mask)
+{
+    // tile covers x in [X0, X0+64), y in [Y0, Y0+64) of the frame
+    const int X0 = it.x0 + tx * LM_GT, Y0 = it.y0 + ty * LM_GT;
+    for (int i = threadIdx.x; i < LM_GT * LM_GT; i += blockDim.x) s_mask[i] = 0;
+    __syncthreads();
+    const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6), lane = lm_lane();
+    for (int m = wave; m < it.mem_cnt; m += nwaves) {
+        const LmGimgMember mem = members[it.mem_off + m];
+        const LmCcRec r = cc[mem.cc];
+        if (r.max_x < X0 || r.min_x >= X0 + LM_GT || r.max_y < Y0 || r.min_y >= Y0 + LM_GT) continue;
+        const int wx0 = r.min_x >> 5, nw = (r.max_x >> 5) - wx0 + 1;
+        const int ya = r.min_y > Y0 ? r.min_y : Y0;
+        const int yb = r.max_y < Y0 + LM_GT - 1 ? r.max_y : Y0 + LM_GT - 1;
+        const int total = nw * (yb - ya + 1);
+        for (int idx = lane; idx < total; idx += 64) {
+            const int rr = idx / nw, j = idx - rr * nw;
+            const int y = ya + rr;
+            unsigned wbits = crop[r.crop_off + (unsigned long long)((y - r.min_y) * nw + j)];
+            const int xw = (wx0 + j) * 32;
+            while (wbits) {
+                const int b = __ffs((int)wbits) - 1;
+                wbits &= wbits - 1;
+                const int x = xw + b;
+                if (x >= X0 && x < X0 + LM_GT) atomicAdd(&s_mask[(y - Y0) * LM_GT + (x - X0)], mem.count);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) lm_k_gimg_max(const LmGimgItem* __restrict__ items, const LmGimgUnit* __restrict__ units,
+                                                     int n_units, const LmGimgMember* __restrict__ members,
+                                                     const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
+                                                     int32_t* __restrict__ item_max)
+{
+    __shared__ int s_mask[LM_GT * LM_GT];
+    __shared__ int s_max;
+    for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const LmGimgUnit un = units[u];
+        const LmGimgItem it = items[un.item];
+        if (threadIdx.x == 0) s_max = 0;
+        lm_gimg_accumulate(it, un.tx, un.ty, members, cc, crop, s_mask);
+        int mx = 0;
+        for (int i = threadIdx.x; i < LM_GT * LM_GT; i += blockDim.x) mx = s_mask[i] > mx ? s_mask[i] : mx;
+        if (mx) atomicMax(&s_max, mx);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_max) atomicMax(&item_max[un.item], s_max);
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) lm_k_gimg_write(const LmGimgItem* __restrict__ items, const LmGimgUnit* __restrict__ units,
+                                                       int n_units, const LmGimgMember* __restrict__ members,
+                                                       const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
+                                                       const int32_t* __restrict__ item_max, double thr, uint8_t* __restrict__ images)
+{
+    __shared__ int s_mask[LM_GT * LM_GT];
+    for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const LmGimgUnit un = units[u];
+        const LmGimgItem it = items[un.item];
+        lm_gimg_accumulate(it, un.tx, un.ty, members, cc, crop, s_mask);
+        const double mx = (double)item_max[un.item];
+        const int tw = (it.w - un.tx * LM_GT < LM_GT) ? it.w - un.tx * LM_GT : LM_GT;
+        const int th = (it.h - un.ty * LM_GT < LM_GT) ? it.h - un.ty * LM_GT : LM_GT;
+        for (int i = threadIdx.x; i < tw * th; i += blockDim.x) {
+            const int yy = i / tw, xx = i - yy * tw;
+            const double v = (double)s_mask[yy * LM_GT + xx] / mx;      // float64 like numpy (:630); max >= 1 by construction
+            images[it.img_off + (long long)(un.ty * LM_GT + yy) * it.w + (un.tx * LM_GT + xx)] = (v >= thr) ? 255 : 0;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// G4: frames_from_groups, channel 0: canvas[y, x] = sum over the frame's live groups of their current
+// segment image, uint8 wrap-around.  Every contribution is 0 or 255 (== -1 mod 256), so the pixel is
+// (-k) mod 256 with k = number of contributing segment pixels.  Block = (frame, 64-row x 256-col tile),
+// k counted in LDS.
+// ------------------------------------------------------------------------------------------------
+struct LmRenderItem { int32_t x0, y0, w, h; long long img_off; };
+
+#define LM_RT_ROWS 64
+#define LM_RT_COLS 256
+
+__global__ void __launch_bounds__(256) lm_k_render_frames(const long long* __restrict__ frame_item_off,
+                                                          const LmRenderItem* __restrict__ items, const uint8_t* __restrict__ images,
+                                                          int first_frame, int W, int H, uint8_t* __restrict__ out)
+{
+    __shared__ int s_cnt[LM_RT_ROWS * LM_RT_COLS];
+    const int f = first_frame + blockIdx.z;
+    const int X0 = blockIdx.x * LM_RT_COLS, Y0 = blockIdx.y * LM_RT_ROWS;
+    for (int i = threadIdx.x; i < LM_RT_ROWS * LM_RT_COLS; i += blockDim.x) s_cnt[i] = 0;
+    __syncthreads();
+    const long long i0 = frame_item_off[f], i1 = frame_item_off[f + 1];
+    const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6), lane = lm_lane();
+    for (long long i = i0 + wave; i < i1; i += nwaves) {
+        const LmRenderItem it = items[i];
+        const int xa = it.x0 > X0 ? it.x0 : X0, xb = (it.x0 + it.w < X0 + LM_RT_COLS) ? it.x0 + it.w : X0 + LM_RT_COLS;
+        const int ya = it.y0 > Y0 ? it.y0 : Y0, yb = (it.y0 + it.h < Y0 + LM_RT_ROWS) ? it.y0 + it.h : Y0 + LM_RT_ROWS;
+        if (xa >= xb || ya >= yb) continue;
+        const int tw = xb - xa, total = tw * (yb - ya);
+        for (int idx = lane; idx < total; idx += 64) {
+            const int yy = idx / tw, xx = idx - yy * tw;
+            const int y = ya + yy, x = xa + xx;
+            if (images[it.img_off + (long long)(y - it.y0) * it.w + (x - it.x0)]) atomicAdd(&s_cnt[(y - Y0) * LM_RT_COLS + (x - X0)], 1);
+        }
+    }
+    __syncthreads();
+    uint8_t* dst = out + (long long)blockIdx.z * W * H;
+    for (int i = threadIdx.x; i < LM_RT_ROWS * LM_RT_COLS; i += blockDim.x) {
+        const int yy = i / LM_RT_COLS, xx = i - yy * LM_RT_COLS;
+        const int y = Y0 + yy, x = X0 + xx;
+        if (y < H && x < W) dst[(long long)y * W + x] = (uint8_t)((0u - (unsigned)s_cnt[i]) & 0xffu);
+    }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+struct LmGroups {
+    LmStream* s;
+    // parameters
+    int max_gap, min_times, t_window;
+    double min_recall, img_thr;
+    int n_frames, n_uniq0;
+    // ---- results (host)
+    int64_t n_split;
+    std::vector<int32_t> uniq_cc;               // [n_uniq] first-seen CC record of every unique (aliases after split)
+    std::vector<int64_t> ulist_off;             // [n_uniq+1] CSR of every unique's entries
+    std::vector<int32_t> ulist_cc;              // global cc index of each entry (frame and raw label follow from the record)
+    std::vector<int32_t> assign;                // [n_cc] unique index per kept CC after the split
+    std::vector<int32_t> stable;                // stable unique indices, ascending
+    std::vector<int32_t> pair_a, pair_b, pair_match;      // bbox-overlapping stable pairs (unique indices, a < b), sorted
+    int64_t total_intersections;
+    std::vector<int64_t> tov_off; std::vector<int32_t> tov_other; std::vector<double> tov_recall, tov_precision;
+    std::vector<int64_t> aov_off; std::vector<int32_t> aov_other, aov_matched, aov_size_other, aov_size_self;
+    std::vector<int64_t> grp_off; std::vector<int32_t> grp_members;     // cc_groups
+    std::vector<int32_t> gid_of_unique;         // [n_uniq] group of a unique or -1
+    std::vector<int64_t> ages_off; std::vector<int32_t> ages;           // group_ages
+    std::vector<int64_t> gpf_off; std::vector<int32_t> gpf;             // groups_per_frame
+    std::vector<int32_t> conf_g1, conf_g2; std::vector<int64_t> conf_matched, conf_unmatched, conf_union; std::vector<double> conf_inter;
+    std::vector<int32_t> bounds;                // [n_groups][4] min_x, max_x, min_y, max_y
+    std::vector<int64_t> gimg_off;              // [n_items + 1] byte offsets of the segment images (item order: group, segment)
+    std::vector<int64_t> gimg_item_off;         // [n_groups + 1] first item of every group
+    std::vector<uint8_t> gimg_host;             // filled on demand
+    // ---- device
+    uint8_t* d_images = nullptr;
+    long long* d_frame_item_off = nullptr;
+    LmRenderItem* d_render_items = nullptr;
+    std::vector<void*> d_owned;
+};
+
+#define LM_G_ARRAYS 40
+enum {
+    LM_G_UNIQ_CC = 0, LM_G_ULIST_OFF, LM_G_ULIST_CC, LM_G_ASSIGN, LM_G_STABLE, LM_G_PAIR_A, LM_G_PAIR_B, LM_G_PAIR_MATCH,
+    LM_G_TOV_OFF, LM_G_TOV_OTHER, LM_G_TOV_RECALL, LM_G_TOV_PRECISION, LM_G_AOV_OFF, LM_G_AOV_OTHER, LM_G_AOV_MATCHED,
+    LM_G_AOV_SIZE_OTHER, LM_G_AOV_SIZE_SELF, LM_G_GRP_OFF, LM_G_GRP_MEMBERS, LM_G_GID, LM_G_AGES_OFF, LM_G_AGES, LM_G_GPF_OFF,
+    LM_G_GPF, LM_G_CONF_G1, LM_G_CONF_G2, LM_G_CONF_MATCHED, LM_G_CONF_UNMATCHED, LM_G_CONF_UNION, LM_G_CONF_INTER, LM_G_BOUNDS,
+    LM_G_GIMG_OFF, LM_G_GIMG_ITEM_OFF, LM_G_GIMG, LM_G_SCALARS
+};
+
+template <class T> static int lm_upload(LmGroups* g, const std::vector<T>& v, T** d)
+{
+    *d = nullptr;
+    LM_HIP(hipMalloc((void**)d, (v.size() ? v.size() : 1) * sizeof(T)));
+    g->d_owned.push_back(*d);
+    if (!v.empty()) LM_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return LM_OK;
+}
+
+extern "C" void lm_group_destroy(LmGroups* g)
+{
+    if (!g) return;
+    for (void* p : g->d_owned) (void)hipFree(p);
+    delete g;
+}
+
+static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st)
+{
+    LmStream* s = g->s;
+    int64_t k[7];
+    int rc = lm_stream_counters(s, k, st);
+    if (rc) return rc;
+    const int F = (int)k[0];
+    const long long n_cc = k[1];
+    const int nU0 = (int)k[3];
+    g->n_frames = F;
+    g->n_uniq0 = nU0;
+    // ---- records to the host
+    std::vector<int32_t> rec((size_t)std::max<long long>(n_cc, 1) * 8);
+    std::vector<int64_t> foff((size_t)F + 1);
+    rc = lm_stream_read(s, rec.data(), foff.data(), nullptr, nullptr, nullptr, st);
+    if (rc) return rc;
+    auto R = [&](long long c, int field) { return rec[(size_t)c * 8 + field]; };   // 0 cc_id 1 min_x 2 max_x 3 min_y 4 max_y 5 size 6 frame 7 assign
+
+    // ---- per-unique entry lists (CC order == ascending frame, the reference's append order)
+    std::vector<int64_t> cnt((size_t)nU0 + 1, 0);
+    for (long long c = 0; c < n_cc; c++) cnt[(size_t)R(c, 7) + 1]++;
+    for (int u = 0; u < nU0; u++) cnt[(size_t)u + 1] += cnt[u];
+    std::vector<int32_t> lst((size_t)std::max<long long>(n_cc, 1));
+    {
+        std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
+        for (long long c = 0; c < n_cc; c++) lst[(size_t)pos[R(c, 7)]++] = (int32_t)c;
+    }
+    // ---- split_stable_cc_by_gaps (:181-228)
+    g->assign.resize((size_t)std::max<long long>(n_cc, 1));
+    for (long long c = 0; c < n_cc; c++) g->assign[(size_t)c] = R(c, 7);
+    g->uniq_cc.resize(nU0);
+    std::vector<std::pair<int64_t, int64_t>> seg((size_t)nU0);      // [begin, end) in lst of every unique
+    for (int u = 0; u < nU0; u++) {
+        seg[u] = {cnt[u], cnt[(size_t)u + 1]};
+        g->uniq_cc[u] = lst[(size_t)cnt[u]];    // every unique has at least its first-seen entry
+    }
+    g->n_split = 0;
+    for (int u = 0; u < nU0; u++) {
+        const int64_t b = cnt[u], e = cnt[(size_t)u + 1];
+        const int64_t n_local = e - b;
+        std::vector<int64_t> cuts;              // starts of later runs
+        for (int64_t i = b + 1; i < e; i++)
+            if (R(lst[(size_t)i], 6) - R(lst[(size_t)i - 1], 6) > g->max_gap) cuts.push_back(i);
+        if (cuts.empty() || n_local < g->min_times) continue;
+        seg[u].second = cuts[0];
+        for (size_t ci = 0; ci < cuts.size(); ci++) {
+            const int64_t rb = cuts[ci], re = (ci + 1 < cuts.size()) ? cuts[ci + 1] : e;
+            const int new_u = (int)seg.size();
+            seg.push_back({rb, re});
+            g->uniq_cc.push_back(g->uniq_cc[u]);            // another reference to the original CC (:212)
+            for (int64_t i = rb; i < re; i++) g->assign[(size_t)lst[(size_t)i]] = new_u;
+        }
+        g->n_split++;
+    }
+    const int nU = (int)seg.size();
+    g->ulist_off.assign((size_t)nU + 1, 0);
+    g->ulist_cc.clear();
+    g->ulist_cc.reserve((size_t)n_cc);
+    for (int u = 0; u < nU; u++) {
+        for (int64_t i = seg[u].first; i < seg[u].second; i++) g->ulist_cc.push_back(lst[(size_t)i]);
+        g->ulist_off[(size_t)u + 1] = (int64_t)g->ulist_cc.size();
+    }
+    auto first_frame = [&](int u) { return R(g->ulist_cc[(size_t)g->ulist_off[u]], 6); };
+    auto last_frame = [&](int u) { return R(g->ulist_cc[(size_t)g->ulist_off[(size_t)u + 1] - 1], 6); };
+    auto usize = [&](int u) { return R(g->uniq_cc[u], 5); };
+    auto ubox = [&](int u, int i) { return R(g->uniq_cc[u], 1 + i); };     // min_x max_x min_y max_y
+
+    // ---- stable set (:230-236)
+    g->stable.clear();
+    for (int u = 0; u < nU; u++)
+        if (g->ulist_off[(size_t)u + 1] - g->ulist_off[u] >= g->min_times) g->stable.push_back(u);
+    const int nS = (int)g->stable.size();
+
+    // ---- overlapping stable CCs (:245-306): box self-join + pixel overlaps on the device
+    g->pair_a.clear(); g->pair_b.clear(); g->pair_match.clear();
+    if (nS > 1) {
+        std::vector<unsigned long long> hbox((size_t)nS);
+        std::vector<int32_t> hcc((size_t)nS);
+        for (int i = 0; i < nS; i++) {
+            const int u = g->stable[i];
+            hbox[i] = (unsigned long long)(unsigned short)ubox(u, 0) | ((unsigned long long)(unsigned short)ubox(u, 1) << 16) |
+                      ((unsigned long long)(unsigned short)ubox(u, 2) << 32) | ((unsigned long long)(unsigned short)ubox(u, 3) << 48);
+            hcc[i] = g->uniq_cc[u];
+        }
+        unsigned long long* d_box; int32_t* d_cc; int* d_np;
+        if (lm_upload(g, hbox, &d_box) || lm_upload(g, hcc, &d_cc)) return LM_ERR_HIP;
+        LM_HIP(hipMalloc((void**)&d_np, 64));
+        g->d_owned.push_back(d_np);
+        int cap_pairs = 1 << 22;
+        int2* d_pairs = nullptr;
+        int np = 0;
+        for (;;) {
+            LM_HIP(hipMalloc((void**)&d_pairs, (size_t)cap_pairs * sizeof(int2)));
+            LM_HIP(hipMemsetAsync(d_np, 0, sizeof(int), st));
+            const int gx = std::min((nS + 255) / 256, LM_HIP_EMULATED ? 2 : 64), gy = std::min((nS + LM_SJ_TILE - 1) / LM_SJ_TILE, LM_HIP_EMULATED ? 2 : 64);
+            hipLaunchKernelGGL(lm_k_selfjoin, dim3(gx, gy), dim3(256), 0, st, d_box, nS, d_np, d_pairs, cap_pairs);
+            LM_HIP(hipMemcpyAsync(&np, d_np, sizeof(int), hipMemcpyDeviceToHost, st));
+            LM_HIP(hipStreamSynchronize(st));
+            if (np <= cap_pairs) break;
+            (void)hipFree(d_pairs);         // grow and redo (the join is cheap)
+            cap_pairs = np + (np >> 3);
+        }
+        g->d_owned.push_back(d_pairs);
+        if (np > 0) {
+            int32_t* d_match;
+            LM_HIP(hipMalloc((void**)&d_match, (size_t)np * sizeof(int32_t)));
+            g->d_owned.push_back(d_match);
+            hipLaunchKernelGGL(lm_k_pair_overlap, dim3(LM_HIP_EMULATED ? 2 : 1024), dim3(256), 0, st, s->cc, s->crop, d_cc, d_pairs, np, d_match);
+            std::vector<int2> hp((size_t)np);
+            std::vector<int32_t> hm((size_t)np);
+            LM_HIP(hipMemcpyAsync(hp.data(), d_pairs, (size_t)np * sizeof(int2), hipMemcpyDeviceToHost, st));
+            LM_HIP(hipMemcpyAsync(hm.data(), d_match, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            LM_HIP(hipStreamSynchronize(st));
+            std::vector<int32_t> order((size_t)np);
+            for (int i = 0; i < np; i++) order[i] = i;
+            std::sort(order.begin(), order.end(), [&](int x, int y) { return hp[x].x != hp[y].x ? hp[x].x < hp[y].x : hp[x].y < hp[y].y; });
+            g->pair_a.resize(np); g->pair_b.resize(np); g->pair_match.resize(np);
+            for (int i = 0; i < np; i++) {
+                const int o = order[i];
+                g->pair_a[i] = g->stable[hp[o].x]; g->pair_b[i] = g->stable[hp[o].y]; g->pair_match[i] = hm[o];
+            }
+        }
+    }
+    // per-unique neighbour lists, filled in sorted pair order (== the reference's iteration order)
+    struct Tov { int32_t other; double recall, precision; };
+    struct Aov { int32_t other, matched, size_other, size_self; };
+    std::vector<std::vector<Tov>> tov((size_t)nU);
+    std::vector<std::vector<Aov>> aov((size_t)nU);
+    g->total_intersections = 0;
+    for (size_t i = 0; i < g->pair_a.size(); i++) {
+        const int a = g->pair_a[i], b = g->pair_b[i];
+        const int match = g->pair_match[i];
+        const int sa = usize(a), sb = usize(b);
+        const double recall = (double)match / (double)sa;           // connected_component.py:239
+        const double precision = (double)match / (double)sb;        // :240
+        if (recall > 0.0 || precision > 0.0) {
+            const int matched_pixels = (int)((double)sa * recall);   // float64 round trip, can be match-1 (:294)
+            aov[a].push_back({b, matched_pixels, sb, sa});
+            aov[b].push_back({a, matched_pixels, sa, sb});
+            if (last_frame(a) + g->t_window >= first_frame(b) && last_frame(b) >= first_frame(a) - g->t_window) {
+                tov[a].push_back({b, recall, precision});
+                tov[b].push_back({a, precision, recall});
+                g->total_intersections++;
+            }
+        }
+    }
+    // ---- compute_groups (:308-413): sequential, order-dependent
+    std::vector<std::vector<int32_t>> groups;
+    std::vector<int32_t> gid((size_t)nU, -1);
+    for (int a : g->stable) {
+        int gi;
+        if (gid[a] >= 0) gi = gid[a];
+        else { gi = (int)groups.size(); groups.push_back({a}); gid[a] = gi; }
+        for (const Tov& t : tov[a]) {
+            if (t.recall < g->min_recall) continue;
+            const int b = t.other;
+            if (gid[b] < 0) { gid[b] = gi; groups[gi].push_back(b); }
+            else if (gid[b] != gi) {
+                const int og = gid[b];
+                for (int m : groups[og]) { gid[m] = gi; groups[gi].push_back(m); }
+                groups[og].clear();
+            }
+        }
+    }
+    g->grp_off.assign(1, 0);
+    g->grp_members.clear();
+    g->gid_of_unique.assign((size_t)nU, -1);
+    for (auto& grp : groups) {
+        if (grp.empty()) continue;
+        const int ng = (int)g->grp_off.size() - 1;
+        for (int m : grp) { g->grp_members.push_back(m); g->gid_of_unique[m] = ng; }
+        g->grp_off.push_back((int64_t)g->grp_members.size());
+    }
+    const int nG = (int)g->grp_off.size() - 1;
+    // ---- temporal information (:415-444)
+    g->ages_off.assign(1, 0); g->ages.clear();
+    std::vector<std::vector<int32_t>> gpf((size_t)F);
+    for (int gi = 0; gi < nG; gi++) {
+        std::vector<int32_t> a;
+        for (int64_t i = g->grp_off[gi]; i < g->grp_off[(size_t)gi + 1]; i++) {
+            const int u = g->grp_members[(size_t)i];
+            a.push_back(first_frame(u));
+            a.push_back(last_frame(u));
+        }
+        std::sort(a.begin(), a.end());
+        a.erase(std::unique(a.begin(), a.end()), a.end());
+        for (int v : a) g->ages.push_back(v);
+        g->ages_off.push_back((int64_t)g->ages.size());
+        for (int f = a.front(); f < std::min(a.back() + 1, F); f++) gpf[f].push_back(gi);
+    }
+    g->gpf_off.assign(1, 0); g->gpf.clear();
+    for (int f = 0; f < F; f++) { for (int v : gpf[f]) g->gpf.push_back(v); g->gpf_off.push_back((int64_t)g->gpf.size()); }
+    // ---- conflicts (:446-500); emitted grouped by g1 in first-insertion order of g2
+    {
+        struct Acc { int64_t matched = 0, unmatched = 0, area_union = 0; double inter = 0; };
+        std::vector<std::vector<std::pair<int32_t, Acc>>> conf((size_t)nG);
+        std::vector<std::unordered_map<int32_t, int32_t>> idx((size_t)nG);
+        auto add = [&](int x, int y, int64_t m, int64_t um, int64_t au, double ai) {
+            auto it = idx[x].find(y);
+            if (it == idx[x].end()) { idx[x][y] = (int32_t)conf[x].size(); conf[x].push_back({y, Acc()}); it = idx[x].find(y); }
+            Acc& a = conf[x][it->second].second;
+            a.matched += m; a.unmatched += um; a.area_union += au; a.inter += ai;
+        };
+        auto area = [&](int u) { return (int64_t)(ubox(u, 1) - ubox(u, 0) + 1) * (ubox(u, 3) - ubox(u, 2) + 1); };
+        for (int a : g->stable)
+            for (const Aov& t : aov[a]) {
+                const int b = t.other;
+                if (!(a < b)) continue;
+                const int64_t unmatched = (int64_t)t.size_self + t.size_other - (int64_t)t.matched * 2;
+                int64_t inter = 0;
+                if (ubox(a, 0) <= ubox(b, 1) && ubox(b, 0) <= ubox(a, 1) && ubox(a, 2) <= ubox(b, 3) && ubox(b, 2) <= ubox(a, 3))
+                    inter = (int64_t)(std::min(ubox(a, 1), ubox(b, 1)) - std::max(ubox(a, 0), ubox(b, 0)) + 1) *
+                            (std::min(ubox(a, 3), ubox(b, 3)) - std::max(ubox(a, 2), ubox(b, 2)) + 1);
+                const int64_t uni = area(a) + area(b) - inter;
+                const int ga = g->gid_of_unique[a], gb = g->gid_of_unique[b];
+                if (ga == gb) continue;
+                add(ga, gb, t.matched, unmatched, uni, (double)inter);
+                add(gb, ga, t.matched, unmatched, uni, (double)inter);
+            }
+        g->conf_g1.clear(); g->conf_g2.clear(); g->conf_matched.clear(); g->conf_unmatched.clear(); g->conf_union.clear(); g->conf_inter.clear();
+        for (int x = 0; x < nG; x++)
+            for (auto& e : conf[x]) {
+                g->conf_g1.push_back(x); g->conf_g2.push_back(e.first); g->conf_matched.push_back(e.second.matched);
+                g->conf_unmatched.push_back(e.second.unmatched); g->conf_union.push_back(e.second.area_union); g->conf_inter.push_back(e.second.inter);
+            }
+    }
+    // flatten the neighbour lists
+    g->tov_off.assign(1, 0); g->tov_other.clear(); g->tov_recall.clear(); g->tov_precision.clear();
+    g->aov_off.assign(1, 0); g->aov_other.clear(); g->aov_matched.clear(); g->aov_size_other.clear(); g->aov_size_self.clear();
+    for (int u = 0; u < nU; u++) {
+        for (const Tov& t : tov[u]) { g->tov_other.push_back(t.other); g->tov_recall.push_back(t.recall); g->tov_precision.push_back(t.precision); }
+        g->tov_off.push_back((int64_t)g->tov_other.size());
+        for (const Aov& t : aov[u]) { g->aov_other.push_back(t.other); g->aov_matched.push_back(t.matched); g->aov_size_other.push_back(t.size_other); g->aov_size_self.push_back(t.size_self); }
+        g->aov_off.push_back((int64_t)g->aov_other.size());
+    }
+    // ---- group images (:575-636)
+    g->bounds.assign((size_t)nG * 4, 0);
+    std::vector<LmGimgItem> items;
+    std::vector<LmGimgMember> members;
+    std::vector<LmGimgUnit> units;
+    g->gimg_off.assign(1, 0);
+    g->gimg_item_off.assign(1, 0);
+    for (int gi = 0; gi < nG; gi++) {
+        int x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
+        for (int64_t i = g->grp_off[gi]; i < g->grp_off[(size_t)gi + 1]; i++) {
+            const int u = g->grp_members[(size_t)i];
+            x0 = std::min(x0, (int)ubox(u, 0)); x1 = std::max(x1, (int)ubox(u, 1));
+            y0 = std::min(y0, (int)ubox(u, 2)); y1 = std::max(y1, (int)ubox(u, 3));
+        }
+        g->bounds[(size_t)gi * 4 + 0] = x0; g->bounds[(size_t)gi * 4 + 1] = x1; g->bounds[(size_t)gi * 4 + 2] = y0; g->bounds[(size_t)gi * 4 + 3] = y1;
+        const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+        for (int64_t ai = g->ages_off[gi]; ai + 1 < g->ages_off[(size_t)gi + 1]; ai++) {
+            const int t0 = g->ages[(size_t)ai], t1 = g->ages[(size_t)ai + 1];
+            LmGimgItem it;
+            it.x0 = x0; it.y0 = y0; it.w = w; it.h = h;
+            it.mem_off = (int32_t)members.size();
+            for (int64_t i = g->grp_off[gi]; i < g->grp_off[(size_t)gi + 1]; i++) {
+                const int u = g->grp_members[(size_t)i];
+                int count = 0;                              // entries with t0 <= frame <= t1, duplicates counted (:619)
+                for (int64_t e = g->ulist_off[u]; e < g->ulist_off[(size_t)u + 1]; e++) {
+                    const int fr = R(g->ulist_cc[(size_t)e], 6);
+                    if (fr > t1) break;
+                    if (fr >= t0) count++;
+                }
+                if (count) members.push_back({g->uniq_cc[u], count});
+            }
+            it.mem_cnt = (int32_t)members.size() - it.mem_off;
+            it.img_off = g->gimg_off.back();
+            const int item_idx = (int)items.size();
+            items.push_back(it);
+            g->gimg_off.push_back(it.img_off + (int64_t)w * h);
+            for (int ty = 0; ty * LM_GT < h; ty++)
+                for (int tx = 0; tx * LM_GT < w; tx++) units.push_back({item_idx, (int16_t)tx, (int16_t)ty});
+        }
+        g->gimg_item_off.push_back((int64_t)items.size());
+    }
+    const long long img_bytes = g->gimg_off.back();
+    LM_HIP(hipMalloc((void**)&g->d_images, (size_t)std::max<long long>(img_bytes, 1)));
+    g->d_owned.push_back(g->d_images);
+    if (!items.empty()) {
+        LmGimgItem* d_items; LmGimgMember* d_members; LmGimgUnit* d_units; int32_t* d_max;
+        if (lm_upload(g, items, &d_items) || lm_upload(g, members, &d_members) || lm_upload(g, units, &d_units)) return LM_ERR_HIP;
+        LM_HIP(hipMalloc((void**)&d_max, items.size() * sizeof(int32_t)));
+        g->d_owned.push_back(d_max);
+        LM_HIP(hipMemsetAsync(d_max, 0, items.size() * sizeof(int32_t), st));
+        const int nb = (int)std::min<size_t>(units.size(), LM_HIP_EMULATED ? 2 : 4096);
+        hipLaunchKernelGGL(lm_k_gimg_max, dim3(nb), dim3(256), 0, st, d_items, d_units, (int)units.size(), d_members, s->cc, s->crop, d_max);
+        hipLaunchKernelGGL(lm_k_gimg_write, dim3(nb), dim3(256), 0, st, d_items, d_units, (int)units.size(), d_members, s->cc, s->crop,
+                           d_max, g->img_thr, g->d_images);
+        LM_HIP(hipGetLastError());
+    }
+    // ---- render tables for frames_from_groups (:638-681)
+    if (reconstruct_tables) {
+        std::vector<long long> fio((size_t)F + 1, 0);
+        std::vector<LmRenderItem> ritems;
+        for (int f = 0; f < F; f++) {
+            for (int64_t i = g->gpf_off[f]; i < g->gpf_off[(size_t)f + 1]; i++) {
+                const int gi = g->gpf[(size_t)i];
+                const int32_t* a = g->ages.data() + g->ages_off[gi];
+                const int na = (int)(g->ages_off[(size_t)gi + 1] - g->ages_off[gi]);
+                if (na < 2) continue;       // no segment image (the reference would raise IndexError at :650 here)
+                int sidx = 0;
+                while (sidx + 1 < na - 1 && a[sidx + 1] < f) sidx++;   // while ages[ptr+1] < img_idx: ptr += 1 (:650-652)
+                const int64_t item = g->gimg_item_off[gi] + sidx;
+                LmRenderItem ri;
+                ri.x0 = g->bounds[(size_t)gi * 4 + 0]; ri.y0 = g->bounds[(size_t)gi * 4 + 2];
+                ri.w = g->bounds[(size_t)gi * 4 + 1] - ri.x0 + 1; ri.h = g->bounds[(size_t)gi * 4 + 3] - ri.y0 + 1;
+                ri.img_off = g->gimg_off[(size_t)item];
+                ritems.push_back(ri);
+            }
+            fio[(size_t)f + 1] = (long long)ritems.size();
+        }
+        if (lm_upload(g, fio, &g->d_frame_item_off) || lm_upload(g, ritems, &g->d_render_items)) return LM_ERR_HIP;
+    }
+    LM_HIP(hipStreamSynchronize(st));
+    return LM_OK;
+}
+
+extern "C" LmGroups* lm_group_run(LmStream* s, int max_gap, int min_times, int t_window, double min_recall, double img_threshold,
+                                  int reconstruct_tables, void* stream)
+{
+    if (!s) { lm_set_error("lm_group_run: null stream"); return nullptr; }
+    LmGroups* g = new LmGroups();
+    g->s = s;
+    g->max_gap = max_gap; g->min_times = min_times; g->t_window = t_window;
+    g->min_recall = min_recall; g->img_thr = img_threshold;
+    if (lm_group_run_impl(g, reconstruct_tables, (hipStream_t)stream) != LM_OK) {
+        lm_group_destroy(g);
+        return nullptr;
+    }
+    return g;
+}
+
+// Renders frames [first, first + n) of the reconstructed clean binary stream into d_out ([n][H][W] uint8, device).
+extern "C" int lm_group_render(LmGroups* g, int first, int n, uint8_t* d_out, void* stream)
+{
+    if (!g || !g->d_frame_item_off || first < 0 || n <= 0 || first + n > g->n_frames || !d_out) {
+        lm_set_error("lm_group_render: bad arguments (or lm_group_run was called with reconstruct_tables = 0)");
+        return LM_ERR_ARG;
+    }
+    const LmGeom gm = g->s->ctx->g;
+    hipLaunchKernelGGL(lm_k_render_frames, dim3((gm.W + LM_RT_COLS - 1) / LM_RT_COLS, (gm.H + LM_RT_ROWS - 1) / LM_RT_ROWS, n), dim3(256), 0,
+                       (hipStream_t)stream, g->d_frame_item_off, g->d_render_items, g->d_images, first, gm.W, gm.H, d_out);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+// Generic accessor: pointer to a host array owned by `g` (valid until lm_group_destroy) and its element count.
+// Element types: see the LM_G_* table in include/lecturemath_amd.h.
+extern "C" int lm_group_array(LmGroups* g, int which, const void** ptr, int64_t* count)
+{
+    if (!g || !ptr || !count) { lm_set_error("lm_group_array: bad arguments"); return LM_ERR_ARG; }
+#define LM_GA(id, vec) case id: *ptr = (vec).data(); *count = (int64_t)(vec).size(); return LM_OK;
+    static thread_local int64_t scalars[8];
+    switch (which) {
+        LM_GA(LM_G_UNIQ_CC, g->uniq_cc) LM_GA(LM_G_ULIST_OFF, g->ulist_off) LM_GA(LM_G_ULIST_CC, g->ulist_cc) LM_GA(LM_G_ASSIGN, g->assign)
+        LM_GA(LM_G_STABLE, g->stable) LM_GA(LM_G_PAIR_A, g->pair_a) LM_GA(LM_G_PAIR_B, g->pair_b) LM_GA(LM_G_PAIR_MATCH, g->pair_match)
+        LM_GA(LM_G_TOV_OFF, g->tov_off) LM_GA(LM_G_TOV_OTHER, g->tov_other) LM_GA(LM_G_TOV_RECALL, g->tov_recall)
+        LM_GA(LM_G_TOV_PRECISION, g->tov_precision) LM_GA(LM_G_AOV_OFF, g->aov_off) LM_GA(LM_G_AOV_OTHER, g->aov_other)
+        LM_GA(LM_G_AOV_MATCHED, g->aov_matched) LM_GA(LM_G_AOV_SIZE_OTHER, g->aov_size_other) LM_GA(LM_G_AOV_SIZE_SELF, g->aov_size_self)
+        LM_GA(LM_G_GRP_OFF, g->grp_off) LM_GA(LM_G_GRP_MEMBERS, g->grp_members) LM_GA(LM_G_GID, g->gid_of_unique)
+        LM_GA(LM_G_AGES_OFF, g->ages_off) LM_GA(LM_G_AGES, g->ages) LM_GA(LM_G_GPF_OFF, g->gpf_off) LM_GA(LM_G_GPF, g->gpf)
+        LM_GA(LM_G_CONF_G1, g->conf_g1) LM_GA(LM_G_CONF_G2, g->conf_g2) LM_GA(LM_G_CONF_MATCHED, g->conf_matched)
+        LM_GA(LM_G_CONF_UNMATCHED, g->conf_unmatched) LM_GA(LM_G_CONF_UNION, g->conf_union) LM_GA(LM_G_CONF_INTER, g->conf_inter)
+        LM_GA(LM_G_BOUNDS, g->bounds) LM_GA(LM_G_GIMG_OFF, g->gimg_off) LM_GA(LM_G_GIMG_ITEM_OFF, g->gimg_item_off)
+        case LM_G_GIMG: {
+            if (g->gimg_host.size() != (size_t)g->gimg_off.back()) {
+                g->gimg_host.resize((size_t)g->gimg_off.back());
+                if (!g->gimg_host.empty())
+                    LM_HIP(hipMemcpy(g->gimg_host.data(), g->d_images, g->gimg_host.size(), hipMemcpyDeviceToHost));
+            }
+            *ptr = g->gimg_host.data(); *count = (int64_t)g->gimg_host.size();
+            return LM_OK;
+        }
+        case LM_G_SCALARS:
+            scalars[0] = g->n_split; scalars[1] = g->total_intersections; scalars[2] = (int64_t)g->grp_off.size() - 1;
+            scalars[3] = (int64_t)g->uniq_cc.size(); scalars[4] = g->n_frames; scalars[5] = g->gimg_off.back();
+            *ptr = scalars; *count = 6;
+            return LM_OK;
+        default: break;
+    }
+#undef LM_GA
+    lm_set_error("lm_group_array: unknown array id %d", which);
+    return LM_ERR_ARG;
+}

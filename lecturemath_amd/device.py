@@ -198,3 +198,104 @@ class FrameStream:
         return {"width": self.width, "height": self.height, "unique_recs": urec, "unique_crops": crops,
                 "unique_cc_frames": frames, "cc_idx_per_frame": per_frame, "tempo_count": r["tempo_count"],
                 "active": r["active"], "raw": r}
+
+
+_G_DTYPES = {0: np.int32, 1: np.int64, 2: np.int32, 3: np.int32, 4: np.int32, 5: np.int32, 6: np.int32, 7: np.int32,
+             8: np.int64, 9: np.int32, 10: np.float64, 11: np.float64, 12: np.int64, 13: np.int32, 14: np.int32, 15: np.int32,
+             16: np.int32, 17: np.int64, 18: np.int32, 19: np.int32, 20: np.int64, 21: np.int32, 22: np.int64, 23: np.int32,
+             24: np.int32, 25: np.int32, 26: np.int64, 27: np.int64, 28: np.int64, 29: np.float64, 30: np.int32, 31: np.int64,
+             32: np.int64, 33: np.uint8, 34: np.int64}
+_G_NAMES = ["uniq_cc", "ulist_off", "ulist_cc", "assign", "stable", "pair_a", "pair_b", "pair_match", "tov_off", "tov_other",
+            "tov_recall", "tov_precision", "aov_off", "aov_other", "aov_matched", "aov_size_other", "aov_size_self", "grp_off",
+            "grp_members", "gid", "ages_off", "ages", "gpf_off", "gpf", "conf_g1", "conf_g2", "conf_matched", "conf_unmatched",
+            "conf_union", "conf_inter", "bounds", "gimg_off", "gimg_item_off", "gimg", "scalars"]
+
+
+class Grouping:
+    """Step 03 over a finished FrameStream (pre_ST3D_v3.0_03_cc_grouping.py:22-118)."""
+
+    def __init__(self, stream, max_gap=85, min_times=3, t_window=5, min_recall=0.5, img_threshold=0.5, reconstruct=True):
+        self.stream = stream
+        self.lib, self.be = stream.lib, stream.be
+        self.handle = self.lib.lm_group_run(stream.handle, max_gap, min_times, t_window, min_recall, img_threshold,
+                                            1 if reconstruct else 0, self.be.stream())
+        if not self.handle:
+            raise _lib.LecturemathError(_lib.LM_ERR_HIP, self.lib.last_error())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.lm_group_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def array(self, which):
+        """Copy of one result array (see the id table in include/lecturemath_amd.h)."""
+        if isinstance(which, str):
+            which = _G_NAMES.index(which)
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        self.lib.check(self.lib.lm_group_array(self.handle, which, ctypes.addressof(p), ctypes.addressof(n)))
+        dt = np.dtype(_G_DTYPES[which])
+        if n.value == 0:
+            return np.zeros(0, dt)
+        buf = (ctypes.c_char * (n.value * dt.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dt).copy()
+
+    def render(self, first, n, out=None):
+        """frames_from_groups channel 0 for frames [first, first+n) -> device uint8 [n,H,W]."""
+        out = out if out is not None else self.be.empty((n, self.stream.height, self.stream.width), np.uint8)
+        self.lib.check(self.lib.lm_group_render(self.handle, first, n, _lib.ptr(out), self.be.stream()))
+        return out
+
+    def result(self, with_images=True, with_clean=True):
+        """Plain-data view with the reference's names (same shape as oracle.grouping.run_step03)."""
+        A = {name: self.array(i) for i, name in enumerate(_G_NAMES) if name != "gimg" or with_images}
+        sc = A["scalars"]
+        nu, ng, nf = int(sc[3]), int(sc[2]), int(sc[4])
+
+        def csr(off, *cols):
+            return [[tuple(c[j].item() for c in cols) if len(cols) > 1 else cols[0][j].item()
+                     for j in range(off[i], off[i + 1])] for i in range(len(off) - 1)]
+
+        out = {
+            "n_split": int(sc[0]), "total_intersections": int(sc[1]),
+            "stable_idxs": [int(v) for v in A["stable"]],
+            "time_overlapping_cc": csr(A["tov_off"], A["tov_other"], A["tov_recall"], A["tov_precision"]),
+            "all_overlapping_cc": csr(A["aov_off"], A["aov_other"], A["aov_matched"], A["aov_size_other"], A["aov_size_self"]),
+            "cc_groups": csr(A["grp_off"], A["grp_members"]),
+            "group_idx_per_cc": {u: int(g) for u, g in enumerate(A["gid"]) if g >= 0},
+            "group_ages": {g: lst for g, lst in enumerate(csr(A["ages_off"], A["ages"]))},
+            "groups_per_frame": csr(A["gpf_off"], A["gpf"]),
+            "group_boundaries": {g: tuple(int(v) for v in A["bounds"][4 * g:4 * g + 4]) for g in range(ng)},
+            "arrays": A,
+        }
+        conf = {g: {} for g in range(ng)}
+        for i in range(len(A["conf_g1"])):
+            conf[int(A["conf_g1"][i])][int(A["conf_g2"][i])] = {
+                "matched": int(A["conf_matched"][i]), "unmatched": int(A["conf_unmatched"][i]),
+                "area_union": int(A["conf_union"][i]), "area_intersection": float(A["conf_inter"][i])}
+        out["conflicts"] = conf
+        if with_images:
+            imgs = {}
+            for g in range(ng):
+                x0, x1, y0, y1 = out["group_boundaries"][g]
+                w, h = x1 - x0 + 1, y1 - y0 + 1
+                lst = []
+                for it in range(A["gimg_item_off"][g], A["gimg_item_off"][g + 1]):
+                    o = A["gimg_off"][it]
+                    lst.append(A["gimg"][o:o + w * h].reshape(h, w))
+                imgs[g] = lst
+            out["group_images"] = imgs
+        if with_clean and nf:
+            out["clean_binary"] = list(self.be.to_host(self.render(0, nf)))
+        # unique_cc_frames / cc_idx_per_frame after the split
+        rec = self.stream.read(with_crops=False)["rec"]
+        out["unique_cc_frames"] = [[(int(rec[c, 6]), int(rec[c, 0]) + 1) for c in A["ulist_cc"][A["ulist_off"][u]:A["ulist_off"][u + 1]]]
+                                   for u in range(nu)]
+        foff = self.stream.read(with_crops=False)["frame_off"]
+        out["cc_idx_per_frame"] = [[(int(A["assign"][c]), int(rec[c, 0])) for c in range(foff[f], foff[f + 1])] for f in range(nf)]
+        return out

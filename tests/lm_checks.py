@@ -112,3 +112,48 @@ def check_label_vs_oracle(lib, img):
             assert (st[0] == np.stack(occ.age_boundaries(l, None, n)[:5])).all()
     finally:
         lab.close()
+
+
+def grouping_equal_golden(r, g):
+    """Every step-03 intermediate of the reference (G4 fixture) vs the product's Grouping.result()."""
+    assert r["n_split"] == int(g["n_split"])
+    assert r["unique_cc_frames"] == unrag(g["post_split_ucf"], g["post_split_ucf_off"])
+    assert r["cc_idx_per_frame"] == unrag(g["post_split_cipf"], g["post_split_cipf_off"])
+    assert r["stable_idxs"] == list(g["stable"])
+    assert r["total_intersections"] == int(g["total_intersections"])
+    tflat = [(a, b, np.float64(rc).view(np.int64), np.float64(p).view(np.int64))
+             for a, lst in enumerate(r["time_overlapping_cc"]) for b, rc, p in lst]
+    assert (np.asarray(tflat, np.int64).reshape(-1, 4) == g["time_ov"]).all()
+    aflat = [(a, *t) for a, lst in enumerate(r["all_overlapping_cc"]) for t in lst]
+    assert (np.asarray(aflat, np.int64).reshape(-1, 5) == g["all_ov"]).all()
+    assert [[(m,) for m in grp] for grp in r["cc_groups"]] == unrag(g["groups"], g["groups_off"])
+    assert sorted(r["group_idx_per_cc"].items()) == [tuple(x) for x in g["gid"]]
+    ng = len(r["cc_groups"])
+    assert [[(a,) for a in r["group_ages"][k]] for k in range(ng)] == unrag(g["ages"], g["ages_off"])
+    assert [[(a,) for a in fr] for fr in r["groups_per_frame"]] == unrag(g["gpf"], g["gpf_off"])
+    got = sorted((k, o, d["matched"], d["unmatched"], d["area_union"], d["area_intersection"])
+                 for k in r["conflicts"] for o, d in r["conflicts"][k].items())
+    exp = sorted(tuple(row) for row in g["conflicts"])
+    assert len(got) == len(exp) and all(tuple(float(v) for v in a) == tuple(float(v) for v in b) for a, b in zip(got, exp))
+    assert (np.asarray([r["group_boundaries"][k] for k in range(ng)], np.int64).reshape(-1, 4) == g["bounds"]).all()
+    assert [len(r["group_images"][k]) for k in range(ng)] == list(g["gimg_count"])
+    gi = np.concatenate([im.ravel() for k in range(ng) for im in r["group_images"][k]]) if ng else np.zeros(0, np.uint8)
+    assert (gi == g["gimg"]).all()
+    clean = np.stack(r["clean_binary"])
+    assert (np.packbits(clean == 255, axis=2) == g["clean_packed"]).all()
+    other = np.argwhere((clean != 0) & (clean != 255)).astype(np.int32)
+    assert (other == g["clean_other"]).all() and (clean[(clean != 0) & (clean != 255)] == g["clean_other_val"]).all()
+
+
+def check_grouping_golden(lib, name, max_batch=16):
+    g, spec, frames = load_stream(name)
+    fs = device.FrameStream(spec["w"], spec["h"], len(frames), 0.85, 0.85, spec["gap2"], 20, max_batch=max_batch, lib=lib)
+    try:
+        fs.push(fs.be.from_host(frames))
+        gr = device.Grouping(fs, max_gap=spec["gap3"], min_times=3, t_window=5, min_recall=0.5, img_threshold=0.5)
+        try:
+            grouping_equal_golden(gr.result(), g)
+        finally:
+            gr.close()
+    finally:
+        fs.close()

@@ -98,3 +98,9 @@ def test_dense_wide_noise_band_fallback(hip_lib, oracle_built):
     rng = np.random.default_rng(21)
     img = ((rng.random((70, 1100)) < 0.5) * 255).astype(np.uint8)
     lm_checks.check_label_vs_oracle(hip_lib, img)
+
+
+@pytest.mark.parametrize("name", lm_checks.STREAMS)
+def test_grouping_golden(hip_lib, name):
+    """Step 03 (split, stable set, overlaps, groups, ages, conflicts, group images, reconstructed frames) vs the reference."""
+    lm_checks.check_grouping_golden(hip_lib, name)

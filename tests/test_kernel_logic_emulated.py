@@ -74,3 +74,7 @@ def test_dense_wide_noise_band_fallback(emu_lib, oracle_built):
     rng = np.random.default_rng(21)
     img = ((rng.random((70, 1100)) < 0.5) * 255).astype(np.uint8)
     lm_checks.check_label_vs_oracle(emu_lib, img)
+
+
+def test_grouping_golden_short_gap(emu_lib):
+    lm_checks.check_grouping_golden(emu_lib, "short_gap_jitter")
