@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec of the hot path (binarize-threshold + CC labelling + CC records + temporal matching
-[+ grouping when built]) on a synthetic 1080p stream, per BASELINE.json (configs[2], the configuration the
++ space-time grouping with frame reconstruction) on a synthetic 1080p stream, per BASELINE.json (configs[2], the configuration the
 metric is quoted on: the synthetic 1080p stream on one MI355X; `--frames 10000` is its full length).
 
 A "step" is one pass of the hot path over one synthetic stream of --frames frames whose fp32 logits are
@@ -75,6 +75,7 @@ def main():
     fs = device.FrameStream(W, H, F, 0.85, 0.85, 85, 20, max_batch=a.batch, lib=lib)
     binary = torch.empty((F, H, W), dtype=torch.uint8, device="cuda")
     labels = None if a.no_labels else torch.empty((a.batch, H, W), dtype=torch.int32, device="cuda")
+    clean = torch.empty((a.batch, H, W), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -85,6 +86,14 @@ def main():
             # the label image of a batch is an output of the labelling kernel; the same buffer is reused per batch
             lib.check(lib.lm_stream_push(fs.handle, binary[f0:f0 + n].data_ptr(), n,
                                          labels.data_ptr() if labels is not None else None, stream))
+        # step 03: grouping + reconstruction of every frame (frames_from_groups), rendered batch by batch
+        gr = device.Grouping(fs, max_gap=85, min_times=3, t_window=5, min_recall=0.5, img_threshold=0.5, reconstruct=True)
+        for f0 in range(0, F, a.batch):
+            n = min(a.batch, F - f0)
+            gr.render(f0, n, clean[:n])
+        info = gr.array("scalars")
+        gr.close()
+        return info
 
     for _ in range(a.warmup):
         step()
@@ -97,7 +106,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        step()
+        ginfo = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -150,10 +159,11 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "configs[2]: synthetic %dx%d binary-board stream, %d frames/stream/GPU: fp32 logits -> "
-                               "threshold+invert -> CC label (int32 image) -> CC stats/records/crops -> temporal matching"
+                               "threshold+invert -> CC label (int32 image) -> CC stats/records/crops -> temporal matching -> grouping (step 03) + "
+                               "reconstructed frames"
                                % (W, H, F),
-                   "frames_per_step": F, "batch": a.batch, "stages_not_yet_in_timed_region": ["cc_grouping(step03)", "fcn"],
-                   "stream": {k: k1[k] for k in ("n_cc", "n_unique", "tempo_count")}, "parallelism": "independent streams per GPU"},
+                   "frames_per_step": F, "batch": a.batch, "stages_not_in_timed_region": ["fcn conv stack (logits are synthetic, SURVEY 8(d) config 3)"],
+                   "stream": dict({k: k1[k] for k in ("n_cc", "n_unique", "tempo_count")}, n_groups=int(ginfo[2]), n_split=int(ginfo[0])), "parallelism": "independent streams per GPU"},
         "roofline": roofline, "cpu_baseline": cpu, "gen_seconds": round(gen_s, 2),
     }
     print(json.dumps(out))

@@ -145,6 +145,26 @@ int lm_group_render(LmGroups* g, int first, int n, uint8_t* d_out, void* stream)
  * 34 SCALARS i64[6]: n_split, total_intersections, n_groups, n_uniq, n_frames, group image bytes */
 int lm_group_array(LmGroups* g, int which, const void** ptr, int64_t* count);
 
+/* ====================================================================================================
+ * 5. FCN-LectureNet inference (lecturenet_v1/FCN_lecturenet.py: encode_decode :260-323, forward :364-403).
+ * ==================================================================================================== */
+typedef struct LmFcn LmFcn;
+
+/* widths18 = d1..d5, mid, u5,c5, u4,c4, u3,c3, u2,c2, u1,c1, pixel_features_1, pixel_features_2 (CreateFromConfig
+ * :621-646; every width a multiple of 8).  Activation buffers are allocated for frames up to max_h x max_w. */
+LmFcn* lm_fcn_create(const int32_t* widths18, int pixel_kernel, int kernel, int max_h, int max_w);
+void lm_fcn_destroy(LmFcn* f);
+
+/* One layer's weights, BatchNorm already folded in and packed by the host (lecturemath_amd/fcn.py documents the
+ * layout; layer ids: 0-4 conv_down_block_1..5, 5 mid_block, 6-10 transposed_conv_5..1, 11-15 conv_up_block_5..1,
+ * 16 conv_text_mask_out, 17 conv_reconstruct, 18 conv_pixels_1, 19 conv_pixels_2, 20 conv_out).  HOST pointers. */
+int lm_fcn_set_layer(LmFcn* f, int layer, const float* h_w, int64_t w_count, const float* h_bias, int bias_count, int cin,
+                     int cout, int k, int ck);
+
+/* forward() for one RGB frame (device, uint8 [h][w][3]).  Device fp32 outputs (each may be NULL): d_out [h*w]
+ * binarization logit (no sigmoid), d_text [h*w] text-mask logit, d_rec [3][h*w] tanh reconstruction. */
+int lm_fcn_forward(LmFcn* f, const uint8_t* d_rgb, int h, int w, float* d_out, float* d_text, float* d_rec, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,7 @@
 #include "lm_cc_kernels.hip"
 #include "lm_match_kernels.hip"
 #include "lm_group.hip"
+#include "lm_fcn.hip"
 
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";

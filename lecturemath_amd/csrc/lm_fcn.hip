@@ -1,0 +1,529 @@
+// lm_fcn.hip -- FCN-LectureNet inference on gfx950: hand-written MFMA convolution stack.
+//
+// Replaces the torch modules behind FCN_LectureNet.binarize (AccessMath/lecturenet_v1/FCN_lecturenet.py,
+// relative to /root/reference/ACCESS2021_release):
+//   prepare_image :607-618            lm_k_prepare (uint8 HWC RGB -> fp32 NHWC in [-1,1], channels padded to 8)
+//   encode_decode :260-323            lm_k_conv_mfma (3x3 conv + folded BN + GELU; 2x2/s2 transposed conv as four
+//                                     scattered 1x1 convs; skip concats read as a second input, never materialised),
+//                                     lm_k_maxpool2, lm_k_convT_border (output_size rows/cols that only see the bias)
+//   forward heads :364-403            lm_k_conv_small (Cout <= 4: 7x7 text mask, 3x3 reconstruction + tanh, 7x7 output),
+//                                     lm_k_diff ((x0 - rec) * sigmoid(text)), lm_k_conv_mfma (7x7 pixel convs)
+// Arithmetic: fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains), BatchNorm folded into
+// weights/bias on the host in fp32 (eval mode, eps 1e-5), GELU = exact erf form (nn.GELU default).
+//
+// Layout: activations NHWC fp32 with a per-buffer pixel stride (so a conv can write into a channel slice of a
+// wider buffer: the (diff, features) concatenations of the pixel branch are produced in place).
+// Implicit GEMM: M = output pixels (block tile 16 x 16 px, wave = 4 rows x 16 cols = two 32-px MFMA blocks),
+// N = output channels (NT blocks of 32 per wave), K = taps x input channels walked in chunks of CK channels.
+// Per chunk a block stages in LDS the (16+KH-1) x (16+KW-1) x CK input patch (pixel stride CK+4 floats: the
+// 16 B A-fragment reads of 16 neighbouring pixels then fall on distinct banks) and the chunk's weights for ALL
+// taps, pre-packed on the host in fragment order [tap][kstep][nblock][lane][4].
+#include "lm_common.h"
+
+#include <vector>
+
+#if LM_HIP_EMULATED
+extern char lm_emu_dynsmem[];
+#define LM_DYN_SMEM(name) char* name = lm_emu_dynsmem
+#else
+#define LM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#endif
+
+#define LM_ACT_NONE 0
+#define LM_ACT_GELU 1
+#define LM_ACT_TANH 2
+
+LM_DEV float lm_act(float v, int act)
+{
+    if (act == LM_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == LM_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+struct LmConvArgs {
+    const float* in0; int c0, ps0;      // first input: channels used, pixel stride (floats)
+    const float* in1; int c1, ps1;      // optional second input (channel concat), c1 = 0 when absent
+    int H, W;                           // input grid
+    const float* wpk;                   // packed weights [chunk][tap][kstep][nblock][64][4]
+    const float* bias;                  // [nblocks * 32] folded bias
+    float* out; int ops, ooff;          // output pixel stride (floats) and channel offset
+    int Cout, nblocks;                  // real output channels, ceil(Cout / 32)
+    int K;                              // kernel side (1, 3, 7), padding (K-1)/2
+    int act;
+    int tmode, dy, dx, OH, OW;          // transposed mode: input (y, x) -> output (2y+dy, 2x+dx) of an OH x OW grid
+};
+
+template <int CK, int NT>
+__global__ void __launch_bounds__(256) lm_k_conv_mfma(const LmConvArgs a)
+{
+    LM_DYN_SMEM(smem);
+    constexpr int PSTR = CK + 4;            // padded pixel stride in LDS (floats)
+    constexpr int KS = CK / 8;              // k-steps of 8 channels per chunk
+    const int K = a.K, pad = (K - 1) >> 1, taps = K * K;
+    const int PW = 16 + K - 1, PH = 16 + K - 1;
+    float* s_patch = (float*)smem;
+    float* s_w = s_patch + PH * PW * PSTR;               // [tap][ks][NT][64][4]
+    const int tiles_x = (a.W + 15) >> 4;
+    const int ty0 = (blockIdx.x / tiles_x) << 4, tx0 = (blockIdx.x % tiles_x) << 4;
+    const int nb0 = blockIdx.y * NT;
+    const int lane = lm_lane(), wave = (int)(threadIdx.x >> 6), half = lane >> 5;
+    const int nchunks = (a.c0 + a.c1) / CK;
+
+    lm_f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][n][r] = 0.0f;
+
+    // this lane's pixel inside the two 32-px MFMA blocks of the wave: rows wave*4 + m*2 + (i>>4), col i & 15
+    const int pi = lane & 31;
+    const int prow = wave * 4 + (pi >> 4), pcol = pi & 15;
+
+    for (int ch = 0; ch < nchunks; ch++) {
+        const bool first = ch * CK < a.c0;
+        const float* src = first ? a.in0 : a.in1;
+        const int ps = first ? a.ps0 : a.ps1;
+        const int coff = first ? ch * CK : ch * CK - a.c0;
+        __syncthreads();
+        // ---- stage the input patch (zero outside the image)
+        for (int i = threadIdx.x; i < PH * PW * (CK / 4); i += blockDim.x) {
+            const int px = i / (CK / 4), q = i - px * (CK / 4);
+            const int py = px / PW, pxx = px - py * PW;
+            const int y = ty0 + py - pad, x = tx0 + pxx - pad;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y >= 0 && y < a.H && x >= 0 && x < a.W) v = *(const float4*)(src + ((long long)y * a.W + x) * ps + coff + q * 4);
+            *(float4*)(s_patch + px * PSTR + q * 4) = v;
+        }
+        // ---- stage the chunk's weights for every tap (the block's NT n-blocks)
+        {
+            const float* wsrc = a.wpk + (long long)ch * taps * KS * a.nblocks * 256;
+            const int n4 = taps * KS * NT * 64;          // float4 count
+            for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+                const int tk = i / (NT * 64), rem = i - tk * (NT * 64);      // tk = tap * KS + ks
+                const int nb = rem >> 6, l = rem & 63;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (nb0 + nb < a.nblocks) v = *(const float4*)(wsrc + ((long long)(tk * a.nblocks + nb0 + nb) * 64 + l) * 4);
+                *(float4*)(s_w + (long long)i * 4) = v;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA over taps x k-steps
+        for (int t = 0; t < taps; t++) {
+            const int kh = t / K, kw = t - kh * K;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                float4 af[2], bf[NT];
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+                    af[m] = *(const float4*)(s_patch + ((prow + m * 2 + kh) * PW + pcol + kw) * PSTR + ks * 8 + half * 4);
+#pragma unroll
+                for (int n = 0; n < NT; n++) bf[n] = *(const float4*)(s_w + ((long long)((t * KS + ks) * NT + n) * 64 + lane) * 4);
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int n = 0; n < NT; n++) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, bf[n].x, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, bf[n].y, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bf[n].z, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[n].w, acc[m][n], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*half][col = lane & 31]; row = pixel in the 32-px block, col = channel
+    const int cj = lane & 31;
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+        const int co = (nb0 + n) * 32 + cj;
+        if (nb0 + n >= a.nblocks || co >= a.Cout) continue;
+        const float b = a.bias[co];
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int y = ty0 + wave * 4 + m * 2 + (i >> 4), x = tx0 + (i & 15);
+                if (y >= a.H || x >= a.W) continue;
+                const float v = lm_act(acc[m][n][r] + b, a.act);
+                long long opix = a.tmode ? ((long long)(2 * y + a.dy) * a.OW + (2 * x + a.dx)) : ((long long)y * a.W + x);
+                a.out[opix * a.ops + a.ooff + co] = v;
+            }
+    }
+}
+
+// rows / columns of a transposed-conv output that no input pixel reaches (output_size = 2*in + 1): act(bias)
+__global__ void __launch_bounds__(256) lm_k_convT_border(float* out, int ops, int ooff, int OH, int OW, int H2, int W2, int Cout,
+                                                         const float* __restrict__ bias, int act)
+{
+    // pixels with y >= H2 or x >= W2
+    const long long nb_px = (long long)(OH - H2) * OW + (long long)H2 * (OW - W2);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nb_px * Cout; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i / Cout;
+        const int c = (int)(i - p * Cout);
+        int y, x;
+        if (p < (long long)(OH - H2) * OW) { y = H2 + (int)(p / OW); x = (int)(p % OW); }
+        else { const long long q = p - (long long)(OH - H2) * OW; y = (int)(q / (OW - W2)); x = W2 + (int)(q % (OW - W2)); }
+        out[((long long)y * OW + x) * ops + ooff + c] = lm_act(bias[c], act);
+    }
+}
+
+__global__ void __launch_bounds__(256) lm_k_maxpool2(const float* __restrict__ in, int ips, float* __restrict__ out, int ops,
+                                                     int H, int W, int C)
+{
+    const int OH = H >> 1, OW = W >> 1, C4 = C >> 2;
+    const long long total = (long long)OH * OW * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i / C4;
+        const int q = (int)(i - p * C4);
+        const int oy = (int)(p / OW), ox = (int)(p - (long long)oy * OW);
+        const float* s = in + ((long long)(2 * oy) * W + 2 * ox) * ips + q * 4;
+        const float4 a = *(const float4*)s, b = *(const float4*)(s + ips), c = *(const float4*)(s + (long long)W * ips),
+                     d = *(const float4*)(s + (long long)W * ips + ips);
+        float4 r;
+        r.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x));
+        r.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
+        r.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z));
+        r.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
+        *(float4*)(out + p * ops + q * 4) = r;
+    }
+}
+
+// uint8 HWC RGB -> fp32 NHWC (x/255 - 0.5)/0.5, channels 3..7 zero (to_tensor + normalize, :607-618)
+__global__ void __launch_bounds__(256) lm_k_prepare(const uint8_t* __restrict__ rgb, float* __restrict__ out, long long npx)
+{
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += (long long)gridDim.x * blockDim.x) {
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) v[c] = ((float)rgb[p * 3 + c] / 255.0f - 0.5f) / 0.5f;
+        *(float4*)(out + p * 8) = make_float4(v[0], v[1], v[2], 0.f);
+        *(float4*)(out + p * 8 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// Direct convolution for Cout <= 4 (heads): one thread per output pixel, 16x16 px tile, input patch (all channels,
+// padded to a multiple of 4) and weights [tap][C][4] in LDS.
+__global__ void __launch_bounds__(256) lm_k_conv_small(const float* __restrict__ in, int ips, int C, int H, int W,
+                                                       const float* __restrict__ w4, const float* __restrict__ bias, int K, int Cout,
+                                                       int act, float* __restrict__ out, int ops)
+{
+    LM_DYN_SMEM(smem);
+    const int pad = (K - 1) >> 1, taps = K * K, PW = 16 + K - 1, PH = 16 + K - 1;
+    const int CS = C + 4;                                   // padded pixel stride (floats)
+    float* s_patch = (float*)smem;
+    float* s_w = s_patch + PH * PW * CS;                    // [tap][C][4]
+    const int tiles_x = (W + 15) >> 4;
+    const int ty0 = (blockIdx.x / tiles_x) << 4, tx0 = (blockIdx.x % tiles_x) << 4;
+    for (int i = threadIdx.x; i < PH * PW * (C / 4); i += blockDim.x) {
+        const int px = i / (C / 4), q = i - px * (C / 4);
+        const int py = px / PW, pxx = px - py * PW;
+        const int y = ty0 + py - pad, x = tx0 + pxx - pad;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y >= 0 && y < H && x >= 0 && x < W) v = *(const float4*)(in + ((long long)y * W + x) * ips + q * 4);
+        *(float4*)(s_patch + px * CS + q * 4) = v;
+    }
+    for (int i = threadIdx.x; i < taps * C; i += blockDim.x) *(float4*)(s_w + i * 4) = *(const float4*)(w4 + (long long)i * 4);
+    __syncthreads();
+    const int ly = (int)(threadIdx.x >> 4), lx = (int)(threadIdx.x & 15);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < taps; t++) {
+        const int kh = t / K, kw = t - kh * K;
+        const float* pp = s_patch + ((ly + kh) * PW + lx + kw) * CS;
+        const float* ww = s_w + (long long)t * C * 4;
+        for (int c = 0; c < C; c += 4) {
+            const float4 v = *(const float4*)(pp + c);
+            const float4 w0 = *(const float4*)(ww + (c + 0) * 4), w1 = *(const float4*)(ww + (c + 1) * 4),
+                         w2 = *(const float4*)(ww + (c + 2) * 4), w3 = *(const float4*)(ww + (c + 3) * 4);
+            acc[0] = fmaf(v.x, w0.x, acc[0]); acc[1] = fmaf(v.x, w0.y, acc[1]); acc[2] = fmaf(v.x, w0.z, acc[2]); acc[3] = fmaf(v.x, w0.w, acc[3]);
+            acc[0] = fmaf(v.y, w1.x, acc[0]); acc[1] = fmaf(v.y, w1.y, acc[1]); acc[2] = fmaf(v.y, w1.z, acc[2]); acc[3] = fmaf(v.y, w1.w, acc[3]);
+            acc[0] = fmaf(v.z, w2.x, acc[0]); acc[1] = fmaf(v.z, w2.y, acc[1]); acc[2] = fmaf(v.z, w2.z, acc[2]); acc[3] = fmaf(v.z, w2.w, acc[3]);
+            acc[0] = fmaf(v.w, w3.x, acc[0]); acc[1] = fmaf(v.w, w3.y, acc[1]); acc[2] = fmaf(v.w, w3.z, acc[2]); acc[3] = fmaf(v.w, w3.w, acc[3]);
+        }
+    }
+    const int y = ty0 + ly, x = tx0 + lx;
+    if (y < H && x < W)
+        for (int c = 0; c < Cout; c++) out[((long long)y * W + x) * ops + c] = lm_act(acc[c] + bias[c], act);
+}
+
+// diff = (x0 - rec) * sigmoid(text)  (:379), written to channels 0..2 of three NHWC buffers
+__global__ void __launch_bounds__(256) lm_k_diff(const float* __restrict__ x0, const float* __restrict__ rec4,
+                                                 const float* __restrict__ text, long long npx, float* __restrict__ o0, int s0,
+                                                 float* __restrict__ o1, int s1, float* __restrict__ o2, int s2)
+{
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += (long long)gridDim.x * blockDim.x) {
+        const float m = 1.0f / (1.0f + expf(-text[p]));
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float d = (x0[p * 8 + c] - rec4[p * 4 + c]) * m;
+            o0[p * s0 + c] = d;
+            o1[p * s1 + c] = d;
+            o2[p * s2 + c] = d;
+        }
+    }
+}
+
+// NHWC (stride 4, 3 used) -> CHW planes
+__global__ void __launch_bounds__(256) lm_k_nhwc4_to_chw3(const float* __restrict__ in, float* __restrict__ out, long long npx)
+{
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += (long long)gridDim.x * blockDim.x) {
+        const float4 v = *(const float4*)(in + p * 4);
+        out[p] = v.x; out[npx + p] = v.y; out[2 * npx + p] = v.z;
+    }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+#define LM_FCN_LAYERS 26
+// layer ids: 0..4 conv_down_block_1..5, 5 mid_block, 6..10 transposed_conv_5..1 (+ upsample BN), 11..15 conv_up_block_5..1,
+// 16 conv_text_mask_out, 17 conv_reconstruct, 18 conv_pixels_1, 19 conv_pixels_2, 20 conv_out
+struct LmFcnLayer {
+    float* w = nullptr;       // packed weights (MFMA layout, or [tap][C][4] for the small-Cout kernel; convT: 4 sets back to back)
+    float* bias = nullptr;
+    long long w_count = 0;
+    int cin = 0, cout = 0, k = 0, ck = 0;
+};
+
+struct LmFcn {
+    int widths[18];
+    int pk, kk;
+    int max_h, max_w;
+    LmFcnLayer layer[LM_FCN_LAYERS];
+    std::vector<float*> bufs;
+    // activations (allocated for max_h x max_w)
+    float *x0 = nullptr, *pre[5] = {}, *pool[5] = {}, *mid = nullptr, *up[5] = {}, *cu[5] = {};
+    float *text = nullptr, *rec4 = nullptr, *px0 = nullptr, *px1 = nullptr, *px2 = nullptr, *outl = nullptr;
+};
+
+static int lm_fcn_alloc(LmFcn* f, float** p, size_t count)
+{
+    LM_HIP(hipMalloc((void**)p, count * sizeof(float) + 256));
+    LM_HIP(hipMemset(*p, 0, count * sizeof(float) + 256));     // padding channels must stay zero
+    f->bufs.push_back(*p);
+    return LM_OK;
+}
+
+extern "C" void lm_fcn_destroy(LmFcn* f)
+{
+    if (!f) return;
+    for (float* p : f->bufs) (void)hipFree(p);
+    for (auto& l : f->layer) { if (l.w) (void)hipFree(l.w); if (l.bias) (void)hipFree(l.bias); }
+    delete f;
+}
+
+static inline int lm_pad8(int c) { return (c + 7) & ~7; }
+
+extern "C" LmFcn* lm_fcn_create(const int32_t* widths18, int pixel_kernel, int kernel, int max_h, int max_w)
+{
+    if (!widths18 || max_h < 32 || max_w < 32 || (pixel_kernel != 1 && pixel_kernel != 3 && pixel_kernel != 5 && pixel_kernel != 7) ||
+        (kernel != 3 && kernel != 1 && kernel != 5 && kernel != 7)) {
+        lm_set_error("lm_fcn_create: bad arguments (frames must be at least 32 px per side, kernel sizes in {1,3,5,7})");
+        return nullptr;
+    }
+    for (int i = 0; i < 18; i++)
+        if (widths18[i] <= 0 || (widths18[i] & 7)) { lm_set_error("lm_fcn_create: layer widths must be positive multiples of 8"); return nullptr; }
+    LmFcn* f = new LmFcn();
+    memcpy(f->widths, widths18, sizeof(f->widths));
+    f->pk = pixel_kernel; f->kk = kernel; f->max_h = max_h; f->max_w = max_w;
+    const int* w = f->widths;   // d1..d5 0..4, mid 5, (u5,c5) 6,7 (u4,c4) 8,9 (u3,c3) 10,11 (u2,c2) 12,13 (u1,c1) 14,15, pm1 16, pm2 17
+    size_t px[6];
+    int h = max_h, ww = max_w;
+    for (int l = 0; l < 6; l++) { px[l] = (size_t)h * ww; h >>= 1; ww >>= 1; }
+    int rc = LM_OK;
+    rc |= lm_fcn_alloc(f, &f->x0, px[0] * 8);
+    for (int n = 0; n < 5; n++) {
+        rc |= lm_fcn_alloc(f, &f->pre[n], px[n] * w[n]);
+        rc |= lm_fcn_alloc(f, &f->pool[n], px[n + 1] * w[n]);
+    }
+    rc |= lm_fcn_alloc(f, &f->mid, px[5] * w[5]);
+    for (int n = 0; n < 5; n++) {       // n = 0 is level 5 (deepest)
+        rc |= lm_fcn_alloc(f, &f->up[n], px[4 - n] * w[6 + 2 * n]);
+        if (n < 4) rc |= lm_fcn_alloc(f, &f->cu[n], px[4 - n] * w[7 + 2 * n]);
+    }
+    const int c1 = w[15], pm1 = w[16], pm2 = w[17];
+    rc |= lm_fcn_alloc(f, &f->px0, px[0] * lm_pad8(3 + c1));       // (diff, x_up1): conv_up_block_1 writes channels 3..
+    rc |= lm_fcn_alloc(f, &f->px1, px[0] * lm_pad8(3 + pm1));
+    rc |= lm_fcn_alloc(f, &f->px2, px[0] * lm_pad8(3 + pm2));
+    rc |= lm_fcn_alloc(f, &f->text, px[0]);
+    rc |= lm_fcn_alloc(f, &f->rec4, px[0] * 4);
+    rc |= lm_fcn_alloc(f, &f->outl, px[0]);
+    if (rc != LM_OK) { lm_fcn_destroy(f); return nullptr; }
+    return f;
+}
+
+// Uploads one layer's host-packed weights and folded bias (packing: lecturemath_amd/fcn.py).
+extern "C" int lm_fcn_set_layer(LmFcn* f, int layer, const float* h_w, int64_t w_count, const float* h_bias, int bias_count, int cin,
+                                int cout, int k, int ck)
+{
+    if (!f || layer < 0 || layer >= LM_FCN_LAYERS || !h_w || !h_bias || w_count <= 0 || bias_count <= 0) {
+        lm_set_error("lm_fcn_set_layer: bad arguments");
+        return LM_ERR_ARG;
+    }
+    LmFcnLayer& l = f->layer[layer];
+    if (l.w) (void)hipFree(l.w);
+    if (l.bias) (void)hipFree(l.bias);
+    l.w = nullptr; l.bias = nullptr;
+    LM_HIP(hipMalloc((void**)&l.w, (size_t)w_count * sizeof(float)));
+    LM_HIP(hipMalloc((void**)&l.bias, (size_t)bias_count * sizeof(float)));
+    LM_HIP(hipMemcpy(l.w, h_w, (size_t)w_count * sizeof(float), hipMemcpyHostToDevice));
+    LM_HIP(hipMemcpy(l.bias, h_bias, (size_t)bias_count * sizeof(float), hipMemcpyHostToDevice));
+    l.w_count = w_count; l.cin = cin; l.cout = cout; l.k = k; l.ck = ck;
+    return LM_OK;
+}
+
+static size_t lm_conv_smem(int K, int CK, int NT)
+{
+    const int P = 16 + K - 1;
+    return (size_t)P * P * (CK + 4) * 4 + (size_t)K * K * (CK / 8) * NT * 1024;
+}
+
+template <int CK, int NT> static int lm_launch_conv_t(const LmConvArgs& a, hipStream_t st)
+{
+    const size_t smem = lm_conv_smem(a.K, CK, NT);
+#if !LM_HIP_EMULATED
+    static size_t configured = 0;
+    if (smem > configured) {
+        LM_HIP(hipFuncSetAttribute((const void*)lm_k_conv_mfma<CK, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        configured = smem;
+    }
+#endif
+    const int tiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
+    hipLaunchKernelGGL((lm_k_conv_mfma<CK, NT>), dim3(tiles, (a.nblocks + NT - 1) / NT), dim3(256), smem, st, a);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+static int lm_launch_conv(const LmConvArgs& a, int ck, hipStream_t st)
+{
+    // n-blocks per wave: as many as fit 160 KiB of LDS and divide the channel blocks evenly
+    int nt = 1;
+    for (int cand : {4, 2}) {
+        if (a.nblocks % cand == 0 && lm_conv_smem(a.K, ck, cand) <= 150 * 1024) { nt = cand; break; }
+    }
+    if (ck == 16) {
+        if (nt == 4) return lm_launch_conv_t<16, 4>(a, st);
+        if (nt == 2) return lm_launch_conv_t<16, 2>(a, st);
+        return lm_launch_conv_t<16, 1>(a, st);
+    }
+    if (nt == 4) return lm_launch_conv_t<8, 4>(a, st);
+    if (nt == 2) return lm_launch_conv_t<8, 2>(a, st);
+    return lm_launch_conv_t<8, 1>(a, st);
+}
+
+static int lm_conv_layer(LmFcn* f, int layer, const float* in0, int c0, int ps0, const float* in1, int c1, int ps1, int H, int W,
+                         float* out, int ops, int ooff, int act, hipStream_t st)
+{
+    const LmFcnLayer& l = f->layer[layer];
+    if (!l.w) { lm_set_error("lm_fcn_forward: layer %d has no weights (call lm_fcn_set_layer)", layer); return LM_ERR_STATE; }
+    LmConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in0 = in0; a.c0 = c0; a.ps0 = ps0; a.in1 = in1; a.c1 = c1; a.ps1 = ps1; a.H = H; a.W = W;
+    a.wpk = l.w; a.bias = l.bias; a.out = out; a.ops = ops; a.ooff = ooff; a.Cout = l.cout; a.nblocks = (l.cout + 31) / 32;
+    a.K = l.k; a.act = act;
+    return lm_launch_conv(a, l.ck, st);
+}
+
+static int lm_convT_layer(LmFcn* f, int layer, const float* in, int cin, int H, int W, float* out, int OH, int OW, hipStream_t st)
+{
+    const LmFcnLayer& l = f->layer[layer];
+    if (!l.w) { lm_set_error("lm_fcn_forward: layer %d has no weights", layer); return LM_ERR_STATE; }
+    const int nblocks = (l.cout + 31) / 32;
+    const long long per_set = (long long)(cin / l.ck) * (l.ck / 8) * nblocks * 256;
+    for (int d = 0; d < 4; d++) {
+        LmConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in0 = in; a.c0 = cin; a.ps0 = cin; a.H = H; a.W = W;
+        a.wpk = l.w + d * per_set; a.bias = l.bias; a.out = out; a.ops = l.cout; a.ooff = 0; a.Cout = l.cout; a.nblocks = nblocks;
+        a.K = 1; a.act = LM_ACT_GELU; a.tmode = 1; a.dy = d >> 1; a.dx = d & 1; a.OH = OH; a.OW = OW;
+        int rc = lm_launch_conv(a, l.ck, st);
+        if (rc) return rc;
+    }
+    if (OH > 2 * H || OW > 2 * W) {
+        const long long n = ((long long)(OH - 2 * H) * OW + (long long)2 * H * (OW - 2 * W)) * l.cout;
+        hipLaunchKernelGGL(lm_k_convT_border, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, st, out, l.cout, 0,
+                           OH, OW, 2 * H, 2 * W, l.cout, l.bias, LM_ACT_GELU);
+    }
+    return LM_OK;
+}
+
+static int lm_small_layer(LmFcn* f, int layer, const float* in, int ips, int C, int H, int W, float* out, int ops, int act, hipStream_t st)
+{
+    const LmFcnLayer& l = f->layer[layer];
+    if (!l.w) { lm_set_error("lm_fcn_forward: layer %d has no weights", layer); return LM_ERR_STATE; }
+    const int P = 16 + l.k - 1;
+    const size_t smem = (size_t)P * P * (C + 4) * 4 + (size_t)l.k * l.k * C * 16;
+#if !LM_HIP_EMULATED
+    static size_t configured = 0;
+    if (smem > configured) {
+        LM_HIP(hipFuncSetAttribute((const void*)lm_k_conv_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        configured = smem;
+    }
+#endif
+    const int tiles = ((W + 15) / 16) * ((H + 15) / 16);
+    hipLaunchKernelGGL(lm_k_conv_small, dim3(tiles), dim3(256), smem, st, in, ips, C, H, W, l.w, l.bias, l.k, l.cout, act, out, ops);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+// forward() of the non-reconstruction branch (:364-403) on one RGB frame resident on the device.
+// Outputs (device, fp32): d_out [h*w] binarization logit, d_text [h*w] text-mask logit, d_rec [3][h*w] reconstruction.
+extern "C" int lm_fcn_forward(LmFcn* f, const uint8_t* d_rgb, int h, int w, float* d_out, float* d_text, float* d_rec, void* stream)
+{
+    if (!f || !d_rgb || h < 32 || w < 32 || h > f->max_h || w > f->max_w || (long long)h * w > (long long)f->max_h * f->max_w) {
+        lm_set_error("lm_fcn_forward: bad arguments (frame %dx%d, network sized for %dx%d)", w, h, f ? f->max_w : 0, f ? f->max_h : 0);
+        return LM_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int* wd = f->widths;
+    int H[6], W[6];
+    H[0] = h; W[0] = w;
+    for (int l = 1; l < 6; l++) { H[l] = H[l - 1] >> 1; W[l] = W[l - 1] >> 1; }
+    const long long npx = (long long)h * w;
+    const int c1 = wd[15], pm1 = wd[16], pm2 = wd[17];
+    const int s_px0 = lm_pad8(3 + c1), s_px1 = lm_pad8(3 + pm1), s_px2 = lm_pad8(3 + pm2);
+    int rc;
+    hipLaunchKernelGGL(lm_k_prepare, dim3((unsigned)std::min<long long>((npx + 255) / 256, 8192)), dim3(256), 0, st, d_rgb, f->x0, npx);
+    // ---- encoder
+    const float* cur = f->x0;
+    int cc = 8;
+    for (int n = 0; n < 5; n++) {
+        if ((rc = lm_conv_layer(f, n, cur, cc, cc, nullptr, 0, 0, H[n], W[n], f->pre[n], wd[n], 0, LM_ACT_GELU, st))) return rc;
+        const long long tot = (long long)H[n + 1] * W[n + 1] * (wd[n] / 4);
+        hipLaunchKernelGGL(lm_k_maxpool2, dim3((unsigned)std::min<long long>((tot + 255) / 256, 8192)), dim3(256), 0, st, f->pre[n], wd[n],
+                           f->pool[n], wd[n], H[n], W[n], wd[n]);
+        cur = f->pool[n];
+        cc = wd[n];
+    }
+    if ((rc = lm_conv_layer(f, 5, cur, cc, cc, nullptr, 0, 0, H[5], W[5], f->mid, wd[5], 0, LM_ACT_GELU, st))) return rc;
+    // ---- decoder
+    cur = f->mid;
+    cc = wd[5];
+    for (int n = 0; n < 5; n++) {           // level L = 5 - n, works on grid H[4 - n]
+        const int g = 4 - n;
+        const int cu = wd[6 + 2 * n], co = wd[7 + 2 * n];
+        if ((rc = lm_convT_layer(f, 6 + n, cur, cc, H[g + 1], W[g + 1], f->up[n], H[g], W[g], st))) return rc;
+        float* dst = (n < 4) ? f->cu[n] : f->px0;
+        const int ops = (n < 4) ? co : s_px0, ooff = (n < 4) ? 0 : 3;
+        if ((rc = lm_conv_layer(f, 11 + n, f->up[n], cu, cu, f->pre[g], wd[g], wd[g], H[g], W[g], dst, ops, ooff, LM_ACT_GELU, st))) return rc;
+        cur = dst;
+        cc = co;
+    }
+    // ---- heads.  x_up1 lives in channels 3..3+c1 of px0 (pixel stride s_px0)
+    const float* xup = f->px0 + 3;
+    // x_up1 is not 16-byte aligned at channel offset 3, so the small kernel reads the whole (diff, x_up1) buffer with zero
+    // weights on channels 0..2 (the host packs them that way)
+    if ((rc = lm_small_layer(f, 16, f->px0, s_px0, s_px0, h, w, f->text, 1, LM_ACT_NONE, st))) return rc;
+    if ((rc = lm_small_layer(f, 17, f->px0, s_px0, s_px0, h, w, f->rec4, 4, LM_ACT_TANH, st))) return rc;
+    (void)xup;
+    hipLaunchKernelGGL(lm_k_diff, dim3((unsigned)std::min<long long>((npx + 255) / 256, 8192)), dim3(256), 0, st, f->x0, f->rec4, f->text, npx,
+                       f->px0, s_px0, f->px1, s_px1, f->px2, s_px2);
+    if ((rc = lm_conv_layer(f, 18, f->px0, s_px0, s_px0, nullptr, 0, 0, h, w, f->px1, s_px1, 3, LM_ACT_GELU, st))) return rc;
+    if ((rc = lm_conv_layer(f, 19, f->px1, s_px1, s_px1, nullptr, 0, 0, h, w, f->px2, s_px2, 3, LM_ACT_GELU, st))) return rc;
+    if ((rc = lm_small_layer(f, 20, f->px2, s_px2, s_px2, h, w, f->outl, 1, LM_ACT_NONE, st))) return rc;
+    if (d_out) LM_HIP(hipMemcpyAsync(d_out, f->outl, (size_t)npx * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (d_text) LM_HIP(hipMemcpyAsync(d_text, f->text, (size_t)npx * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (d_rec) hipLaunchKernelGGL(lm_k_nhwc4_to_chw3, dim3((unsigned)std::min<long long>((npx + 255) / 256, 8192)), dim3(256), 0, st, f->rec4, d_rec, npx);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}

@@ -203,16 +203,30 @@ __global__ void __launch_bounds__(256) lm_k_render_frames(const long long* __res
     __syncthreads();
     const long long i0 = frame_item_off[f], i1 = frame_item_off[f + 1];
     const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6), lane = lm_lane();
-    for (long long i = i0 + wave; i < i1; i += nwaves) {
-        const LmRenderItem it = items[i];
-        const int xa = it.x0 > X0 ? it.x0 : X0, xb = (it.x0 + it.w < X0 + LM_RT_COLS) ? it.x0 + it.w : X0 + LM_RT_COLS;
-        const int ya = it.y0 > Y0 ? it.y0 : Y0, yb = (it.y0 + it.h < Y0 + LM_RT_ROWS) ? it.y0 + it.h : Y0 + LM_RT_ROWS;
-        if (xa >= xb || ya >= yb) continue;
-        const int tw = xb - xa, total = tw * (yb - ya);
-        for (int idx = lane; idx < total; idx += 64) {
-            const int yy = idx / tw, xx = idx - yy * tw;
-            const int y = ya + yy, x = xa + xx;
-            if (images[it.img_off + (long long)(y - it.y0) * it.w + (x - it.x0)]) atomicAdd(&s_cnt[(y - Y0) * LM_RT_COLS + (x - X0)], 1);
+    // each wave screens 64 items at a time (one box test per lane), then paints the few that touch the tile
+    for (long long ib = i0 + (long long)wave * 64; ib < i1; ib += (long long)nwaves * 64) {
+        LmRenderItem mine;
+        mine.x0 = 0; mine.y0 = 0; mine.w = 0; mine.h = 0; mine.img_off = 0;
+        bool hit = false;
+        if (ib + lane < i1) {
+            mine = items[ib + lane];
+            hit = mine.x0 < X0 + LM_RT_COLS && mine.x0 + mine.w > X0 && mine.y0 < Y0 + LM_RT_ROWS && mine.y0 + mine.h > Y0;
+        }
+        unsigned long long mask = __ballot(hit);
+        while (mask) {
+            const int l = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            LmRenderItem it;
+            it.x0 = __shfl(mine.x0, l); it.y0 = __shfl(mine.y0, l); it.w = __shfl(mine.w, l); it.h = __shfl(mine.h, l);
+            it.img_off = __shfl(mine.img_off, l);
+            const int xa = it.x0 > X0 ? it.x0 : X0, xb = (it.x0 + it.w < X0 + LM_RT_COLS) ? it.x0 + it.w : X0 + LM_RT_COLS;
+            const int ya = it.y0 > Y0 ? it.y0 : Y0, yb = (it.y0 + it.h < Y0 + LM_RT_ROWS) ? it.y0 + it.h : Y0 + LM_RT_ROWS;
+            const int tw = xb - xa, total = tw * (yb - ya);
+            for (int idx = lane; idx < total; idx += 64) {
+                const int yy = idx / tw, xx = idx - yy * tw;
+                const int y = ya + yy, x = xa + xx;
+                if (images[it.img_off + (long long)(y - it.y0) * it.w + (x - it.x0)]) atomicAdd(&s_cnt[(y - Y0) * LM_RT_COLS + (x - X0)], 1);
+            }
         }
     }
     __syncthreads();

@@ -1,0 +1,166 @@
+"""Host side of the HIP FCN-LectureNet: BatchNorm folding, weight packing into MFMA fragment order, and a class with
+the reference's inference API (AccessMath/lecturenet_v1/FCN_lecturenet.py: CreateFromConfig :620-659, load_state_dict,
+eval, cuda, binarize :430-505) so the step-01 worker and test_FCN_binarizer.py can use it unchanged.
+
+All convolution arithmetic runs in liblecturemath_hip.so (lm_fcn.hip); numpy here only rearranges weights once.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .device import Backend
+
+BN_EPS = 1e-5
+
+# layer ids of lm_fcn.hip
+L_DOWN, L_MID, L_UPT, L_UPC, L_TEXT, L_REC, L_PX1, L_PX2, L_OUT = 0, 5, 6, 11, 16, 17, 18, 19, 20
+
+WIDTH_KEYS = [  # CreateFromConfig :621-646, with its defaults
+    ("FCN_BINARIZER_NET_DOWN_CONV_FILTERS_1", 16), ("FCN_BINARIZER_NET_DOWN_CONV_FILTERS_2", 32),
+    ("FCN_BINARIZER_NET_DOWN_CONV_FILTERS_3", 64), ("FCN_BINARIZER_NET_DOWN_CONV_FILTERS_4", 128),
+    ("FCN_BINARIZER_NET_DOWN_CONV_FILTERS_5", 256), ("FCN_BINARIZER_NET_MIDDLE_CONV_FILTERS_MIDDLE", 512),
+    ("FCN_BINARIZER_NET_UPSAMPLE_FILTERS_5", 256), ("FCN_BINARIZER_NET_UP_CONV_FILTERS_5", 256),
+    ("FCN_BINARIZER_NET_UPSAMPLE_FILTERS_4", 128), ("FCN_BINARIZER_NET_UP_CONV_FILTERS_4", 128),
+    ("FCN_BINARIZER_NET_UPSAMPLE_FILTERS_3", 64), ("FCN_BINARIZER_NET_UP_CONV_FILTERS_3", 64),
+    ("FCN_BINARIZER_NET_UPSAMPLE_FILTERS_2", 32), ("FCN_BINARIZER_NET_UP_CONV_FILTERS_2", 32),
+    ("FCN_BINARIZER_NET_UPSAMPLE_FILTERS_1", 16), ("FCN_BINARIZER_NET_UP_CONV_FILTERS_1", 16),
+    ("FCN_BINARIZER_NET_PIXEL_FEATURES_1", 32), ("FCN_BINARIZER_NET_PIXEL_FEATURES_2", 16),
+]
+
+
+def _np(v):
+    return v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+
+
+def fold_bn(w, b, sd, bn, out_axis):
+    """conv (or transposed conv) followed by eval-mode BatchNorm -> one affine conv, in fp32."""
+    g, beta = _np(sd[bn + ".weight"]).astype(np.float32), _np(sd[bn + ".bias"]).astype(np.float32)
+    mean, var = _np(sd[bn + ".running_mean"]).astype(np.float32), _np(sd[bn + ".running_var"]).astype(np.float32)
+    s = (g / np.sqrt(var + np.float32(BN_EPS))).astype(np.float32)
+    shape = [1] * w.ndim
+    shape[out_axis] = -1
+    return (w * s.reshape(shape)).astype(np.float32), ((b - mean) * s + beta).astype(np.float32)
+
+
+def pack_mfma(w_oikk, ck, cin_map, cin_padded):
+    """[Cout][Cin][K][K] -> [chunk][tap][kstep][nblock][lane 64][4] for v_mfma_f32_32x32x2_f32:
+    element e of lane l = W[co = nblock*32 + (l & 31)][ci = chunk*ck + kstep*8 + 4*(l >> 5) + e][tap].
+    cin_map[i] = position of logical input channel i in the padded channel space of the input buffer(s)."""
+    cout, cin, k, _ = w_oikk.shape
+    nblocks = (cout + 31) // 32
+    wp = np.zeros((nblocks * 32, cin_padded, k * k), np.float32)
+    wp[:cout][:, np.asarray(cin_map)] = w_oikk.reshape(cout, cin, k * k)
+    nchunks, ks = cin_padded // ck, ck // 8
+    # wp[co, ci, tap] -> [chunk, ks, half, e, tap, nblock, j]
+    a = wp.reshape(nblocks, 32, nchunks, ks, 2, 4, k * k)            # nb, j, chunk, ks, half, e, tap
+    a = a.transpose(2, 6, 3, 0, 4, 1, 5)                              # chunk, tap, ks, nb, half, j, e
+    return np.ascontiguousarray(a).reshape(-1)
+
+
+def pack_small(w_oikk, cin_map, cin_padded):
+    """[Cout<=4][Cin][K][K] -> [tap][C padded][4]."""
+    cout, cin, k, _ = w_oikk.shape
+    out = np.zeros((k * k, cin_padded, 4), np.float32)
+    out[:, np.asarray(cin_map), :cout] = w_oikk.reshape(cout, cin, k * k).transpose(2, 1, 0)
+    return out.reshape(-1)
+
+
+def _pad8(c):
+    return (c + 7) & ~7
+
+
+class FcnEngine:
+    """Device network built from a reference state_dict."""
+
+    def __init__(self, widths, pixel_kernel, kernel, max_h, max_w, lib=None):
+        self.lib = lib or _lib.load()
+        self.be = Backend(self.lib)
+        self.widths = [int(v) for v in widths]
+        self.pk, self.kk = int(pixel_kernel), int(kernel)
+        self.max_h, self.max_w = max_h, max_w
+        arr = (ctypes.c_int32 * 18)(*self.widths)
+        self.handle = self.lib.lm_fcn_create(arr, self.pk, self.kk, max_h, max_w)
+        if not self.handle:
+            raise _lib.LecturemathError(_lib.LM_ERR_ARG, self.lib.last_error())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.lm_fcn_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _set(self, layer, w, b, cin, cout, k, ck):
+        w = np.ascontiguousarray(w, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        self.lib.check(self.lib.lm_fcn_set_layer(self.handle, layer, w.ctypes.data, w.size, b.ctypes.data, b.size, cin, cout, k, ck))
+
+    def load_state_dict(self, sd):
+        d1, d2, d3, d4, d5, mid, u5, c5, u4, c4, u3, c3, u2, c2, u1, c1, pm1, pm2 = self.widths
+        downs = [d1, d2, d3, d4, d5]
+
+        def conv_bn(name):
+            w, b = _np(sd[name + ".0.weight"]).astype(np.float32), _np(sd[name + ".0.bias"]).astype(np.float32)
+            return fold_bn(w, b, sd, name + ".1", 0)
+
+        def bias_pad(b):
+            out = np.zeros(((len(b) + 31) // 32) * 32, np.float32)
+            out[:len(b)] = b
+            return out
+
+        def ck_for(*chans):
+            return 16 if all(c % 16 == 0 for c in chans) else 8
+
+        # encoder + mid (layer 1 sees the 3 RGB channels padded to 8)
+        cin = [3] + downs
+        for n in range(5):
+            w, b = conv_bn("conv_down_block_%d" % (n + 1))
+            cpad = 8 if n == 0 else cin[n]
+            ck = ck_for(cpad)
+            self._set(L_DOWN + n, pack_mfma(w, ck, range(cin[n]), cpad), bias_pad(b), cpad, downs[n], self.kk, ck)
+        w, b = conv_bn("mid_block")
+        ck = ck_for(d5)
+        self._set(L_MID, pack_mfma(w, ck, range(d5), d5), bias_pad(b), d5, mid, self.kk, ck)
+        # decoder: level 5 .. 1
+        ups = {5: (mid, u5, c5, d5), 4: (c5, u4, c4, d4), 3: (c4, u3, c3, d3), 2: (c3, u2, c2, d2), 1: (c2, u1, c1, d1)}
+        for i, lvl in enumerate((5, 4, 3, 2, 1)):
+            tin, u, c, skip = ups[lvl]
+            wt = _np(sd["transposed_conv_%d.weight" % lvl]).astype(np.float32)          # [Cin][Cout][2][2]
+            bt = _np(sd["transposed_conv_%d.bias" % lvl]).astype(np.float32)
+            wt, bt = fold_bn(wt, bt, sd, "upsample_block_%d.0" % lvl, 1)
+            ck = ck_for(tin)
+            sets = [pack_mfma(np.ascontiguousarray(wt[:, :, dy, dx].T)[:, :, None, None], ck, range(tin), tin)
+                    for dy in (0, 1) for dx in (0, 1)]
+            self._set(L_UPT + i, np.concatenate(sets), bias_pad(bt), tin, u, 1, ck)
+            w, b = conv_bn("conv_up_block_%d" % lvl)                                      # input = cat(up, skip_pre)
+            ck = ck_for(u, skip)
+            self._set(L_UPC + i, pack_mfma(w, ck, range(u + skip), u + skip), bias_pad(b), u + skip, c, self.kk, ck)
+        # heads: inputs are (diff | features | zero pad) buffers
+        s0, s1, s2 = _pad8(3 + c1), _pad8(3 + pm1), _pad8(3 + pm2)
+        w, b = conv_bn("conv_text_mask_out")
+        self._set(L_TEXT, pack_small(w, range(3, 3 + c1), s0), np.pad(b, (0, 4 - len(b))), s0, 1, self.pk, 0)
+        w, b = conv_bn("conv_reconstruct")
+        self._set(L_REC, pack_small(w, range(3, 3 + c1), s0), np.pad(b, (0, 4 - len(b))), s0, 3, self.kk, 0)
+        w, b = conv_bn("conv_pixels_1")
+        self._set(L_PX1, pack_mfma(w, 8, range(3 + c1), s0), bias_pad(b), s0, pm1, self.pk, 8)
+        w, b = conv_bn("conv_pixels_2")
+        self._set(L_PX2, pack_mfma(w, 8, range(3 + pm1), s1), bias_pad(b), s1, pm2, self.pk, 8)
+        w, b = conv_bn("conv_out")
+        self._set(L_OUT, pack_small(w, range(3 + pm2), s2), np.pad(b, (0, 4 - len(b))), s2, 1, self.pk, 0)
+
+    def forward(self, rgb):
+        """rgb: device (or host numpy) uint8 [H,W,3] -> device fp32 (logit [H,W], text logit [H,W], rec [3,H,W])."""
+        if isinstance(rgb, np.ndarray):
+            rgb = self.be.from_host(rgb)
+        h, w = int(rgb.shape[0]), int(rgb.shape[1])
+        out = self.be.empty((h, w), np.float32)
+        text = self.be.empty((h, w), np.float32)
+        rec = self.be.empty((3, h, w), np.float32)
+        self.lib.check(self.lib.lm_fcn_forward(self.handle, _lib.ptr(rgb), h, w, _lib.ptr(out), _lib.ptr(text), _lib.ptr(rec),
+                                               self.be.stream()))
+        return out, text, rec

@@ -5,6 +5,8 @@
 
 #include <vector>
 
+alignas(16) char lm_emu_dynsmem[160 * 1024];
+
 namespace hipemu {
 
 enum { READY = 0, AT_BLOCK_BARRIER = 1, AT_WAVE_COLL = 2, DONE = 3 };

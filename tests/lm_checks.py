@@ -157,3 +157,22 @@ def check_grouping_golden(lib, name, max_batch=16):
             gr.close()
     finally:
         fs.close()
+
+
+def check_fcn_golden(lib, name, tol=1e-3):
+    """HIP FCN forward vs the reference module's outputs (G5 fixture); tolerance 1e-3 on logits (BASELINE.json)."""
+    from lecturemath_amd import fcn
+    g = np.load(os.path.join(GOLD, "g5_fcn_%s.npz" % name))
+    sd = {k[3:]: g[k] for k in g.files if k.startswith("sd.")}
+    rgb = g["rgb"]
+    h, w = rgb.shape[:2]
+    eng = fcn.FcnEngine(g["widths"], int(g["pk"]), 3, h, w, lib)
+    try:
+        eng.load_state_dict(sd)
+        out, text, rec = (eng.be.to_host(t) for t in eng.forward(rgb))
+        assert np.abs(out - g["out"][0, 0]).max() <= tol
+        assert np.abs(text - g["text"][0, 0]).max() <= tol
+        assert np.abs(rec - g["rec"][0]).max() <= tol
+        return float(np.abs(out - g["out"][0, 0]).max())
+    finally:
+        eng.close()

@@ -104,3 +104,28 @@ def test_dense_wide_noise_band_fallback(hip_lib, oracle_built):
 def test_grouping_golden(hip_lib, name):
     """Step 03 (split, stable set, overlaps, groups, ages, conflicts, group images, reconstructed frames) vs the reference."""
     lm_checks.check_grouping_golden(hip_lib, name)
+
+
+@pytest.mark.parametrize("name", ["k7_70x94", "k3_135x240", "k7_66x130_wide"])
+def test_fcn_golden(hip_lib, name):
+    """FCN-LectureNet forward (fp32 MFMA conv stack) vs the reference module: max |logit diff| <= 1e-3."""
+    assert lm_checks.check_fcn_golden(hip_lib, name) < 1e-4
+
+
+def test_fcn_shipped_config_vs_oracle(hip_lib):
+    """The shipped network widths (configs/FCN_LectureNet.conf:109-132, 15.8 M parameters, 7x7 pixel convs) on an
+    odd-sized 270x478 frame (exercises every output_size padding) against the torch fp32 oracle."""
+    import torch
+    from lecturemath_amd import fcn
+    from oracle import fcn as ofcn
+    sd = ofcn.random_state_dict(ofcn.SHIPPED_WIDTHS, pixel_kernel=7, seed=0)
+    rgb, _ = synth.whiteboard_rgb(270, 478, n_glyphs=120, seed=4)
+    eng = fcn.FcnEngine(ofcn.SHIPPED_WIDTHS, 7, 3, 270, 478, hip_lib)
+    eng.load_state_dict(sd)
+    out, text, rec = (t.cpu().numpy() for t in eng.forward(rgb))
+    with torch.no_grad():
+        o, t, r = ofcn.forward(sd, ofcn.prepare_image(rgb))
+    assert np.abs(out - o[0, 0].numpy()).max() <= 1e-3
+    assert np.abs(text - t[0, 0].numpy()).max() <= 1e-3
+    assert np.abs(rec - r[0].numpy()).max() <= 1e-3
+    eng.close()

@@ -78,3 +78,7 @@ def test_dense_wide_noise_band_fallback(emu_lib, oracle_built):
 
 def test_grouping_golden_short_gap(emu_lib):
     lm_checks.check_grouping_golden(emu_lib, "short_gap_jitter")
+
+
+def test_fcn_golden_tiny(emu_lib):
+    assert lm_checks.check_fcn_golden(emu_lib, "k7_70x94") < 1e-4
