@@ -41,11 +41,93 @@ def parse():
     p.add_argument("--cpu-frames", type=int, default=200, help="prefix of the stream timed on the CPU oracle (0 = skip)")
     p.add_argument("--no-labels", action="store_true", help="do not materialise the int32 label image")
     p.add_argument("--seed", type=int, default=20213)
+    p.add_argument("--workload", default="stream", choices=["stream", "fcn"],
+                   help="stream = configs[2] (headline metric); fcn = configs[1], FCN-LectureNet inference on one 1080p frame")
     return p.parse_args()
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+
+
+def fcn_flops(widths, pk, kk, h, w):
+    """2*Cin*Cout*k*k*Hout*Wout per conv (transposed convs: Hin*Win), SURVEY.md 8(d) config 2."""
+    d1, d2, d3, d4, d5, mid, u5, c5, u4, c4, u3, c3, u2, c2, u1, c1, pm1, pm2 = widths
+    hs, ws = [h], [w]
+    for _ in range(5):
+        hs.append(hs[-1] // 2)
+        ws.append(ws[-1] // 2)
+    f = 0
+    cin = 3
+    for n, co in enumerate((d1, d2, d3, d4, d5)):
+        f += 2 * cin * co * kk * kk * hs[n] * ws[n]
+        cin = co
+    f += 2 * d5 * mid * kk * kk * hs[5] * ws[5]
+    prev = mid
+    for n, (u, c, skip) in enumerate(((u5, c5, d5), (u4, c4, d4), (u3, c3, d3), (u2, c2, d2), (u1, c1, d1))):
+        g = 4 - n
+        f += 2 * prev * u * 4 * hs[g + 1] * ws[g + 1]
+        f += 2 * (u + skip) * c * kk * kk * hs[g] * ws[g]
+        prev = c
+    px = h * w
+    f += 2 * c1 * 1 * pk * pk * px + 2 * c1 * 3 * kk * kk * px
+    f += 2 * (3 + c1) * pm1 * pk * pk * px + 2 * (3 + pm1) * pm2 * pk * pk * px + 2 * (3 + pm2) * 1 * pk * pk * px
+    return f
+
+
+def main_fcn(a):
+    import torch
+    from lecturemath_amd import _lib, fcn, synth
+    from oracle import fcn as ofcn
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    lib = _lib.load()
+    H, W = a.height, a.width
+    widths, pk = ofcn.SHIPPED_WIDTHS, 7
+    sd = ofcn.random_state_dict(widths, pixel_kernel=pk, seed=0)
+    eng = fcn.FcnEngine(widths, pk, 3, H, W, lib)
+    eng.load_state_dict(sd)
+    rgb, _ = synth.whiteboard_rgb(H, W, 1500, seed=20211)
+    d_rgb = torch.from_numpy(rgb).cuda()
+    lab = None
+    for _ in range(a.warmup):
+        eng.forward(d_rgb)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(a.steps):
+        out, text, rec = eng.forward(d_rgb)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gpu_ms = e0.elapsed_time(e1) / a.steps
+    fl = fcn_flops(widths, pk, 3, H, W)
+    tflops = fl / (gpu_ms * 1e-3) / 1e12
+    cpu = None
+    if a.cpu_frames > 0:
+        torch.set_num_threads(os.cpu_count())
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            o, t, r = ofcn.forward(sd, ofcn.prepare_image(rgb))
+        cdt = time.perf_counter() - t0
+        err = float((out.cpu() - o[0, 0]).abs().max())
+        cpu = {"value": round(1.0 / cdt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": "one 1080p frame, oracle/fcn.py (torch fp32 CPU functional restatement); max |logit diff| vs HIP = %.2e" % err}
+    print(json.dumps({
+        "metric": "frames/sec FCN-LectureNet binarizer inference @1080p", "value": round(a.steps / dt, 3), "unit": "frames/s", "n_gpus": 1,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: FCN-LectureNet (shipped widths, 15.8 M params, random init + randomised BN) forward on one "
+                               "%dx%d synthetic whiteboard frame" % (W, H), "gflop_per_frame": round(fl / 1e9, 1)},
+        "roofline": {"bound": "mfma", "kernel": "lm_fcn_forward[lm_k_conv_mfma + heads]", "achieved": round(tflops, 2),
+                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                     "launch_ms": round(gpu_ms, 3)},
+        "cpu_baseline": cpu}))
 
 
 def main():
     a = parse()
+    if a.workload == "fcn":
+        return main_fcn(a)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
