@@ -60,6 +60,9 @@ void lm_ctx_destroy(LmCtx* ctx);
 /* FCN_LectureNet.binarize post-processing + worker inversion (FCN_lecturenet.py:452,461-467;
  * FCN_lecturenet_binarizer.py:54): out = 255 - (trunc(sigmoid(logit)*255) >= thr ? 255 : 0), n pixels. */
 int lm_threshold_invert(const float* d_logits, uint8_t* d_out, int64_t n, int thr, void* stream);
+/* same without (invert = 0) or with (invert != 0) the worker's inversion: FCN_LectureNet.binarize itself returns the
+ * non-inverted image (:461-467) */
+int lm_threshold(const float* d_logits, uint8_t* d_out, int64_t n, int thr, int invert, void* stream);
 
 /* scipy.ndimage.label (labeler.py:126) for n_frames frames (uint8, non-zero = foreground, contiguous
  * [n_frames][height][width]).  d_labels (int32, same shape) may be NULL when only the CC records are
@@ -96,6 +99,8 @@ LmStream* lm_stream_create(LmCtx* ctx, int max_frames, int64_t max_ccs, int64_t 
                            double min_recall, double min_precision, int max_gap, int min_pixels);
 void lm_stream_destroy(LmStream* s);
 int lm_stream_reset(LmStream* s, void* stream);
+/* MIN_CC_PIXELS filter (labeler.py:22,177) applied to frames pushed from now on (filter_small=False callers use 1) */
+int lm_stream_set_min_pixels(LmStream* s, int min_pixels);
 
 /* Push the next n_frames binary frames (device, uint8): label -> stats -> kept CCs + crops -> match.
  * d_labels may be NULL.  Asynchronous on `stream`. */
@@ -104,6 +109,15 @@ int lm_stream_push(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* 
 /* Synchronise and read the stream's counters: out[0]=n_frames, [1]=n_cc, [2]=n_crop_words, [3]=n_unique,
  * [4]=n_active, [5]=tempo_count, [6]=device error code. */
 int lm_stream_counters(LmStream* s, int64_t* h_out7, void* stream);
+
+/* Rebuild a stream on the device from host arrays in lm_stream_read's format (step 02 -> step 03 through the pickled
+ * hand-off).  h_active / h_active_cc / h_active_last (n_active each: unique index, global index of its first-seen CC,
+ * last frame it was matched; ascending unique index) restore the matching state so that lm_stream_push may continue;
+ * pass NULL / 0 when only lm_group_run follows. */
+int lm_stream_import(LmStream* s, const int32_t* h_rec, const int64_t* h_frame_off, const int64_t* h_crop_off,
+                     const uint32_t* h_crop, int n_frames, int64_t n_cc, int64_t n_crop_words, int n_unique,
+                     int64_t tempo_count, const int32_t* h_active, const int32_t* h_active_cc, const int32_t* h_active_last,
+                     int n_active, void* stream);
 
 /* Copy results to the host (call lm_stream_counters first to size the buffers).
  * h_rec: n_cc x 8 int32 = cc_id, min_x, max_x, min_y, max_y, size, frame, assigned unique index.

@@ -38,6 +38,7 @@ SIGNATURES = {
     "lm_ctx_create": (_vp, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "lm_ctx_destroy": (None, [_vp]),
     "lm_threshold_invert": (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, _vp]),
+    "lm_threshold": (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp]),
     "lm_label_batch": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "lm_label_counts": (ctypes.c_int, [_vp, _vp, _vp]),
     "lm_cc_stats_batch": (ctypes.c_int, [_vp, _vp]),
@@ -48,8 +49,11 @@ SIGNATURES = {
     "lm_stream_create": (_vp, [_vp, ctypes.c_int, _i64, _i64, ctypes.c_int, _f64, _f64, ctypes.c_int, ctypes.c_int]),
     "lm_stream_destroy": (None, [_vp]),
     "lm_stream_reset": (ctypes.c_int, [_vp, _vp]),
+    "lm_stream_set_min_pixels": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lm_stream_push": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "lm_stream_counters": (ctypes.c_int, [_vp, _vp, _vp]),
+    "lm_stream_import": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, _i64, _i64, ctypes.c_int, _i64, _vp, _vp, _vp,
+                                        ctypes.c_int, _vp]),
     "lm_stream_read": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lm_group_run": (_vp, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f64, _f64, ctypes.c_int, _vp]),
     "lm_group_destroy": (None, [_vp]),

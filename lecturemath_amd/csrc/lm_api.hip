@@ -172,14 +172,19 @@ extern "C" LmCtx* lm_ctx_create(int width, int height, int max_batch)
 // ------------------------------------------------------------------------------------------------
 // threshold
 // ------------------------------------------------------------------------------------------------
-extern "C" int lm_threshold_invert(const float* d_logits, uint8_t* d_out, int64_t n, int thr, void* stream)
+extern "C" int lm_threshold(const float* d_logits, uint8_t* d_out, int64_t n, int thr, int invert, void* stream)
 {
-    if (!d_logits || !d_out || n < 0) { lm_set_error("lm_threshold_invert: bad arguments"); return LM_ERR_ARG; }
+    if (!d_logits || !d_out || n < 0) { lm_set_error("lm_threshold: bad arguments"); return LM_ERR_ARG; }
     if (n == 0) return LM_OK;
     hipLaunchKernelGGL(lm_k_threshold_invert, dim3(lm_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream,
-                       d_logits, d_out, (long long)n, thr);
+                       d_logits, d_out, (long long)n, thr, invert ? 0xffu : 0u);
     LM_HIP(hipGetLastError());
     return LM_OK;
+}
+
+extern "C" int lm_threshold_invert(const float* d_logits, uint8_t* d_out, int64_t n, int thr, void* stream)
+{
+    return lm_threshold(d_logits, d_out, n, thr, 1, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -360,6 +365,13 @@ extern "C" void lm_stream_destroy(LmStream* s)
     delete s;
 }
 
+extern "C" int lm_stream_set_min_pixels(LmStream* s, int min_pixels)
+{
+    if (!s || min_pixels < 0) { lm_set_error("lm_stream_set_min_pixels: bad arguments"); return LM_ERR_ARG; }
+    s->min_pixels = min_pixels;
+    return LM_OK;
+}
+
 extern "C" int lm_stream_reset(LmStream* s, void* stream)
 {
     if (!s) { lm_set_error("lm_stream_reset: null stream"); return LM_ERR_ARG; }
@@ -497,6 +509,81 @@ extern "C" int lm_stream_counters(LmStream* s, int64_t* out, void* stream)
                      s->cap_cc, s->cap_words, s->cap_uniq, s->cap_frames);
         return h.error;
     }
+    return LM_OK;
+}
+
+// unpack host records into the device layout (inverse of lm_k_pack_records)
+__global__ void __launch_bounds__(256) lm_k_unpack_records(const int32_t* __restrict__ in8, const long long* __restrict__ crop_off,
+                                                           long long n, LmCcRec* __restrict__ cc, int32_t* __restrict__ assign)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int32_t* o = in8 + i * 8;
+        LmCcRec r;
+        r.cc_id = o[0]; r.min_x = (int16_t)o[1]; r.max_x = (int16_t)o[2]; r.min_y = (int16_t)o[3]; r.max_y = (int16_t)o[4];
+        r.size = o[5]; r.frame = o[6]; r.pad = 0; r.crop_off = (unsigned long long)crop_off[i];
+        cc[i] = r;
+        assign[i] = o[7];
+    }
+}
+
+__global__ void __launch_bounds__(256) lm_k_import_active(const LmCcRec* __restrict__ cc, const int32_t* __restrict__ active_cc, int n,
+                                                          unsigned long long* __restrict__ active_box)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) active_box[i] = lm_pack_box(cc[active_cc[i]]);
+}
+
+// Rebuilds a stream on the device from host arrays in lm_stream_read's format (the step-02 -> step-03 hand-off through a
+// pickle, console_ui_process.py:150-186).  With the active list (unique index, its first-seen CC, last frame matched; may be
+// NULL / 0) the stream can also keep receiving frames.
+extern "C" int lm_stream_import(LmStream* s, const int32_t* h_rec, const int64_t* h_frame_off, const int64_t* h_crop_off,
+                                const uint32_t* h_crop, int n_frames, int64_t n_cc, int64_t n_crop_words, int n_unique,
+                                int64_t tempo_count, const int32_t* h_active, const int32_t* h_active_cc,
+                                const int32_t* h_active_last, int n_active, void* stream)
+{
+    if (!s || n_frames < 0 || n_cc < 0 || n_crop_words < 0 || (n_cc > 0 && (!h_rec || !h_crop_off || !h_crop)) || !h_frame_off) {
+        lm_set_error("lm_stream_import: bad arguments");
+        return LM_ERR_ARG;
+    }
+    if (n_frames > s->cap_frames || n_cc > s->cap_cc || (unsigned long long)n_crop_words > s->cap_words || n_unique > s->cap_uniq) {
+        lm_set_error("lm_stream_import: stream too small (frames %d/%d, ccs %lld/%lld, crop words %lld/%llu, uniques %d/%d)", n_frames,
+                     s->cap_frames, (long long)n_cc, s->cap_cc, (long long)n_crop_words, s->cap_words, n_unique, s->cap_uniq);
+        return LM_ERR_CAPACITY;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int rc = lm_stream_reset(s, stream);
+    if (rc) return rc;
+    if (n_cc > 0) {
+        int32_t* d_rec = nullptr;
+        long long* d_off = nullptr;
+        LM_HIP(hipMalloc((void**)&d_rec, (size_t)n_cc * 8 * sizeof(int32_t)));
+        if (hipMalloc((void**)&d_off, (size_t)n_cc * sizeof(long long)) != hipSuccess) { (void)hipFree(d_rec); lm_set_error("lm_stream_import: hipMalloc failed"); return LM_ERR_HIP; }
+        hipError_t e = hipMemcpyAsync(d_rec, h_rec, (size_t)n_cc * 8 * sizeof(int32_t), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_off, h_crop_off, (size_t)n_cc * sizeof(long long), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && n_crop_words > 0) e = hipMemcpyAsync(s->crop, h_crop, (size_t)n_crop_words * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(lm_k_unpack_records, dim3(lm_blocks(n_cc, 256)), dim3(256), 0, st, d_rec, d_off, (long long)n_cc, s->cc, s->assign);
+            e = hipStreamSynchronize(st);
+        }
+        (void)hipFree(d_rec);
+        (void)hipFree(d_off);
+        if (e != hipSuccess) { lm_set_error("lm_stream_import: copy failed"); return LM_ERR_HIP; }
+    }
+    LM_HIP(hipMemcpyAsync(s->frame_cc_off, h_frame_off, (size_t)(n_frames + 1) * sizeof(long long), hipMemcpyHostToDevice, st));
+    LmCounters h;
+    memset(&h, 0, sizeof(h));
+    h.n_cc = n_cc; h.n_words = (unsigned long long)n_crop_words; h.tempo_count = (unsigned long long)tempo_count;
+    h.n_frames = n_frames; h.n_matched = n_frames; h.n_uniq = n_unique; h.n_active = 0;
+    if (n_active > 0 && h_active && h_active_cc && h_active_last) {
+        if (n_active > s->cap_uniq) { lm_set_error("lm_stream_import: active list larger than max_uniques"); return LM_ERR_CAPACITY; }
+        LM_HIP(hipMemcpyAsync(s->active, h_active, (size_t)n_active * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        LM_HIP(hipMemcpyAsync(s->active_cc, h_active_cc, (size_t)n_active * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        LM_HIP(hipMemcpyAsync(s->active_last, h_active_last, (size_t)n_active * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(lm_k_import_active, dim3(lm_blocks(n_active, 256)), dim3(256), 0, st, s->cc, s->active_cc, n_active, s->active_box);
+        h.n_active = n_active;
+    }
+    LM_HIP(hipMemcpyAsync(s->counters, &h, sizeof(h), hipMemcpyHostToDevice, st));
+    LM_HIP(hipStreamSynchronize(st));
+    s->frames_pushed = n_frames;
     return LM_OK;
 }
 

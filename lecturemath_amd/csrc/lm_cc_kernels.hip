@@ -19,16 +19,16 @@
 // binary = ((uint8)(sigmoid(x) * 255.0f) >= thr) ? 255 : 0 ; out = 255 - binary
 // sigmoid(x) = 1 / (1 + exp(-x)) in fp32; see DESIGN.md "threshold edge" for the ulp discussion.
 // ------------------------------------------------------------------------------------------------
-LM_DEV unsigned lm_thr_px(float x, int thr)
+LM_DEV unsigned lm_thr_px(float x, int thr, unsigned flip)
 {
     float s = 1.0f / (1.0f + expf(-x));
     float v = s * 255.0f;
     unsigned u = (unsigned)v;            // truncation, v in [0, 255]
-    return (u >= (unsigned)thr) ? 0u : 255u;   // already inverted
+    return ((u >= (unsigned)thr) ? 255u : 0u) ^ flip;   // flip = 0xff: the worker's 255 - binary
 }
 
 __global__ void __launch_bounds__(256) lm_k_threshold_invert(const float* __restrict__ logits,
-                                                             uint8_t* __restrict__ out, long long n, int thr)
+                                                             uint8_t* __restrict__ out, long long n, int thr, unsigned flip)
 {
     long long stride = (long long)gridDim.x * blockDim.x;
     long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -37,15 +37,15 @@ __global__ void __launch_bounds__(256) lm_k_threshold_invert(const float* __rest
     if (aligned) {
         for (; i4 < n4; i4 += stride) {
             float4 v = *(const float4*)(logits + i4 * 4);
-            unsigned r = lm_thr_px(v.x, thr) | (lm_thr_px(v.y, thr) << 8) | (lm_thr_px(v.z, thr) << 16) |
-                         (lm_thr_px(v.w, thr) << 24);
+            unsigned r = lm_thr_px(v.x, thr, flip) | (lm_thr_px(v.y, thr, flip) << 8) | (lm_thr_px(v.z, thr, flip) << 16) |
+                         (lm_thr_px(v.w, thr, flip) << 24);
             *(unsigned*)(out + i4 * 4) = r;
         }
         long long tail = n4 * 4 + ((long long)blockIdx.x * blockDim.x + threadIdx.x);
-        if (tail < n) out[tail] = (uint8_t)lm_thr_px(logits[tail], thr);
+        if (tail < n) out[tail] = (uint8_t)lm_thr_px(logits[tail], thr, flip);
     } else {
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-            out[i] = (uint8_t)lm_thr_px(logits[i], thr);
+            out[i] = (uint8_t)lm_thr_px(logits[i], thr, flip);
     }
 }
 

@@ -121,6 +121,8 @@ class FrameStream:
         self.labeler = FrameLabeler(width, height, max_batch, lib)
         self.lib, self.be = self.labeler.lib, self.labeler.be
         self.width, self.height = width, height
+        self.min_pixels = min_pixels
+        self._create_args = None
         px = width * height
         max_ccs = max_ccs or max_frames * max(px // 256, 64)
         max_crop_words = max_crop_words or max_frames * max(px // 4, 4096)
@@ -145,6 +147,10 @@ class FrameStream:
     def reset(self):
         self.lib.check(self.lib.lm_stream_reset(self.handle, self.be.stream()))
 
+    def set_min_pixels(self, min_pixels):
+        self.lib.check(self.lib.lm_stream_set_min_pixels(self.handle, int(min_pixels)))
+        self.min_pixels = int(min_pixels)
+
     def push(self, binary, labels_out=None):
         """binary: device uint8 [n,H,W] (any n; split into batches internally). Asynchronous."""
         self.lib.check(self.lib.lm_stream_push(self.handle, _lib.ptr(binary), int(binary.shape[0]), _lib.ptr(labels_out),
@@ -167,6 +173,37 @@ class FrameStream:
         self.lib.check(self.lib.lm_stream_read(self.handle, rec.ctypes.data, foff.ctypes.data, coff.ctypes.data,
                                                crop.ctypes.data if with_crops else None, active.ctypes.data, self.be.stream()))
         return dict(k, rec=rec[:k["n_cc"]], frame_off=foff, crop_off=coff[:k["n_cc"]], crop=crop, active=active[:k["n_active"]])
+
+    def export_state(self):
+        """Host snapshot (numpy) of everything needed to rebuild the stream: records, crops, active list."""
+        r = self.read(with_crops=True)
+        rec = r["rec"]
+        nu = r["n_unique"]
+        first = np.full(nu, -1, np.int64)
+        last = np.zeros(nu, np.int32)
+        if len(rec):
+            order = np.arange(len(rec) - 1, -1, -1)
+            first[rec[order, 7]] = order                  # smallest CC index wins (written last)
+            np.maximum.at(last, rec[:, 7], rec[:, 6])
+        act = r["active"].astype(np.int32)
+        return {"width": self.width, "height": self.height, "rec": rec, "frame_off": r["frame_off"], "crop_off": r["crop_off"],
+                "crop": r["crop"][:r["n_crop_words"]], "n_unique": nu, "tempo_count": r["tempo_count"], "active": act,
+                "active_cc": first[act].astype(np.int32), "active_last": last[act].astype(np.int32), "uniq_first_cc": first}
+
+    def import_state(self, st):
+        """Inverse of export_state (capacities of this stream must suffice)."""
+        rec = np.ascontiguousarray(st["rec"], np.int32)
+        foff = np.ascontiguousarray(st["frame_off"], np.int64)
+        coff = np.ascontiguousarray(st["crop_off"], np.int64)
+        crop = np.ascontiguousarray(st["crop"], np.uint32)
+        act = np.ascontiguousarray(st["active"], np.int32)
+        acc = np.ascontiguousarray(st["active_cc"], np.int32)
+        acl = np.ascontiguousarray(st["active_last"], np.int32)
+        self.lib.check(self.lib.lm_stream_import(
+            self.handle, rec.ctypes.data if len(rec) else None, foff.ctypes.data, coff.ctypes.data if len(rec) else None,
+            crop.ctypes.data if len(crop) else (np.zeros(1, np.uint32).ctypes.data if len(rec) else None), len(foff) - 1, len(rec),
+            len(crop), int(st["n_unique"]), int(st["tempo_count"]), act.ctypes.data if len(act) else None,
+            acc.ctypes.data if len(act) else None, acl.ctypes.data if len(act) else None, len(act), self.be.stream()))
 
     def result(self, with_crops=True):
         """Same plain-data view the oracle produces (reference attribute names):

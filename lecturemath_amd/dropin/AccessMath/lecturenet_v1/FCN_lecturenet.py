@@ -1,0 +1,128 @@
+"""FCN_LectureNet inference on the MI355X with the reference's API (lecturenet_v1/FCN_lecturenet.py):
+CreateFromConfig :620-659, load_state_dict / eval / cuda (torch.nn.Module methods the callers use,
+pre_ST3D_v3.0_01_binarize.py:30-37, test_FCN_binarizer.py:38-46), binarize :430-505, prepare_image :607-618,
+from_img_space_to_cv2 :534-555.  The convolution stack runs in liblecturemath_hip.so (lm_fcn.hip); training-only members
+of the reference class are not provided (inference path only, SURVEY.md section 2 #7b/#23)."""
+import numpy as np
+import PIL.Image
+
+from lecturemath_amd import _lib, fcn
+
+
+class FCN_LectureNet:
+    MAX_PIXELS = 2500000      # :435
+
+    def __init__(self, channels, n_conv_down_1, n_conv_down_2, n_conv_down_3, n_conv_down_4, n_conv_down_5, mid_block,
+                 n_upsample_5, n_conv_up_5, n_upsample_4, n_conv_up_4, n_upsample_3, n_conv_up_3, n_upsample_2, n_conv_up_2,
+                 n_upsample_1, n_conv_up_1, kernel_size, n_pmaps_1, n_pmaps_2, pixel_kernel_size, reconstruction_mode):
+        if channels != 3 or reconstruction_mode:
+            raise NotImplementedError("the MI355X path implements the 3-channel binarization branch (reconstruction_mode=False)")
+        self.widths = [n_conv_down_1, n_conv_down_2, n_conv_down_3, n_conv_down_4, n_conv_down_5, mid_block, n_upsample_5,
+                       n_conv_up_5, n_upsample_4, n_conv_up_4, n_upsample_3, n_conv_up_3, n_upsample_2, n_conv_up_2, n_upsample_1,
+                       n_conv_up_1, n_pmaps_1, n_pmaps_2]
+        self.kernel_size, self.pixel_kernel_size = kernel_size, pixel_kernel_size
+        self.reconstruction_mode = reconstruction_mode
+        self._sd = None
+        self._engine = None
+        self._engine_hw = (0, 0)
+
+    # ---- torch.nn.Module look-alikes used by the callers
+    def load_state_dict(self, state_dict, strict=True):
+        self._sd = dict(state_dict)
+        if self._engine is not None:
+            self._engine.load_state_dict(self._sd)
+
+    def eval(self):
+        return self
+
+    def cuda(self, device=None):
+        return self
+
+    def cpu(self):
+        raise _lib.LecturemathLibraryError("FCN_LectureNet of lecturemath_amd runs on the GPU only (no CPU fallback)")
+
+    def parameters(self):
+        return iter(())
+
+    def _get_engine(self, h, w):
+        if self._sd is None:
+            raise RuntimeError("load_state_dict() must be called before binarize()")
+        if self._engine is None or h > self._engine_hw[0] or w > self._engine_hw[1] or h * w > self._engine_hw[0] * self._engine_hw[1]:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = fcn.FcnEngine(self.widths, self.pixel_kernel_size, self.kernel_size, h, w)
+            self._engine.load_state_dict(self._sd)
+            self._engine_hw = (h, w)
+        return self._engine
+
+    # ---- inference
+    def forward_logits(self, rgb_u8):
+        """Extension: uint8 RGB [H,W,3] (numpy or device tensor) -> device fp32 (logit, text logit, reconstruction)."""
+        return self._get_engine(int(rgb_u8.shape[0]), int(rgb_u8.shape[1])).forward(rgb_u8)
+
+    def binarize(self, PIL_image, return_others=False, force_binary=False, binary_treshold=128, apply_sigmoid=True):
+        o_width, o_height = PIL_image.size
+        width, height = o_width, o_height
+        while width * height > FCN_LectureNet.MAX_PIXELS:
+            PIL_image = PIL_image.resize((int(width / 2), int(height / 2)), PIL.Image.LANCZOS)
+            width, height = PIL_image.size
+        rgb = np.asarray(PIL_image.convert("RGB"), dtype=np.uint8)
+        eng = self._get_engine(height, width)
+        out, text, rec = eng.forward(rgb)
+        lib, be = eng.lib, eng.be
+        n = height * width
+
+        def post(logits):
+            if force_binary and apply_sigmoid:
+                dst = be.empty((height, width), np.uint8)
+                lib.check(lib.lm_threshold(_lib.ptr(logits), _lib.ptr(dst), n, int(binary_treshold), 0, be.stream()))
+                return be.to_host(dst)
+            v = be.to_host(logits)
+            if apply_sigmoid:
+                v = (1.0 / (1.0 + np.exp(-v, dtype=np.float32))).astype(np.float32)
+            img = (v * 255).astype(np.uint8)
+            if force_binary:
+                img[img >= binary_treshold] = 255
+                img[img < binary_treshold] = 0
+            return img
+
+        binary = post(out)
+        text_mask = rec_img = None
+        if return_others:
+            text_mask = post(text)
+            rec_img = self.from_img_space_to_cv2(be.to_host(rec))
+        if o_width != width:
+            if not force_binary:
+                raise NotImplementedError("INTER_CUBIC upsampling of non-binary outputs (:487-492) is not implemented")
+            ys = (np.arange(o_height) * height) // o_height      # INTER_NEAREST
+            xs = (np.arange(o_width) * width) // o_width
+            binary = binary[ys][:, xs]
+            if return_others:
+                text_mask = text_mask[ys][:, xs]
+                rec_img = rec_img[ys][:, xs]
+        return (binary, text_mask, rec_img) if return_others else binary
+
+    def from_img_space_to_cv2(self, image):
+        img = np.transpose(np.array(image, dtype=np.float32, copy=True), (1, 2, 0))
+        img *= 0.5
+        img += 0.5
+        img = np.ascontiguousarray(img[:, :, ::-1])
+        img *= 255
+        img[img > 255] = 255
+        img[img < 0] = 0
+        return img.astype(np.uint8)
+
+    @staticmethod
+    def prepare_image(PIL_image):
+        import torch
+        a = np.asarray(PIL_image.convert("RGB"), dtype=np.uint8)
+        t = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))).to(torch.float32).div(255)
+        return ((t - 0.5) / 0.5).unsqueeze(0)
+
+    @staticmethod
+    def CreateFromConfig(config, in_channels, reconstruction_mode):
+        w = [config.get(key, default) for key, default in fcn.WIDTH_KEYS]
+        pix_k = config.get("FCN_BINARIZER_NET_PIXEL_KERNEL_SIZE", 3)
+        k = config.get("FCN_BINARIZER_NET_KERNEL_SIZE", 3)
+        return FCN_LectureNet(in_channels, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13],
+                              w[14], w[15], k, w[16], w[17], pix_k, reconstruction_mode)

@@ -1,0 +1,132 @@
+"""Checks of the drop-in layer (lecturemath_amd/dropin: the reference's module paths, classes and script entry points)."""
+import importlib.util
+import os
+import pickle
+import sys
+import types
+
+import numpy as np
+
+import lm_checks
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPIN = os.path.join(ROOT, "lecturemath_amd", "dropin")
+
+
+def use_library(lib):
+    """Make the drop-in modules use `lib` (tests hand in the emulated build; the GPU tests the real one)."""
+    from lecturemath_amd import _lib
+    _lib._default = lib
+    if DROPIN not in sys.path:
+        sys.path.insert(0, DROPIN)
+    from AccessMath.preprocessing.content.labeler import Labeler
+    for fs in Labeler._streams.values():
+        fs.close()
+    Labeler._streams = {}
+
+
+def load_script(name):
+    spec = importlib.util.spec_from_file_location("lm_script_" + name.replace(".", "_"), os.path.join(DROPIN, name))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def fake_process(conf_overrides=None, params=None):
+    from AM_CommonTools.configuration.configuration import Configuration
+    data = {"CC_STABILITY_MIN_RECALL": "0.850", "CC_STABILITY_MIN_PRECISION": "0.850", "CC_STABILITY_MAX_GAP": "85",
+            "CC_STABILITY_MIN_TIMES": "3", "CC_GROUPING_MIN_IMAGE_THRESHOLD": "0.5", "CC_GROUPING_TEMPORAL_WINDOW": "5",
+            "CC_GROUPING_MIN_RECALL": "0.5", "CC_GROUPING_MIN_TIME_F_MEASURE": "None", "CC_GROUPING_MIN_TIME_IOU": "None"}
+    data.update(conf_overrides or {})
+    return types.SimpleNamespace(configuration=Configuration(data), params=params or {})
+
+
+def check_steps_02_03(lib, name):
+    """pre_ST3D 02 -> pickle (reference schema) -> unpickle -> pre_ST3D 03, against the reference's G3/G4 golden."""
+    use_library(lib)
+    from lecturemath_amd import png
+    g, spec, frames = lm_checks.load_stream(name)
+    compressed = [png.encode_gray8(f) for f in frames]
+    times = [1000.0 * i for i in range(len(frames))]
+    idxs = list(range(len(frames)))
+    s02 = load_script("pre_ST3D_v3.0_02_cc_analaysis.py")
+    s03 = load_script("pre_ST3D_v3.0_03_cc_grouping.py")
+    proc = fake_process({"CC_STABILITY_MAX_GAP": str(spec["gap2"])})
+    t, i, est = s02.process_input(proc, (times, idxs, compressed))
+    # step-02 state as the reference exposes it
+    assert est.tempo_count == int(g["tempo_count"])
+    assert [[(int(a), int(b)) for a, b in fl] for fl in est.unique_cc_frames] == lm_checks.unrag(g["ucf"], g["ucf_off"])
+    assert [[(int(u), int(c.cc_id)) for u, c in fr] for fr in est.cc_idx_per_frame] == lm_checks.unrag(g["cipf"], g["cipf_off"])
+    assert list(est.cc_active) == list(g["active"])
+    u0 = est.unique_cc_objects[0]
+    assert isinstance(u0.min_x, np.int32) and u0.img.dtype == np.uint8
+    blob = pickle.dumps((t, i, est), protocol=pickle.HIGHEST_PROTOCOL)
+    t2, i2, est2 = pickle.loads(blob)
+    proc3 = fake_process({"CC_STABILITY_MAX_GAP": str(spec["gap3"])})
+    rec, conf, st3d = s03.process_input(proc3, (t2, i2, est2))
+    group_ages, conflicts = conf
+    ng = len(group_ages)
+    assert [[(a,) for a in group_ages[k]] for k in range(ng)] == lm_checks.unrag(g["ages"], g["ages_off"])
+    got = sorted((k, o, d["matched"], d["unmatched"], d["area_union"], float(d["area_intersection"]))
+                 for k in conflicts for o, d in conflicts[k].items())
+    assert [tuple(float(v) for v in r) for r in got] == sorted(tuple(float(v) for v in row) for row in g["conflicts"])
+    assert (np.asarray([st3d.cc_group_boundaries[k] for k in range(ng)], np.int64).reshape(-1, 4) == g["bounds"]).all()
+    gi = np.concatenate([im.ravel() for k in range(ng) for im in st3d.cc_group_images[k]]) if ng else np.zeros(0, np.uint8)
+    assert (gi == g["gimg"]).all()
+    clean = np.stack([png.decode_gray8(c) for c in rec[2]])
+    assert (np.packbits(clean == 255, axis=2) == g["clean_packed"]).all()
+    assert (clean[(clean != 0) & (clean != 255)] == g["clean_other_val"]).all()
+    assert st3d.width == spec["w"] and st3d.height == spec["h"] and rec[0] == times
+    return blob
+
+
+def check_labeler(lib):
+    use_library(lib)
+    from AccessMath.preprocessing.content.labeler import Labeler
+    g = np.load(os.path.join(lm_checks.GOLD, "g1_label.npz"))
+    for i in (3, 6, 8, 17):
+        ccs = Labeler.extractConnectedComponents(g["img%d" % i])
+        rec = np.asarray([(c.cc_id, c.min_x, c.max_x, c.min_y, c.max_y, c.size) for c in ccs], np.int32).reshape(-1, 6)
+        assert (rec == g["rec%d" % i]).all()
+        flat = np.concatenate([c.img.ravel() for c in ccs]) if ccs else np.zeros(0, np.uint8)
+        assert (flat == g["crops%d" % i]).all()
+        if ccs:
+            assert ccs[0].start_time == 0.0 and ccs[0].img.dtype == np.uint8
+    # filter_small=False keeps every label; is_labeled=True goes through the CC_AgeBoundaries export
+    from oracle import cc as occ
+    img = g["img3"]
+    labels, n = occ.label4(img)
+    every = Labeler.extractConnectedComponents(img, filter_small=False)
+    assert len(every) == n and [c.cc_id for c in every] == list(range(n))
+    pre = Labeler.extractSpatioTemporalContent(labels, np.zeros(img.shape, np.float32), True, True)
+    ref = Labeler.extractConnectedComponents(img)
+    assert [(c.cc_id, c.size) for c in pre] == [(c.cc_id, c.size) for c in ref]
+
+
+def check_fcn_class(lib, name="k7_70x94"):
+    """FCN_LectureNet.CreateFromConfig / load_state_dict / binarize and the step-01 worker vs the reference's outputs."""
+    use_library(lib)
+    import PIL.Image
+    from AM_CommonTools.configuration.configuration import Configuration
+    from AccessMath.lecturenet_v1.FCN_lecturenet import FCN_LectureNet
+    from AccessMath.preprocessing.video_worker.FCN_lecturenet_binarizer import FCN_LectureNet_Binarizer
+    from lecturemath_amd import fcn, png
+    g = np.load(os.path.join(lm_checks.GOLD, "g5_fcn_%s.npz" % name))
+    conf = Configuration({key: str(int(v)) for (key, _), v in zip(fcn.WIDTH_KEYS, g["widths"])})
+    conf.set("FCN_BINARIZER_NET_PIXEL_KERNEL_SIZE", str(int(g["pk"])))
+    net = FCN_LectureNet.CreateFromConfig(conf, 3, False)
+    net.load_state_dict({k[3:]: g[k] for k in g.files if k.startswith("sd.")})
+    net = net.eval().cuda()
+    binary, text_mask, rec_img = net.binarize(PIL.Image.fromarray(g["rgb"]), return_others=True, force_binary=True)
+    # thresholded outputs may differ only where the logit sits within the fp32 tolerance of the decision edge
+    edge = np.abs(g["out"][0, 0] - 0.01569) < 2e-3
+    assert ((binary == g["binary"]) | edge).all()
+    edge_t = np.abs(g["text"][0, 0] - 0.01569) < 2e-3
+    assert ((text_mask == g["text_mask"]) | edge_t).all()
+    assert np.abs(rec_img.astype(np.int32) - g["rec_img"].astype(np.int32)).max() <= 1
+    worker = FCN_LectureNet_Binarizer(net)
+    worker.initialize(g["rgb"].shape[1], g["rgb"].shape[0])
+    worker.handleFrame(np.ascontiguousarray(g["rgb"][:, :, ::-1]), None, 0, 1000.0, 1000.0, 30)
+    assert worker.frame_times == [1000.0] and worker.frame_indices == [30] and worker.getWorkName()
+    dec = png.decode_gray8(worker.compressed_frames[0])
+    assert ((dec == 255 - g["binary"]) | edge).all()
