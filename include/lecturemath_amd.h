@@ -106,6 +106,12 @@ int lm_stream_set_min_pixels(LmStream* s, int min_pixels);
  * d_labels may be NULL.  Asynchronous on `stream`. */
 int lm_stream_push(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* d_labels, void* stream);
 
+/* The two halves of lm_stream_push, for frame-range sharding across GPUs: lm_stream_push_records only labels the frames and
+ * appends their CC records + crops (per-frame work, any rank); lm_stream_match runs the sequential temporal matching over
+ * the next n_frames unmatched frames (the rank that owns the whole stream, after lm_stream_import of the gathered records). */
+int lm_stream_push_records(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* d_labels, void* stream);
+int lm_stream_match(LmStream* s, int n_frames, void* stream);
+
 /* Synchronise and read the stream's counters: out[0]=n_frames, [1]=n_cc, [2]=n_crop_words, [3]=n_unique,
  * [4]=n_active, [5]=tempo_count, [6]=device error code. */
 int lm_stream_counters(LmStream* s, int64_t* h_out7, void* stream);
@@ -113,11 +119,12 @@ int lm_stream_counters(LmStream* s, int64_t* h_out7, void* stream);
 /* Rebuild a stream on the device from host arrays in lm_stream_read's format (step 02 -> step 03 through the pickled
  * hand-off).  h_active / h_active_cc / h_active_last (n_active each: unique index, global index of its first-seen CC,
  * last frame it was matched; ascending unique index) restore the matching state so that lm_stream_push may continue;
- * pass NULL / 0 when only lm_group_run follows. */
+ * pass NULL / 0 when only lm_group_run follows.  n_matched = leading frames whose records already carry their unique
+ * index (n_frames for a finished stream, 0 for gathered raw records). */
 int lm_stream_import(LmStream* s, const int32_t* h_rec, const int64_t* h_frame_off, const int64_t* h_crop_off,
                      const uint32_t* h_crop, int n_frames, int64_t n_cc, int64_t n_crop_words, int n_unique,
                      int64_t tempo_count, const int32_t* h_active, const int32_t* h_active_cc, const int32_t* h_active_last,
-                     int n_active, void* stream);
+                     int n_active, int n_matched, void* stream);
 
 /* Copy results to the host (call lm_stream_counters first to size the buffers).
  * h_rec: n_cc x 8 int32 = cc_id, min_x, max_x, min_y, max_y, size, frame, assigned unique index.

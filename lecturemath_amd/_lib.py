@@ -51,9 +51,11 @@ SIGNATURES = {
     "lm_stream_reset": (ctypes.c_int, [_vp, _vp]),
     "lm_stream_set_min_pixels": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lm_stream_push": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
+    "lm_stream_push_records": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
+    "lm_stream_match": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
     "lm_stream_counters": (ctypes.c_int, [_vp, _vp, _vp]),
     "lm_stream_import": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, _i64, _i64, ctypes.c_int, _i64, _vp, _vp, _vp,
-                                        ctypes.c_int, _vp]),
+                                        ctypes.c_int, ctypes.c_int, _vp]),
     "lm_stream_read": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lm_group_run": (_vp, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f64, _f64, ctypes.c_int, _vp]),
     "lm_group_destroy": (None, [_vp]),

@@ -378,6 +378,7 @@ extern "C" int lm_stream_reset(LmStream* s, void* stream)
     LM_HIP(hipMemsetAsync(s->counters, 0, sizeof(LmCounters), (hipStream_t)stream));
     LM_HIP(hipMemsetAsync(s->frame_cc_off, 0, sizeof(long long), (hipStream_t)stream));
     s->frames_pushed = 0;
+    s->frames_matched = 0;
     return LM_OK;
 }
 
@@ -423,7 +424,18 @@ extern "C" LmStream* lm_stream_create(LmCtx* ctx, int max_frames, int64_t max_cc
     return s;
 }
 
-extern "C" int lm_stream_push(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* d_labels, void* stream)
+static void lm_launch_match(LmStream* s, int f, hipStream_t st)
+{
+    hipLaunchKernelGGL(lm_k_match_scan, LM_HIP_EMULATED ? dim3(2, 2) : dim3(16, 32), dim3(256), 0, st, s->cc, s->frame_cc_off, f, s->active_box,
+                       s->active_last, s->active_cc, s->counters, s->best_pos, s->pairs, s->cap_pairs, s->max_gap);
+    hipLaunchKernelGGL(lm_k_match_eval, dim3(LM_HIP_EMULATED ? 2 : 128), dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, s->active_cc,
+                       s->counters, s->pairs, s->best_pos, s->cap_pairs, s->min_recall, s->min_precision);
+    // compact the active list every 16 frames (purely an optimisation: retirement is evaluated lazily)
+    hipLaunchKernelGGL(lm_k_update, dim3(1), dim3(1024), 0, st, s->cc, s->frame_cc_off, f, s->active, s->active_cc, s->active_box,
+                       s->active_last, s->counters, s->assign, s->best_pos, s->cap_pairs, s->max_gap, s->cap_uniq, (f & 15) == 15 ? 1 : 0);
+}
+
+static int lm_stream_push_impl(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* d_labels, int do_match, void* stream)
 {
     if (!s || !d_binary || n_frames <= 0) { lm_set_error("lm_stream_push: bad arguments"); return LM_ERR_ARG; }
     LmCtx* c = s->ctx;
@@ -432,6 +444,10 @@ extern "C" int lm_stream_push(LmStream* s, const uint8_t* d_binary, int n_frames
     if (s->frames_pushed + n_frames > s->cap_frames) {
         lm_set_error("lm_stream_push: stream holds %d frames, capacity %d", s->frames_pushed, s->cap_frames);
         return LM_ERR_CAPACITY;
+    }
+    if (do_match && s->frames_matched != s->frames_pushed) {
+        lm_set_error("lm_stream_push: %d frames pushed without matching; call lm_stream_match first", s->frames_pushed - s->frames_matched);
+        return LM_ERR_STATE;
     }
     const size_t px = (size_t)g.W * g.H;
     for (int done = 0; done < n_frames;) {
@@ -449,21 +465,36 @@ extern "C" int lm_stream_push(LmStream* s, const uint8_t* d_binary, int n_frames
                            c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x, c->st_count, c->kept_label, c->kept_cropoff,
                            c->frame_kept, s->batch_cc_base, s->batch_word_base, s->cc, s->crop, s->frames_pushed, g.WW, g.H,
                            g.cap);
-        for (int b = 0; b < B; b++) {
-            const int f = s->frames_pushed + b;
-            hipLaunchKernelGGL(lm_k_match_scan, LM_HIP_EMULATED ? dim3(2, 2) : dim3(16, 32), dim3(256), 0, st, s->cc, s->frame_cc_off, f, s->active_box,
-                               s->active_last, s->active_cc, s->counters, s->best_pos, s->pairs, s->cap_pairs, s->max_gap);
-            hipLaunchKernelGGL(lm_k_match_eval, dim3(LM_HIP_EMULATED ? 2 : 128), dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, s->active_cc,
-                               s->counters, s->pairs, s->best_pos, s->cap_pairs, s->min_recall, s->min_precision);
-            // compact the active list every 16 frames (purely an optimisation: retirement is evaluated lazily)
-            hipLaunchKernelGGL(lm_k_update, dim3(1), dim3(1024), 0, st, s->cc, s->frame_cc_off, f, s->active, s->active_cc,
-                               s->active_box, s->active_last, s->counters, s->assign, s->best_pos, s->cap_pairs, s->max_gap,
-                               s->cap_uniq, (f & 15) == 15 ? 1 : 0);
+        if (do_match) {
+            for (int b = 0; b < B; b++) lm_launch_match(s, s->frames_pushed + b, st);
+            s->frames_matched += B;
         }
         LM_HIP(hipGetLastError());
         s->frames_pushed += B;
         done += B;
     }
+    return LM_OK;
+}
+
+extern "C" int lm_stream_push(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* d_labels, void* stream)
+{
+    return lm_stream_push_impl(s, d_binary, n_frames, d_labels, 1, stream);
+}
+
+extern "C" int lm_stream_push_records(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* d_labels, void* stream)
+{
+    return lm_stream_push_impl(s, d_binary, n_frames, d_labels, 0, stream);
+}
+
+extern "C" int lm_stream_match(LmStream* s, int n_frames, void* stream)
+{
+    if (!s || n_frames < 0 || s->frames_matched + n_frames > s->frames_pushed) {
+        lm_set_error("lm_stream_match: %d frames requested, %d pushed, %d matched", n_frames, s ? s->frames_pushed : 0, s ? s->frames_matched : 0);
+        return LM_ERR_ARG;
+    }
+    for (int i = 0; i < n_frames; i++) lm_launch_match(s, s->frames_matched + i, (hipStream_t)stream);
+    s->frames_matched += n_frames;
+    LM_HIP(hipGetLastError());
     return LM_OK;
 }
 
@@ -538,9 +569,10 @@ __global__ void __launch_bounds__(256) lm_k_import_active(const LmCcRec* __restr
 extern "C" int lm_stream_import(LmStream* s, const int32_t* h_rec, const int64_t* h_frame_off, const int64_t* h_crop_off,
                                 const uint32_t* h_crop, int n_frames, int64_t n_cc, int64_t n_crop_words, int n_unique,
                                 int64_t tempo_count, const int32_t* h_active, const int32_t* h_active_cc,
-                                const int32_t* h_active_last, int n_active, void* stream)
+                                const int32_t* h_active_last, int n_active, int n_matched, void* stream)
 {
-    if (!s || n_frames < 0 || n_cc < 0 || n_crop_words < 0 || (n_cc > 0 && (!h_rec || !h_crop_off || !h_crop)) || !h_frame_off) {
+    if (!s || n_frames < 0 || n_cc < 0 || n_crop_words < 0 || (n_cc > 0 && (!h_rec || !h_crop_off || !h_crop)) || !h_frame_off ||
+        n_matched < 0 || n_matched > n_frames) {
         lm_set_error("lm_stream_import: bad arguments");
         return LM_ERR_ARG;
     }
@@ -572,7 +604,7 @@ extern "C" int lm_stream_import(LmStream* s, const int32_t* h_rec, const int64_t
     LmCounters h;
     memset(&h, 0, sizeof(h));
     h.n_cc = n_cc; h.n_words = (unsigned long long)n_crop_words; h.tempo_count = (unsigned long long)tempo_count;
-    h.n_frames = n_frames; h.n_matched = n_frames; h.n_uniq = n_unique; h.n_active = 0;
+    h.n_frames = n_frames; h.n_matched = n_matched; h.n_uniq = n_unique; h.n_active = 0;
     if (n_active > 0 && h_active && h_active_cc && h_active_last) {
         if (n_active > s->cap_uniq) { lm_set_error("lm_stream_import: active list larger than max_uniques"); return LM_ERR_CAPACITY; }
         LM_HIP(hipMemcpyAsync(s->active, h_active, (size_t)n_active * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -584,6 +616,7 @@ extern "C" int lm_stream_import(LmStream* s, const int32_t* h_rec, const int64_t
     LM_HIP(hipMemcpyAsync(s->counters, &h, sizeof(h), hipMemcpyHostToDevice, st));
     LM_HIP(hipStreamSynchronize(st));
     s->frames_pushed = n_frames;
+    s->frames_matched = n_matched;
     return LM_OK;
 }
 

@@ -53,5 +53,6 @@ struct LmStream {
     LmCounters* counters;       // device
     long long* batch_cc_base;   // [max_batch] staging for emit
     unsigned long long* batch_word_base;
-    int frames_pushed;          // host-side mirror (frames are pushed in order)
+    int frames_pushed;          // host-side mirrors (frames are pushed and matched in order)
+    int frames_matched;
 };

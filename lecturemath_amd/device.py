@@ -156,6 +156,15 @@ class FrameStream:
         self.lib.check(self.lib.lm_stream_push(self.handle, _lib.ptr(binary), int(binary.shape[0]), _lib.ptr(labels_out),
                                                self.be.stream()))
 
+    def push_records(self, binary, labels_out=None):
+        """Per-frame half only (label, stats, records, crops): no temporal matching."""
+        self.lib.check(self.lib.lm_stream_push_records(self.handle, _lib.ptr(binary), int(binary.shape[0]), _lib.ptr(labels_out),
+                                                       self.be.stream()))
+
+    def match(self, n_frames):
+        """Sequential temporal matching over the next n_frames unmatched frames."""
+        self.lib.check(self.lib.lm_stream_match(self.handle, int(n_frames), self.be.stream()))
+
     def counters(self):
         k = np.zeros(7, np.int64)
         self.lib.check(self.lib.lm_stream_counters(self.handle, k.ctypes.data, self.be.stream()))
@@ -203,7 +212,8 @@ class FrameStream:
             self.handle, rec.ctypes.data if len(rec) else None, foff.ctypes.data, coff.ctypes.data if len(rec) else None,
             crop.ctypes.data if len(crop) else (np.zeros(1, np.uint32).ctypes.data if len(rec) else None), len(foff) - 1, len(rec),
             len(crop), int(st["n_unique"]), int(st["tempo_count"]), act.ctypes.data if len(act) else None,
-            acc.ctypes.data if len(act) else None, acl.ctypes.data if len(act) else None, len(act), self.be.stream()))
+            acc.ctypes.data if len(act) else None, acl.ctypes.data if len(act) else None, len(act),
+            int(st.get("n_matched", len(foff) - 1)), self.be.stream()))
 
     def result(self, with_crops=True):
         """Same plain-data view the oracle produces (reference attribute names):

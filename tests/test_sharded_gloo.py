@@ -1,0 +1,70 @@
+"""CPU, world_size 2, gloo: frame-range sharding of one stream gives exactly the single-process result, and the FCN weight
+broadcast delivers identical tensors (the N > 1 path; on the GPU box the same code runs over RCCL)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, emu_path, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lecturemath_amd import _lib, device, sharded, synth
+    import lm_checks
+    from oracle import cc as occ
+    from oracle import fcn as ofcn
+    lib = _lib.load(emu_path)
+    frames = np.stack(list(synth.binary_stream(21, 96, 160, seed=8, glyphs_per_add=4, erase_every=8, jitter_p=0.4, occluder=True,
+                                               max_ext=16)))
+    f0, f1 = sharded.frame_range(len(frames), rank, world)
+    fs = sharded.run_stream_sharded(frames[f0:f1], len(frames), 160, 96, max_gap=5, max_batch=4, lib=lib)
+    sd = ofcn.random_state_dict((8,) * 18, pixel_kernel=3, seed=3) if rank == 0 else None
+    got = sharded.broadcast_state_dict(sd, src=0)
+    ref = ofcn.random_state_dict((8,) * 18, pixel_kernel=3, seed=3)
+    assert all(torch.equal(got[k], ref[k]) for k in ref) and len(got) == len(ref)
+    if rank == 0:
+        o = occ.Stability(160, 96, 0.85, 0.85, 5)
+        for f in frames:
+            o.add_frame(f)
+        lm_checks.state_equal_oracle(fs.result(), o.result())
+        # grouping on the gathered stream equals grouping on a single-process stream
+        single = device.FrameStream(160, 96, len(frames), 0.85, 0.85, 5, 20, max_batch=4, lib=lib)
+        single.push(frames)
+        a = device.Grouping(fs, max_gap=5).result()
+        b = device.Grouping(single, max_gap=5).result()
+        assert a["cc_groups"] == b["cc_groups"] and a["group_ages"] == b["group_ages"]
+        assert all((x == y).all() for x, y in zip(a["clean_binary"], b["clean_binary"]))
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    else:
+        assert fs is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_range():
+    from lecturemath_amd import sharded
+    assert [sharded.frame_range(10000, r, 8) for r in (0, 7)] == [(0, 1250), (8750, 10000)]
+    assert [sharded.frame_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert sharded.frame_range(2, 3, 4) == (2, 2)
+
+
+def test_sharded_stream_two_ranks(emu_lib, oracle_built, tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), emu_lib.path, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
