@@ -4,6 +4,7 @@
 #include "lm_stream.h"
 
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -28,6 +29,14 @@ void lm_set_error(const char* fmt, ...)
 extern "C" const char* lm_last_error(void) { return g_err; }
 extern "C" int lm_abi_version(void) { return 1; }
 extern "C" int lm_is_device_build(void) { return LM_HIP_EMULATED ? 0 : 1; }
+
+// LM_DEBUG_BAND_PHASES=2 makes lm_k_band leave every band's unions to lm_k_band_union_global (results unchanged); default 3
+static int lm_debug_band_phases()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LM_DEBUG_BAND_PHASES"); v = e ? atoi(e) : 3; if (v < 2 || v > 3) v = 3; }
+    return v;
+}
 
 static inline unsigned lm_blocks(long long work_items, int block, int max_blocks = 8192)
 {
@@ -117,7 +126,7 @@ extern "C" void lm_ctx_destroy(LmCtx* c)
 {
     if (!c) return;
     lm_profile_free(c);
-    void* ptrs[] = {c->bits, c->starts, c->prefix, c->row_runs, c->rowoff, c->frame_runs, c->parent, c->final_label,
+    void* ptrs[] = {c->bits, c->starts, c->prefix, c->rowoff, c->band_runs, c->band_base, c->band_fallback, c->parent, c->final_label,
                     c->n_labels, c->rootbits, c->wordprefix, c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x, c->st_count, c->kept_label,
                     c->kept_cropoff, c->frame_kept, c->frame_cropwords, c->stage_u8, c->stage_i32, c->stage_f32};
     for (void* p : ptrs)
@@ -137,7 +146,9 @@ extern "C" LmCtx* lm_ctx_create(int width, int height, int max_batch)
     c->g.W = width;
     c->g.H = height;
     c->g.WW = (width + 63) / 64;
-    c->g.cap = height * ((width + 1) / 2);
+    c->nbands = (height + LM_BAND_ROWS - 1) / LM_BAND_ROWS;
+    c->slot = ((LM_BAND_ROWS * ((width + 1) / 2)) + 63) & ~63;       // worst-case runs of one band, multiple of 64
+    c->g.cap = c->nbands * c->slot;
     c->max_batch = max_batch;
     (void)hipGetDevice(&c->device);
     const size_t R = (size_t)max_batch * height, RW = R * c->g.WW, BC = (size_t)max_batch * c->g.cap;
@@ -145,14 +156,15 @@ extern "C" LmCtx* lm_ctx_create(int width, int height, int max_batch)
     rc |= lm_alloc(&c->bits, RW);
     rc |= lm_alloc(&c->starts, RW);
     rc |= lm_alloc(&c->prefix, RW);
-    rc |= lm_alloc(&c->row_runs, R);
     rc |= lm_alloc(&c->rowoff, R);
-    rc |= lm_alloc(&c->frame_runs, (size_t)max_batch);
+    rc |= lm_alloc(&c->band_runs, (size_t)max_batch * c->nbands);
+    rc |= lm_alloc(&c->band_base, (size_t)max_batch * c->nbands);
+    rc |= lm_alloc(&c->band_fallback, (size_t)max_batch * c->nbands);
     rc |= lm_alloc(&c->parent, BC);
     rc |= lm_alloc(&c->final_label, BC);
     rc |= lm_alloc(&c->n_labels, (size_t)max_batch);
-    rc |= lm_alloc(&c->rootbits, (size_t)max_batch * ((c->g.cap + 63) / 64));
-    rc |= lm_alloc(&c->wordprefix, (size_t)max_batch * ((c->g.cap + 63) / 64));
+    rc |= lm_alloc(&c->rootbits, (size_t)max_batch * (c->g.cap / 64));
+    rc |= lm_alloc(&c->wordprefix, (size_t)max_batch * (c->g.cap / 64));
     rc |= lm_alloc(&c->st_min_y, BC);
     rc |= lm_alloc(&c->st_max_y, BC);
     rc |= lm_alloc(&c->st_min_x, BC);
@@ -198,29 +210,39 @@ extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, i
     }
     const LmGeom g = c->g;
     hipStream_t st = (hipStream_t)stream;
-    const long long nrows = (long long)n_frames * g.H;
-    const int chunks = g.WW * 4;
     if (lm_profile_mark(c, st, true, n_frames)) return LM_ERR_HIP;
-    hipLaunchKernelGGL(lm_k_pack, dim3(lm_blocks(nrows * chunks, 256)), dim3(256), 0, st, d_binary, (uint16_t*)c->bits, g.W,
-                       nrows, chunks);
-    hipLaunchKernelGGL(lm_k_rowscan, dim3(lm_blocks(nrows * 64, 256)), dim3(256), 0, st, c->bits, c->starts, c->prefix,
-                       c->row_runs, g.WW, nrows);
-    hipLaunchKernelGGL(lm_k_frame_rowoff, dim3(n_frames), dim3(1024), 0, st, c->row_runs, c->rowoff, c->frame_runs, g.H);
-    const int nbands = (g.H + LM_BAND_ROWS - 1) / LM_BAND_ROWS;
-    const int capw = (g.cap + 63) / 64;
-    hipLaunchKernelGGL(lm_k_band_union, dim3(nbands, n_frames), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff,
-                       c->frame_runs, c->parent, g.WW, g.H, g.cap);
+    const int nbands = c->nbands, slot = c->slot;
+    const int capw = g.cap / 64;
+    const size_t band_smem = (size_t)LM_BAND_ROWS * g.WW * 18 + LM_BAND_LDS * 4 + (65 + 64) * 4 + 64;
+#if !LM_HIP_EMULATED
+    static size_t band_smem_configured = 0;
+    if (band_smem > band_smem_configured) {
+        LM_HIP(hipFuncSetAttribute((const void*)lm_k_band, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_smem));
+        band_smem_configured = band_smem;
+    }
+#endif
+    hipLaunchKernelGGL(lm_k_band, dim3(nbands, n_frames), dim3(512), band_smem, st, d_binary, c->bits, c->starts, c->prefix, c->rowoff,
+                       c->band_runs, c->parent, c->band_fallback, g.W, g.H, g.WW, slot, g.cap, lm_debug_band_phases());
+    hipLaunchKernelGGL(lm_k_band_union_global, dim3(nbands, n_frames), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff,
+                       c->band_fallback, c->parent, g.WW, g.H, g.cap);
     if (nbands > 1)
         hipLaunchKernelGGL(lm_k_seam_union, dim3(lm_blocks((long long)n_frames * (nbands - 1) * g.WW, 256)), dim3(256), 0, st,
                            c->bits, c->starts, c->prefix, c->rowoff, c->parent, g.WW, g.H, g.cap, nbands - 1, n_frames);
-    hipLaunchKernelGGL(lm_k_flatten_flag, dim3(32, n_frames), dim3(256), 0, st, c->parent, c->frame_runs, c->rootbits, g.cap, capw);
-    hipLaunchKernelGGL(lm_k_rank, dim3(n_frames), dim3(1024), 0, st, c->rootbits, c->frame_runs, c->wordprefix, c->n_labels, capw);
-    hipLaunchKernelGGL(lm_k_apply_labels, dim3(32, n_frames), dim3(256), 0, st, c->parent, c->frame_runs, c->rootbits,
-                       c->wordprefix, c->final_label, g.cap, capw);
+    hipLaunchKernelGGL(lm_k_flatten_flag, dim3(nbands, n_frames), dim3(256), 0, st, c->parent, c->band_runs, c->rootbits, slot, g.cap, capw);
+    hipLaunchKernelGGL(lm_k_rank, dim3(n_frames), dim3(1024), 0, st, c->rootbits, c->band_runs, c->wordprefix, c->band_base, c->n_labels,
+                       nbands, slot, capw);
+    hipLaunchKernelGGL(lm_k_apply_labels, dim3(nbands, n_frames), dim3(256), 0, st, c->parent, c->band_runs, c->rootbits, c->wordprefix,
+                       c->band_base, c->final_label, slot, g.cap, capw);
     if (d_labels) {
-        const long long quads = nrows * ((g.W + 3) / 4);
-        hipLaunchKernelGGL(lm_k_write_labels, dim3(lm_blocks(quads, 256)), dim3(256), 0, st, c->bits, c->starts, c->prefix,
-                           c->rowoff, c->final_label, d_labels, g.W, g.H, g.WW, g.cap, nrows);
+        const unsigned Q = (unsigned)(g.W + 3) / 4;
+        const unsigned long long magic_q = ((1ull << 40) / Q) + 1;       // lm_fastdiv: exact for H * Q < 2^24
+        const long long quads = (long long)g.H * Q;
+        if (quads >= (1ll << 24)) { lm_set_error("lm_label_batch: frame too large for the label writer (H*W/4 must be < 2^24)"); return LM_ERR_ARG; }
+        unsigned gx = (unsigned)((quads + 256 * LM_WL_Q - 1) / (256 * LM_WL_Q));
+        const unsigned cap_x = 8192u / (unsigned)n_frames + 1u;
+        if (gx > cap_x) gx = cap_x;
+        hipLaunchKernelGGL(lm_k_write_labels, dim3(gx, n_frames), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff,
+                           c->final_label, d_labels, g.W, g.H, g.WW, g.cap, magic_q);
     }
     if (lm_profile_mark(c, st, false, n_frames)) return LM_ERR_HIP;
     LM_HIP(hipGetLastError());

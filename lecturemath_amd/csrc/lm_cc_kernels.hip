@@ -14,6 +14,13 @@
 // roofline.  No provisional label image ever touches HBM.
 #include "lm_common.h"
 
+#if LM_HIP_EMULATED
+extern char lm_emu_dynsmem[];
+#define LM_DYN_SMEM(name) char* name = lm_emu_dynsmem
+#else
+#define LM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // K0: fp32 logits -> inverted binary uint8 {0,255}
 // binary = ((uint8)(sigmoid(x) * 255.0f) >= thr) ? 255 : 0 ; out = 255 - binary
@@ -50,7 +57,7 @@ __global__ void __launch_bounds__(256) lm_k_threshold_invert(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: uint8 image -> bit mask. One thread per 16-pixel chunk (one 16-B load -> one 2-B store).
+// K1 helper: non-zero bytes of a dword -> 4 bits (the bit packing itself is fused into lm_k_band)
 // ------------------------------------------------------------------------------------------------
 LM_DEV unsigned lm_nz_nibble(unsigned d)
 {
@@ -62,93 +69,15 @@ LM_DEV unsigned lm_nz_nibble(unsigned d)
     return (d * 0x01020408u) >> 24 & 0xFu;
 }
 
-__global__ void __launch_bounds__(256) lm_k_pack(const uint8_t* __restrict__ img, uint16_t* __restrict__ bits16,
-                                                 int W, long long nrows, int chunks_per_row)
-{
-    long long total = nrows * chunks_per_row;
-    long long stride = (long long)gridDim.x * blockDim.x;
-    const bool rows_aligned = ((W & 15) == 0) && ((((uintptr_t)img) & 15) == 0);
-    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += stride) {
-        long long row = gid / chunks_per_row;
-        int ch = (int)(gid - row * chunks_per_row);
-        int x = ch * 16;
-        unsigned m = 0;
-        if (x < W) {
-            const uint8_t* p = img + row * W + x;
-            if (rows_aligned) {   // x + 16 <= W is implied by W % 16 == 0
-                uint4 v = *(const uint4*)p;
-                m = lm_nz_nibble(v.x) | (lm_nz_nibble(v.y) << 4) | (lm_nz_nibble(v.z) << 8) | (lm_nz_nibble(v.w) << 12);
-            } else {
-                int lim = W - x < 16 ? W - x : 16;
-                for (int i = 0; i < lim; i++) m |= (unsigned)(p[i] != 0) << i;
-            }
-        }
-        bits16[gid] = (uint16_t)m;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K2: per row: run-start masks, per-word exclusive prefix of run-start counts, runs per row.
-// One wave per row (lanes = 64-bit words).
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) lm_k_rowscan(const uint64_t* __restrict__ bits, uint64_t* __restrict__ starts,
-                                                    uint16_t* __restrict__ prefix, uint32_t* __restrict__ row_runs,
-                                                    int WW, long long nrows)
-{
-    const int lane = lm_lane();
-    long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-    for (long long row = wave; row < nrows; row += nwaves) {
-        unsigned running = 0;
-        unsigned long long carry = 0;
-        for (int w0 = 0; w0 < WW; w0 += 64) {
-            int w = w0 + lane;
-            unsigned long long b = (w < WW) ? bits[row * WW + w] : 0ull;
-            unsigned long long prevtop = __shfl_up(b >> 63, 1);
-            if (lane == 0) prevtop = carry;
-            unsigned long long s = b & ~((b << 1) | prevtop);
-            unsigned c = (unsigned)__popcll(s);
-            unsigned incl = lm_wave_incl_scan(c);
-            if (w < WW) {
-                starts[row * WW + w] = s;
-                prefix[row * WW + w] = (uint16_t)(running + incl - c);
-            }
-            carry = __shfl(b >> 63, 63);
-            running += __shfl(incl, 63);
-        }
-        if (lane == 0) row_runs[row] = running;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K3: per frame: exclusive scan of runs-per-row -> rowoff (frame-relative), frame_runs.
-// One block per frame.
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) lm_k_frame_rowoff(const uint32_t* __restrict__ row_runs,
-                                                          uint32_t* __restrict__ rowoff, int32_t* __restrict__ frame_runs, int H)
-{
-    const int b = blockIdx.x;
-    unsigned carry = 0;
-    for (int base = 0; base < H; base += 1024) {
-        int r = base + (int)threadIdx.x;
-        unsigned v = (r < H) ? row_runs[(long long)b * H + r] : 0u;
-        unsigned tot;
-        unsigned ex = lm_block_excl_scan<1024>(v, &tot);
-        if (r < H) rowoff[(long long)b * H + r] = carry + ex;
-        carry += tot;
-    }
-    if (threadIdx.x == 0) frame_runs[b] = (int32_t)carry;
-}
-
 // ------------------------------------------------------------------------------------------------
 // K4: union-find over runs, two levels.
-//   K4a  one workgroup per band of LM_BAND_ROWS rows: the band's forest lives in LDS (ds atomics),
-//        is flattened there and written out as global parents (band-local roots).
+//   K4a  lm_k_band: one workgroup per band of LM_BAND_ROWS rows packs the band, scans its rows and keeps the band's
+//        forest in LDS (ds atomics); the flattened band-local roots are written out as global parents.
 //   K4b  seam rows between bands: the few remaining contacts, with device-scope atomics in L2.
 // Root of a set = its smallest run id, so roots are the runs holding each component's first pixel.
 // ------------------------------------------------------------------------------------------------
-#define LM_BAND_ROWS 64
-#define LM_BAND_LDS 8192
+#define LM_BAND_ROWS 32
+#define LM_BAND_LDS 4096
 
 LM_DEV int lm_find(const int32_t* parent, int x)
 {
@@ -200,40 +129,164 @@ LM_DEV void lm_cell_contacts(const uint64_t* __restrict__ bits, const uint64_t* 
     }
 }
 
-__global__ void __launch_bounds__(256) lm_k_band_union(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
-                                                       const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
-                                                       const int32_t* __restrict__ frame_runs, int32_t* __restrict__ parent,
-                                                       int WW, int H, int cap)
+// K4a, fused: uint8 rows of one band -> bit mask (1 B/px HBM read, the only pass over the image), run starts / prefix,
+// band-local run offsets, and the band's union-find forest in LDS.  Run ids are band-structured:
+//     gid = band * SLOT + (runs of the band before the run)          SLOT = worst-case runs of a band
+// which is still monotone in raster order, so no frame-wide scan is needed before the unions; `rowoff[row]` stores
+// band * SLOT + local offset, which is all the later kernels need.
+__global__ void __launch_bounds__(512) lm_k_band(const uint8_t* __restrict__ img, uint64_t* __restrict__ bits, uint64_t* __restrict__ starts,
+                                                 uint16_t* __restrict__ prefix, uint32_t* __restrict__ rowoff,
+                                                 int32_t* __restrict__ band_runs, int32_t* __restrict__ parent,
+                                                 uint8_t* __restrict__ band_fallback, int W, int H, int WW, int slot, int cap, int phases)
 {
-    __shared__ int32_t s_par[LM_BAND_LDS];
-    const int b = blockIdx.y;
-    const int y0 = blockIdx.x * LM_BAND_ROWS;
+    LM_DYN_SMEM(smem);
+    const int b = blockIdx.y, band = blockIdx.x, nbands = gridDim.x;
+    const int y0 = band * LM_BAND_ROWS;
+    const int nrows = (y0 + LM_BAND_ROWS < H) ? LM_BAND_ROWS : H - y0;
+    const long long row0 = (long long)b * H + y0;
+    unsigned long long* s_bits = (unsigned long long*)smem;                   // [64][WW]
+    unsigned long long* s_starts = s_bits + LM_BAND_ROWS * WW;                // [64][WW]
+    int32_t* s_par = (int32_t*)(s_starts + LM_BAND_ROWS * WW);                // [LM_BAND_LDS]
+    unsigned* s_rowoff = (unsigned*)(s_par + LM_BAND_LDS);                    // [65]
+    unsigned* s_rowcnt = s_rowoff + 65;                                       // [64]
+    uint16_t* s_prefix = (uint16_t*)(s_rowcnt + 64);                          // [64][WW]
+    const int lane = lm_lane(), wave = (int)(threadIdx.x >> 6);
+    // ---- 1. pack: one 16-B load per 16 pixels
+    {
+        const int cpr = WW * 4;
+        const bool rows_aligned = ((W & 15) == 0) && ((((uintptr_t)img) & 15) == 0);
+        uint16_t* s_bits16 = (uint16_t*)s_bits;
+        uint16_t* g_bits16 = (uint16_t*)bits;
+        const int total = nrows * cpr;
+        if (rows_aligned) {
+            // batches of 8 independent 16-B loads per thread keep enough bytes in flight at 1-2 blocks per CU
+            for (int c0 = threadIdx.x; c0 < total; c0 += (int)blockDim.x * 8) {
+                uint4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int c = c0 + k * (int)blockDim.x;
+                    v[k] = make_uint4(0u, 0u, 0u, 0u);
+                    if (c < total) {
+                        const int r = c / cpr, ch = c - r * cpr;
+                        if (ch * 16 < W) v[k] = *(const uint4*)(img + (row0 + r) * W + ch * 16);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int c = c0 + k * (int)blockDim.x;
+                    if (c < total) {
+                        const int r = c / cpr, ch = c - r * cpr;
+                        const unsigned m = lm_nz_nibble(v[k].x) | (lm_nz_nibble(v[k].y) << 4) | (lm_nz_nibble(v[k].z) << 8) | (lm_nz_nibble(v[k].w) << 12);
+                        s_bits16[c] = (uint16_t)m;
+                        g_bits16[(row0 + r) * cpr + ch] = (uint16_t)m;
+                    }
+                }
+            }
+        } else {
+            for (int c = threadIdx.x; c < total; c += blockDim.x) {
+                const int r = c / cpr, ch = c - r * cpr, x = ch * 16;
+                unsigned m = 0;
+                if (x < W) {
+                    const uint8_t* p = img + (row0 + r) * W + x;
+                    int lim = W - x < 16 ? W - x : 16;
+                    for (int i = 0; i < lim; i++) m |= (unsigned)(p[i] != 0) << i;
+                }
+                s_bits16[c] = (uint16_t)m;
+                g_bits16[(row0 + r) * cpr + ch] = (uint16_t)m;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 2. per row: run starts, exclusive prefix of run-start counts, runs per row (one wave per row)
+    for (int r = wave; r < nrows; r += (int)(blockDim.x >> 6)) {
+        unsigned running = 0;
+        unsigned long long carry = 0;
+        for (int w0 = 0; w0 < WW; w0 += 64) {
+            const int w = w0 + lane;
+            unsigned long long bw = (w < WW) ? s_bits[r * WW + w] : 0ull;
+            unsigned long long prevtop = __shfl_up(bw >> 63, 1);
+            if (lane == 0) prevtop = carry;
+            const unsigned long long st = bw & ~((bw << 1) | prevtop);
+            const unsigned c = (unsigned)__popcll(st);
+            const unsigned incl = lm_wave_incl_scan(c);
+            if (w < WW) {
+                s_starts[r * WW + w] = st;
+                s_prefix[r * WW + w] = (uint16_t)(running + incl - c);
+                starts[(row0 + r) * WW + w] = st;
+                prefix[(row0 + r) * WW + w] = (uint16_t)(running + incl - c);
+            }
+            carry = __shfl(bw >> 63, 63);
+            running += __shfl(incl, 63);
+        }
+        if (lane == 0) s_rowcnt[r] = running;
+    }
+    __syncthreads();
+    // ---- 3. band-local row offsets
+    if (wave == 0) {
+        const unsigned v = (lane < nrows) ? s_rowcnt[lane] : 0u;
+        const unsigned incl = lm_wave_incl_scan(v);
+        if (lane < nrows) {
+            s_rowoff[lane] = incl - v;
+            rowoff[row0 + lane] = (unsigned)(band * slot) + incl - v;
+        }
+        if (lane == 63) s_rowoff[64] = incl;
+    }
+    __syncthreads();
+    const int n = (int)s_rowoff[64];
+    int32_t* par_g = parent + (long long)b * cap + (long long)band * slot;
+    if (threadIdx.x == 0) {
+        band_runs[b * nbands + band] = n;
+        band_fallback[b * nbands + band] = (n > LM_BAND_LDS) ? 1 : 0;
+    }
+    if (n == 0) return;
+    if (n > LM_BAND_LDS || phases == 2) {      // too many runs for the LDS forest (phases == 2: profiling aid, unions left to L2): identity parents, lm_k_band_union_global does the unions
+        for (int i = threadIdx.x; i < n; i += blockDim.x) par_g[i] = band * slot + i;
+        return;
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s_par[i] = i;
+    __syncthreads();
+    // ---- 4. unions between vertically adjacent runs, all from LDS (per cell: every distinct (run, upper run) contact).
+    // Measured alternatives that were slower on MI355X (profiles/r01_label_experiments.md): run-centric parent stores +
+    // barrier-separated pointer jumping + atomics only for merges (112 vs 76 us per 32 frames).
+    for (int cell = threadIdx.x; cell < (nrows - 1) * WW; cell += blockDim.x) {
+        const int r = 1 + cell / WW, w = cell - (r - 1) * WW;
+        const unsigned long long cur = s_bits[r * WW + w];
+        if (!cur) continue;
+        const unsigned long long v = cur & s_bits[(r - 1) * WW + w];
+        if (!v) continue;
+        unsigned long long carry = 0;
+        if (w > 0) carry = (s_bits[r * WW + w - 1] & s_bits[(r - 1) * WW + w - 1]) >> 63;
+        unsigned long long ps = v & ~((v << 1) | carry);
+        const unsigned long long s_cur = s_starts[r * WW + w], s_up = s_starts[(r - 1) * WW + w];
+        const int base_cur = (int)s_rowoff[r] + (int)s_prefix[r * WW + w] - 1;
+        const int base_up = (int)s_rowoff[r - 1] + (int)s_prefix[(r - 1) * WW + w] - 1;
+        while (ps) {
+            const int p = __ffsll((long long)ps) - 1;
+            ps &= ps - 1;
+            const unsigned long long m = lm_lowmask_incl(p);
+            lm_union(s_par, base_cur + __popcll(s_cur & m), base_up + __popcll(s_up & m));
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) par_g[i] = band * slot + lm_find(s_par, i);
+}
+
+// K4a': bands whose forest did not fit the LDS (very dense frames): the same unions with device-scope atomics.
+__global__ void __launch_bounds__(256) lm_k_band_union_global(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
+                                                              const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
+                                                              const uint8_t* __restrict__ band_fallback, int32_t* __restrict__ parent,
+                                                              int WW, int H, int cap)
+{
+    const int b = blockIdx.y, band = blockIdx.x;
+    if (!band_fallback[b * gridDim.x + band]) return;
+    const int y0 = band * LM_BAND_ROWS;
     const int y1 = (y0 + LM_BAND_ROWS < H) ? y0 + LM_BAND_ROWS : H;
     const long long row0 = (long long)b * H + y0;
-    const int base = (int)rowoff[row0];
-    const int end = (y1 < H) ? (int)rowoff[(long long)b * H + y1] : frame_runs[b];
-    const int n = end - base;
-    if (n <= 0) return;
-    int32_t* par_g = parent + (long long)b * cap;
-    const bool lds = n <= LM_BAND_LDS;          // block-uniform
-    if (lds) {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) s_par[i] = i;
-    } else {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) par_g[base + i] = base + i;
+    int32_t* par = parent + (long long)b * cap;
+    for (int cell = threadIdx.x; cell < (y1 - y0 - 1) * WW; cell += blockDim.x) {
+        const int r = cell / WW, w = cell - r * WW;
+        lm_cell_contacts(bits, starts, prefix, rowoff, row0 + 1 + r, w, WW, [&](int a, int c) { lm_union(par, a, c); });
     }
-    __syncthreads();
-    const int cells = (y1 - y0 - 1) * WW;
-    for (int cell = threadIdx.x; cell < cells; cell += blockDim.x) {
-        int r = cell / WW, w = cell - r * WW;
-        long long row = row0 + 1 + r;
-        if (lds)
-            lm_cell_contacts(bits, starts, prefix, rowoff, row, w, WW, [&](int a, int c) { lm_union(s_par, a - base, c - base); });
-        else
-            lm_cell_contacts(bits, starts, prefix, rowoff, row, w, WW, [&](int a, int c) { lm_union(par_g, a, c); });
-    }
-    if (!lds) return;
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) par_g[base + i] = base + lm_find(s_par, i);
 }
 
 __global__ void __launch_bounds__(256) lm_k_seam_union(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
@@ -260,106 +313,166 @@ __global__ void __launch_bounds__(256) lm_k_seam_union(const uint64_t* __restric
 //   K5b  per frame: exclusive scan of the root-mask popcounts                  one block per frame
 //   K5c  final[i] = rank(root(i)) + 1                                          grid (x, B)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) lm_k_flatten_flag(int32_t* __restrict__ parent, const int32_t* __restrict__ frame_runs,
-                                                         unsigned long long* __restrict__ rootbits, int cap, int capw)
+__global__ void __launch_bounds__(256) lm_k_flatten_flag(int32_t* __restrict__ parent, const int32_t* __restrict__ band_runs,
+                                                         unsigned long long* __restrict__ rootbits, int slot, int cap, int capw)
 {
-    const int b = blockIdx.y;
-    const int n = frame_runs[b];
+    const int b = blockIdx.y, band = blockIdx.x;
+    const int n = band_runs[b * gridDim.x + band];
     int32_t* par = parent + (long long)b * cap;
-    unsigned long long* rb = rootbits + (long long)b * capw;
+    unsigned long long* rb = rootbits + (long long)b * capw + (band * slot >> 6);
     const int lane = lm_lane();
-    for (int base = (int)(blockIdx.x * blockDim.x + (threadIdx.x & ~63u)); base < n; base += (int)(gridDim.x * blockDim.x)) {
-        int i = base + lane;
+    for (int base = (int)(threadIdx.x & ~63u); base < n; base += (int)blockDim.x) {
+        const int i = base + lane;
         bool flag = false;
         if (i < n) {
-            int r = lm_find(par, i);
-            par[i] = r;
-            flag = (r == i);
+            const int gid = band * slot + i;
+            const int r = lm_find(par, gid);
+            par[gid] = r;
+            flag = (r == gid);
         }
-        unsigned long long m = __ballot(flag);
+        const unsigned long long m = __ballot(flag);
         if (lane == 0) rb[base >> 6] = m;
     }
 }
 
-__global__ void __launch_bounds__(1024) lm_k_rank(const unsigned long long* __restrict__ rootbits, const int32_t* __restrict__ frame_runs,
-                                                  uint32_t* __restrict__ wordprefix, int32_t* __restrict__ n_labels, int capw)
+// per frame: roots before every 64-run word (band-relative) and roots before every band; n_labels.  One block per frame.
+__global__ void __launch_bounds__(1024) lm_k_rank(const unsigned long long* __restrict__ rootbits, const int32_t* __restrict__ band_runs,
+                                                  uint32_t* __restrict__ wordprefix, uint32_t* __restrict__ band_base,
+                                                  int32_t* __restrict__ n_labels, int nbands, int slot, int capw)
 {
+    __shared__ unsigned s_tot[1024];       // roots per band (nbands <= 1024: frames up to 65536 rows)
     const int b = blockIdx.x;
-    const int nw = (frame_runs[b] + 63) >> 6;
-    const unsigned long long* rb = rootbits + (long long)b * capw;
-    uint32_t* wp = wordprefix + (long long)b * capw;
+    const int lane = lm_lane(), wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6);
+    for (int band = wave; band < nbands; band += nwaves) {
+        const int nw = (band_runs[b * nbands + band] + 63) >> 6;
+        const unsigned long long* rb = rootbits + (long long)b * capw + (band * slot >> 6);
+        uint32_t* wp = wordprefix + (long long)b * capw + (band * slot >> 6);
+        unsigned running = 0;
+        for (int w0 = 0; w0 < nw; w0 += 64) {
+            const int j = w0 + lane;
+            const unsigned v = (j < nw) ? (unsigned)__popcll(rb[j]) : 0u;
+            const unsigned incl = lm_wave_incl_scan(v);
+            if (j < nw) wp[j] = running + incl - v;
+            running += __shfl(incl, 63);
+        }
+        if (lane == 0) s_tot[band] = running;
+    }
+    __syncthreads();
     unsigned carry = 0;
-    for (int base = 0; base < nw; base += 1024) {
-        int j = base + (int)threadIdx.x;
-        unsigned v = (j < nw) ? (unsigned)__popcll(rb[j]) : 0u;
+    for (int base = 0; base < nbands; base += 1024) {
+        const int j = base + (int)threadIdx.x;
+        const unsigned v = (j < nbands) ? s_tot[j] : 0u;
         unsigned tot;
-        unsigned ex = lm_block_excl_scan<1024>(v, &tot);
-        if (j < nw) wp[j] = carry + ex;
+        const unsigned ex = lm_block_excl_scan<1024>(v, &tot);
+        if (j < nbands) band_base[b * nbands + j] = carry + ex;
         carry += tot;
     }
     if (threadIdx.x == 0) n_labels[b] = (int32_t)carry;
 }
 
-__global__ void __launch_bounds__(256) lm_k_apply_labels(const int32_t* __restrict__ parent, const int32_t* __restrict__ frame_runs,
+__global__ void __launch_bounds__(256) lm_k_apply_labels(const int32_t* __restrict__ parent, const int32_t* __restrict__ band_runs,
                                                          const unsigned long long* __restrict__ rootbits,
-                                                         const uint32_t* __restrict__ wordprefix, int32_t* __restrict__ final_label,
-                                                         int cap, int capw)
+                                                         const uint32_t* __restrict__ wordprefix, const uint32_t* __restrict__ band_base,
+                                                         int32_t* __restrict__ final_label, int slot, int cap, int capw)
 {
-    const int b = blockIdx.y;
-    const int n = frame_runs[b];
+    const int b = blockIdx.y, band = blockIdx.x, nbands = gridDim.x;
+    const int n = band_runs[b * nbands + band];
     const int32_t* par = parent + (long long)b * cap;
     const unsigned long long* rb = rootbits + (long long)b * capw;
     const uint32_t* wp = wordprefix + (long long)b * capw;
+    const uint32_t* bb = band_base + b * nbands;
     int32_t* fin = final_label + (long long)b * cap;
-    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x)) {
-        int r = par[i];
-        fin[i] = (int32_t)(wp[r >> 6] + (unsigned)__popcll(rb[r >> 6] & lm_lowmask_excl(r & 63)) + 1u);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int gid = band * slot + i;
+        const int r = par[gid];
+        fin[gid] = (int32_t)(bb[r / slot] + wp[r >> 6] + (unsigned)__popcll(rb[r >> 6] & lm_lowmask_excl(r & 63)) + 1u);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K6: write the int32 label image. One thread per 4 pixels (one 16-B store).
+// K6: write the int32 label image (4 B/px, the only HBM write of the labelling).  One thread handles LM_WL_Q quads
+// of 4 pixels, quad = base + k*64 + lane, so every store instruction of a wave covers a contiguous 1 KiB while the
+// (dependent) run-table lookups of the LM_WL_Q quads are independent of each other and issued phase by phase.
 // ------------------------------------------------------------------------------------------------
+#define LM_WL_Q 4
+
+// n / d for n < 2^24, d < 2^16 with one 64-bit multiply: m = floor(2^40 / d) + 1 (host), q = (n * m) >> 40.
+// (A plain 64-bit '/' is a ~200-instruction software routine on the GPU and made this kernel VALU bound.)
+LM_DEV unsigned lm_fastdiv(unsigned n, unsigned long long m) { return (unsigned)(((unsigned long long)n * m) >> 40); }
+
 __global__ void __launch_bounds__(256) lm_k_write_labels(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
                                                          const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
                                                          const int32_t* __restrict__ final_label, int32_t* __restrict__ labels,
-                                                         int W, int H, int WW, int cap, long long nrows)
+                                                         int W, int H, int WW, int cap, unsigned long long magic_q)
 {
-    const int Q = (W + 3) >> 2;
-    long long total = nrows * Q;
-    long long stride = (long long)gridDim.x * blockDim.x;
+    const unsigned Q = (unsigned)(W + 3) >> 2;
+    const unsigned total = (unsigned)H * Q;                 // quads of one frame (grid.y = frame)
+    const int b = blockIdx.y;
     const bool vec = ((W & 3) == 0) && ((((uintptr_t)labels) & 15) == 0);
-    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += stride) {
-        long long row = gid / Q;
-        int q = (int)(gid - row * Q);
-        int x = q << 2;
-        int w = x >> 6, sh = x & 63;
-        long long rw = row * WW + w;
-        unsigned nib = (unsigned)(bits[rw] >> sh) & 0xFu;
-        int o[4] = {0, 0, 0, 0};
-        if (nib) {
-            const unsigned long long s = starts[rw];
-            const int32_t* fin = final_label + (row / H) * cap;
-            int id = (int)rowoff[row] + (int)prefix[rw] + __popcll(s & lm_lowmask_excl(sh)) - 1;
-            unsigned sn = (unsigned)(s >> sh) & 0xFu;
-            int lab = 0;
-            bool have = false;
+    const unsigned lane = (unsigned)lm_lane();
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
+    const long long frow = (long long)b * H;
+    const int32_t* fin = final_label + (long long)b * cap;
+    int32_t* lab_frame = labels + (long long)b * H * W;
+    for (unsigned base = wave * (64 * LM_WL_Q); base < total; base += nwaves * (64 * LM_WL_Q)) {
+        unsigned y[LM_WL_Q], x[LM_WL_Q], sh[LM_WL_Q], nib[LM_WL_Q];
+        long long rw[LM_WL_Q];
+        bool live[LM_WL_Q];
+        // phase 1: the quad's 4 mask bits
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if ((nib >> k) & 1u) {
-                    if ((sn >> k) & 1u) { id++; have = false; }
-                    if (!have) { lab = fin[id]; have = true; }
-                    o[k] = lab;
-                } else {
-                    have = false;
+        for (int k = 0; k < LM_WL_Q; k++) {
+            const unsigned gid = base + k * 64 + lane;
+            live[k] = gid < total;
+            y[k] = live[k] ? lm_fastdiv(gid, magic_q) : 0u;
+            x[k] = (gid - y[k] * Q) << 2;
+            sh[k] = x[k] & 63u;
+            rw[k] = (frow + y[k]) * WW + (x[k] >> 6);
+            nib[k] = live[k] ? ((unsigned)(bits[rw[k]] >> sh[k]) & 0xFu) : 0u;
+        }
+        // phase 2: run tables of the quads that contain ink
+        unsigned long long st[LM_WL_Q];
+        int id[LM_WL_Q];
+#pragma unroll
+        for (int k = 0; k < LM_WL_Q; k++) {
+            st[k] = 0;
+            id[k] = 0;
+            if (nib[k]) {
+                st[k] = starts[rw[k]];
+                id[k] = (int)rowoff[frow + y[k]] + (int)prefix[rw[k]] + __popcll(st[k] & lm_lowmask_excl((int)sh[k])) - 1;
+            }
+        }
+        // phase 3: labels (a quad usually touches one run, at most four)
+        int o[LM_WL_Q][4];
+#pragma unroll
+        for (int k = 0; k < LM_WL_Q; k++) {
+            o[k][0] = o[k][1] = o[k][2] = o[k][3] = 0;
+            if (nib[k]) {
+                const unsigned sn = (unsigned)(st[k] >> sh[k]) & 0xFu;
+                int lab = 0, cur = id[k];
+                bool have = false;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if ((nib[k] >> j) & 1u) {
+                        if ((sn >> j) & 1u) { cur++; have = false; }
+                        if (!have) { lab = fin[cur]; have = true; }
+                        o[k][j] = lab;
+                    } else {
+                        have = false;
+                    }
                 }
             }
         }
-        int32_t* dst = labels + row * W + x;
-        if (vec) {
-            *(int4*)dst = make_int4(o[0], o[1], o[2], o[3]);
-        } else {
-            for (int k = 0; k < 4 && x + k < W; k++) dst[k] = o[k];
+        // phase 4: stores
+#pragma unroll
+        for (int k = 0; k < LM_WL_Q; k++) {
+            if (!live[k]) continue;
+            int32_t* dst = lab_frame + (long long)y[k] * W + x[k];
+            if (vec) {
+                *(int4*)dst = make_int4(o[k][0], o[k][1], o[k][2], o[k][3]);
+            } else {
+                for (unsigned j = 0; j < 4 && x[k] + j < (unsigned)W; j++) dst[j] = o[k][j];
+            }
         }
     }
 }

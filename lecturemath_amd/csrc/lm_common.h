@@ -5,14 +5,15 @@
 //   bits     u64 [R][WW]    bit-packed foreground (bit x&63 of word x>>6; WW = ceil(W/64)), 1 bit / px
 //   starts   u64 [R][WW]    bit set where a horizontal run of foreground begins
 //   prefix   u16 [R][WW]    number of run starts in the row left of the word
-//   rowoff   u32 [R]        number of runs in the frame above the row (frame-relative)
+//   rowoff   u32 [R]        band * SLOT + number of runs of the band above the row (run ids are band-structured:
+//                           gid = band * SLOT + local index, monotone in raster order)
 //   parent   i32 [B][CAP]   union-find forest over runs (frame-relative run ids, root = smallest id)
 //   rootbits u64 [B][CAP/64] root flags; wordprefix u32 [B][CAP/64] their exclusive popcount scan
 //   final    i32 [B][CAP]   1-based scipy-ordered label of every run
 // A "run" is a maximal horizontal segment of foreground pixels; runs are numbered in raster order,
 // so the smallest run id of a component starts at the component's first pixel in raster order and
 // numbering roots in id order reproduces scipy.ndimage.label's numbering (labeler.py:126).
-// CAP = H * ceil(W/2) is the worst case, so there is no overflow path.
+// CAP = nbands * SLOT with SLOT = 64 * ceil(W/2) (worst-case runs of a 64-row band), so there is no overflow path.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,7 +45,7 @@ void lm_set_error(const char* fmt, ...);
 struct LmGeom {
     int W, H;
     int WW;        // 64-bit words per row
-    int cap;       // per-frame capacity of runs / labels: H * ceil(W/2)
+    int cap;       // per-frame run-id space / label capacity: nbands * slot
 };
 
 // Device workspace for the per-frame CC path (batch of up to max_batch frames).
@@ -56,9 +57,11 @@ struct LmCtx {
     uint64_t* bits;
     uint64_t* starts;
     uint16_t* prefix;
-    uint32_t* row_runs;
-    uint32_t* rowoff;
-    int32_t* frame_runs;     // [B]
+    uint32_t* rowoff;        // [R] band * slot + runs of the band above the row
+    int32_t* band_runs;      // [B][nbands] runs per band
+    uint32_t* band_base;     // [B][nbands] labels (roots) in the bands above
+    uint8_t* band_fallback;  // [B][nbands] 1 = forest too large for LDS, unions done in L2
+    int nbands, slot;        // bands of LM_BAND_ROWS rows; slot = id space per band (worst-case runs, multiple of 64)
     int32_t* parent;         // [B][cap]
     int32_t* final_label;    // [B][cap]
     int32_t* n_labels;       // [B]

@@ -22,13 +22,6 @@
 
 #include <vector>
 
-#if LM_HIP_EMULATED
-extern char lm_emu_dynsmem[];
-#define LM_DYN_SMEM(name) char* name = lm_emu_dynsmem
-#else
-#define LM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
-#endif
-
 #define LM_ACT_NONE 0
 #define LM_ACT_GELU 1
 #define LM_ACT_TANH 2
