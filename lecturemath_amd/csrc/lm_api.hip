@@ -380,10 +380,12 @@ extern "C" int CC_AgeBoundaries(int* labels, float* ages, int width, int height,
 extern "C" void lm_stream_destroy(LmStream* s)
 {
     if (!s) return;
-    void* ptrs[] = {s->cc, s->assign, s->frame_cc_off, s->crop, s->active_cc, s->active_box, s->active_last, s->active, s->counters, s->best_pos, s->pairs,
+    void* ptrs[] = {s->cc, s->assign, s->frame_cc_off, s->crop, s->active_cc, s->active_box, s->active_last, s->active, s->counters, s->best,
                     s->batch_cc_base, s->batch_word_base};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (s->rd_scratch) (void)hipFree(s->rd_scratch);
+    if (s->garena) (void)hipFree(s->garena);
     delete s;
 }
 
@@ -398,6 +400,7 @@ extern "C" int lm_stream_reset(LmStream* s, void* stream)
 {
     if (!s) { lm_set_error("lm_stream_reset: null stream"); return LM_ERR_ARG; }
     LM_HIP(hipMemsetAsync(s->counters, 0, sizeof(LmCounters), (hipStream_t)stream));
+    LM_HIP(hipMemsetAsync(s->best, 0xff, (size_t)s->ctx->g.cap * sizeof(unsigned long long), (hipStream_t)stream));
     LM_HIP(hipMemsetAsync(s->frame_cc_off, 0, sizeof(long long), (hipStream_t)stream));
     s->frames_pushed = 0;
     s->frames_matched = 0;
@@ -431,9 +434,7 @@ extern "C" LmStream* lm_stream_create(LmCtx* ctx, int max_frames, int64_t max_cc
     rc |= lm_alloc(&s->active_box, (size_t)max_uniques);
     rc |= lm_alloc(&s->active_last, (size_t)max_uniques);
     rc |= lm_alloc(&s->active, (size_t)max_uniques);
-    s->cap_pairs = 1 << 24;     // bbox-overlapping (CC, unique) pairs per frame; more raises LM_ERR_CAPACITY
-    rc |= lm_alloc(&s->best_pos, (size_t)ctx->g.cap);
-    rc |= lm_alloc(&s->pairs, (size_t)s->cap_pairs);
+    rc |= lm_alloc(&s->best, (size_t)ctx->g.cap);
     rc |= lm_alloc(&s->counters, (size_t)1);
     rc |= lm_alloc(&s->batch_cc_base, (size_t)ctx->max_batch);
     rc |= lm_alloc(&s->batch_word_base, (size_t)ctx->max_batch);
@@ -448,13 +449,11 @@ extern "C" LmStream* lm_stream_create(LmCtx* ctx, int max_frames, int64_t max_cc
 
 static void lm_launch_match(LmStream* s, int f, hipStream_t st)
 {
-    hipLaunchKernelGGL(lm_k_match_scan, LM_HIP_EMULATED ? dim3(2, 2) : dim3(16, 32), dim3(256), 0, st, s->cc, s->frame_cc_off, f, s->active_box,
-                       s->active_last, s->active_cc, s->counters, s->best_pos, s->pairs, s->cap_pairs, s->max_gap);
-    hipLaunchKernelGGL(lm_k_match_eval, dim3(LM_HIP_EMULATED ? 2 : 128), dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, s->active_cc,
-                       s->counters, s->pairs, s->best_pos, s->cap_pairs, s->min_recall, s->min_precision);
+    hipLaunchKernelGGL(lm_k_match, LM_HIP_EMULATED ? dim3(2, 2) : dim3(16, 64), dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f,
+                       s->active_box, s->active_last, s->active_cc, s->counters, s->best, s->min_recall, s->min_precision, s->max_gap);
     // compact the active list every 16 frames (purely an optimisation: retirement is evaluated lazily)
     hipLaunchKernelGGL(lm_k_update, dim3(1), dim3(1024), 0, st, s->cc, s->frame_cc_off, f, s->active, s->active_cc, s->active_box,
-                       s->active_last, s->counters, s->assign, s->best_pos, s->cap_pairs, s->max_gap, s->cap_uniq, (f & 15) == 15 ? 1 : 0);
+                       s->active_last, s->counters, s->assign, s->best, s->max_gap, s->cap_uniq, (f & 15) == 15 ? 1 : 0);
 }
 
 static int lm_stream_push_impl(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* d_labels, int do_match, void* stream)
@@ -665,18 +664,19 @@ extern "C" int lm_stream_read(LmStream* s, int32_t* h_rec, int64_t* h_frame_off,
     if (rc) return rc;
     const long long n_cc = k[1];
     if ((h_rec || h_crop_off) && n_cc > 0) {
-        int32_t* d_rec = nullptr;
-        long long* d_off = nullptr;
-        LM_HIP(hipMalloc((void**)&d_rec, (size_t)n_cc * 8 * sizeof(int32_t)));
-        if (hipMalloc((void**)&d_off, (size_t)n_cc * sizeof(long long)) != hipSuccess) { (void)hipFree(d_rec); lm_set_error("lm_stream_read: hipMalloc failed"); return LM_ERR_HIP; }
+        const size_t need = (size_t)n_cc * (8 * sizeof(int32_t) + sizeof(long long));
+        if (s->rd_scratch_bytes < need) {
+            if (s->rd_scratch) (void)hipFree(s->rd_scratch);
+            s->rd_scratch = nullptr; s->rd_scratch_bytes = 0;
+            LM_HIP(hipMalloc(&s->rd_scratch, need + need / 4));
+            s->rd_scratch_bytes = need + need / 4;
+        }
+        long long* d_off = (long long*)s->rd_scratch;                       // 8-byte aligned part first
+        int32_t* d_rec = (int32_t*)(d_off + n_cc);
         hipLaunchKernelGGL(lm_k_pack_records, dim3(lm_blocks(n_cc, 256)), dim3(256), 0, st, s->cc, s->assign, n_cc, d_rec, d_off);
-        hipError_t e1 = hipSuccess, e2 = hipSuccess;
-        if (h_rec) e1 = hipMemcpyAsync(h_rec, d_rec, (size_t)n_cc * 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
-        if (h_crop_off) e2 = hipMemcpyAsync(h_crop_off, d_off, (size_t)n_cc * sizeof(long long), hipMemcpyDeviceToHost, st);
-        hipError_t e3 = hipStreamSynchronize(st);
-        (void)hipFree(d_rec);
-        (void)hipFree(d_off);
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { lm_set_error("lm_stream_read: record copy failed"); return LM_ERR_HIP; }
+        if (h_rec) LM_HIP(hipMemcpyAsync(h_rec, d_rec, (size_t)n_cc * 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (h_crop_off) LM_HIP(hipMemcpyAsync(h_crop_off, d_off, (size_t)n_cc * sizeof(long long), hipMemcpyDeviceToHost, st));
+        LM_HIP(hipStreamSynchronize(st));
     }
     if (h_frame_off) LM_HIP(hipMemcpyAsync(h_frame_off, s->frame_cc_off, (size_t)(k[0] + 1) * sizeof(long long), hipMemcpyDeviceToHost, st));
     if (h_crop && k[2] > 0) LM_HIP(hipMemcpyAsync(h_crop, s->crop, (size_t)k[2] * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

@@ -405,6 +405,8 @@ __global__ void __launch_bounds__(256) lm_k_write_labels(const uint64_t* __restr
                                                          const int32_t* __restrict__ final_label, int32_t* __restrict__ labels,
                                                          int W, int H, int WW, int cap, unsigned long long magic_q)
 {
+    // The kernel is instruction-bound before it is memory-bound (the first version spent ~870 instructions and 54
+    // exec-mask branches per trip): 32-bit index math, one lookup for the common "all ink of the quad is one run" case.
     const unsigned Q = (unsigned)(W + 3) >> 2;
     const unsigned total = (unsigned)H * Q;                 // quads of one frame (grid.y = frame)
     const int b = blockIdx.y;
@@ -412,66 +414,53 @@ __global__ void __launch_bounds__(256) lm_k_write_labels(const uint64_t* __restr
     const unsigned lane = (unsigned)lm_lane();
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
-    const long long frow = (long long)b * H;
+    const uint64_t* fbits = bits + (long long)b * H * WW;
+    const uint64_t* fstarts = starts + (long long)b * H * WW;
+    const uint16_t* fprefix = prefix + (long long)b * H * WW;
+    const uint32_t* frowoff = rowoff + (long long)b * H;
     const int32_t* fin = final_label + (long long)b * cap;
     int32_t* lab_frame = labels + (long long)b * H * W;
     for (unsigned base = wave * (64 * LM_WL_Q); base < total; base += nwaves * (64 * LM_WL_Q)) {
-        unsigned y[LM_WL_Q], x[LM_WL_Q], sh[LM_WL_Q], nib[LM_WL_Q];
-        long long rw[LM_WL_Q];
-        bool live[LM_WL_Q];
-        // phase 1: the quad's 4 mask bits
+        unsigned y[LM_WL_Q], x[LM_WL_Q], rw[LM_WL_Q], nib[LM_WL_Q];
 #pragma unroll
         for (int k = 0; k < LM_WL_Q; k++) {
             const unsigned gid = base + k * 64 + lane;
-            live[k] = gid < total;
-            y[k] = live[k] ? lm_fastdiv(gid, magic_q) : 0u;
-            x[k] = (gid - y[k] * Q) << 2;
-            sh[k] = x[k] & 63u;
-            rw[k] = (frow + y[k]) * WW + (x[k] >> 6);
-            nib[k] = live[k] ? ((unsigned)(bits[rw[k]] >> sh[k]) & 0xFu) : 0u;
+            const unsigned g = gid < total ? gid : total - 1;        // clamp: duplicate work, the store is predicated
+            y[k] = lm_fastdiv(g, magic_q);
+            x[k] = (g - y[k] * Q) << 2;
+            rw[k] = y[k] * (unsigned)WW + (x[k] >> 6);
+            nib[k] = (unsigned)(fbits[rw[k]] >> (x[k] & 63u)) & 0xFu;
         }
-        // phase 2: run tables of the quads that contain ink
-        unsigned long long st[LM_WL_Q];
-        int id[LM_WL_Q];
 #pragma unroll
         for (int k = 0; k < LM_WL_Q; k++) {
-            st[k] = 0;
-            id[k] = 0;
+            int o0 = 0, o1 = 0, o2 = 0, o3 = 0;
             if (nib[k]) {
-                st[k] = starts[rw[k]];
-                id[k] = (int)rowoff[frow + y[k]] + (int)prefix[rw[k]] + __popcll(st[k] & lm_lowmask_excl((int)sh[k])) - 1;
-            }
-        }
-        // phase 3: labels (a quad usually touches one run, at most four)
-        int o[LM_WL_Q][4];
-#pragma unroll
-        for (int k = 0; k < LM_WL_Q; k++) {
-            o[k][0] = o[k][1] = o[k][2] = o[k][3] = 0;
-            if (nib[k]) {
-                const unsigned sn = (unsigned)(st[k] >> sh[k]) & 0xFu;
-                int lab = 0, cur = id[k];
-                bool have = false;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if ((nib[k] >> j) & 1u) {
-                        if ((sn >> j) & 1u) { cur++; have = false; }
-                        if (!have) { lab = fin[cur]; have = true; }
-                        o[k][j] = lab;
-                    } else {
-                        have = false;
-                    }
+                const unsigned sh = x[k] & 63u;
+                const unsigned long long st = fstarts[rw[k]];
+                const int idb = (int)frowoff[y[k]] + (int)fprefix[rw[k]] + __popcll(st & lm_lowmask_excl((int)sh)) - 1;
+                const unsigned sn = (unsigned)(st >> sh) & 0xFu;
+                // run index of pixel j = idb + popc(sn & ((2 << j) - 1))
+                const int jf = __ffs((int)nib[k]) - 1, jl = 31 - __clz((int)nib[k]);
+                const int idf = idb + __popc(sn & ((2u << jf) - 1u)), idl = idb + __popc(sn & ((2u << jl) - 1u));
+                const int lf = fin[idf];
+                if (idf == idl) {                                   // one run: broadcast
+                    o0 = (nib[k] & 1u) ? lf : 0; o1 = (nib[k] & 2u) ? lf : 0; o2 = (nib[k] & 4u) ? lf : 0; o3 = (nib[k] & 8u) ? lf : 0;
+                } else {                                            // up to four runs (alternating pixels)
+                    o0 = (nib[k] & 1u) ? fin[idb + __popc(sn & 1u)] : 0;
+                    o1 = (nib[k] & 2u) ? fin[idb + __popc(sn & 3u)] : 0;
+                    o2 = (nib[k] & 4u) ? fin[idb + __popc(sn & 7u)] : 0;
+                    o3 = (nib[k] & 8u) ? fin[idb + __popc(sn & 15u)] : 0;
                 }
             }
-        }
-        // phase 4: stores
-#pragma unroll
-        for (int k = 0; k < LM_WL_Q; k++) {
-            if (!live[k]) continue;
-            int32_t* dst = lab_frame + (long long)y[k] * W + x[k];
-            if (vec) {
-                *(int4*)dst = make_int4(o[k][0], o[k][1], o[k][2], o[k][3]);
-            } else {
-                for (unsigned j = 0; j < 4 && x[k] + j < (unsigned)W; j++) dst[j] = o[k][j];
+            const unsigned gid = base + k * 64 + lane;
+            if (gid < total) {
+                int32_t* dst = lab_frame + y[k] * (unsigned)W + x[k];
+                if (vec) {
+                    *(int4*)dst = make_int4(o0, o1, o2, o3);
+                } else {
+                    const int oo[4] = {o0, o1, o2, o3};
+                    for (unsigned j = 0; j < 4 && x[k] + j < (unsigned)W; j++) dst[j] = oo[j];
+                }
             }
         }
     }

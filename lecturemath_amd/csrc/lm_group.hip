@@ -15,6 +15,7 @@
 #include "lm_stream.h"
 
 #include <algorithm>
+#include <chrono>
 #include <unordered_map>
 #include <vector>
 
@@ -196,10 +197,11 @@ __global__ void __launch_bounds__(256) lm_k_render_frames(const long long* __res
                                                           const LmRenderItem* __restrict__ items, const uint8_t* __restrict__ images,
                                                           int first_frame, int W, int H, uint8_t* __restrict__ out)
 {
-    __shared__ int s_cnt[LM_RT_ROWS * LM_RT_COLS];
+    // k per pixel in 16-bit lanes, two pixels per LDS word (a pixel would need 65536 overlapping groups to overflow its lane)
+    __shared__ unsigned s_cnt[LM_RT_ROWS * LM_RT_COLS / 2];
     const int f = first_frame + blockIdx.z;
     const int X0 = blockIdx.x * LM_RT_COLS, Y0 = blockIdx.y * LM_RT_ROWS;
-    for (int i = threadIdx.x; i < LM_RT_ROWS * LM_RT_COLS; i += blockDim.x) s_cnt[i] = 0;
+    for (int i = threadIdx.x; i < LM_RT_ROWS * LM_RT_COLS / 2; i += blockDim.x) s_cnt[i] = 0;
     __syncthreads();
     const long long i0 = frame_item_off[f], i1 = frame_item_off[f + 1];
     const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6), lane = lm_lane();
@@ -225,16 +227,34 @@ __global__ void __launch_bounds__(256) lm_k_render_frames(const long long* __res
             for (int idx = lane; idx < total; idx += 64) {
                 const int yy = idx / tw, xx = idx - yy * tw;
                 const int y = ya + yy, x = xa + xx;
-                if (images[it.img_off + (long long)(y - it.y0) * it.w + (x - it.x0)]) atomicAdd(&s_cnt[(y - Y0) * LM_RT_COLS + (x - X0)], 1);
+                if (images[it.img_off + (long long)(y - it.y0) * it.w + (x - it.x0)]) {
+                    const int p = (y - Y0) * LM_RT_COLS + (x - X0);
+                    atomicAdd(&s_cnt[p >> 1], 1u << (16 * (p & 1)));
+                }
             }
         }
     }
     __syncthreads();
     uint8_t* dst = out + (long long)blockIdx.z * W * H;
-    for (int i = threadIdx.x; i < LM_RT_ROWS * LM_RT_COLS; i += blockDim.x) {
-        const int yy = i / LM_RT_COLS, xx = i - yy * LM_RT_COLS;
-        const int y = Y0 + yy, x = X0 + xx;
-        if (y < H && x < W) dst[(long long)y * W + x] = (uint8_t)((0u - (unsigned)s_cnt[i]) & 0xffu);
+    const bool vec = ((W & 15) == 0) && ((((uintptr_t)out) & 15) == 0);
+    // 16 pixels (8 LDS words) -> one 16-byte store
+    for (int i = threadIdx.x; i < LM_RT_ROWS * LM_RT_COLS / 16; i += blockDim.x) {
+        const int yy = i / (LM_RT_COLS / 16), xq = i - yy * (LM_RT_COLS / 16);
+        const int y = Y0 + yy, x = X0 + xq * 16;
+        if (y >= H || x >= W) continue;
+        unsigned o[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned w0 = s_cnt[yy * (LM_RT_COLS / 2) + xq * 8 + q * 2], w1 = s_cnt[yy * (LM_RT_COLS / 2) + xq * 8 + q * 2 + 1];
+            o[q] = ((0u - (w0 & 0xffffu)) & 0xffu) | (((0u - (w0 >> 16)) & 0xffu) << 8) | (((0u - (w1 & 0xffffu)) & 0xffu) << 16) |
+                   (((0u - (w1 >> 16)) & 0xffu) << 24);
+        }
+        uint8_t* d = dst + (long long)y * W + x;
+        if (vec) {
+            *(uint4*)d = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+            for (int k = 0; k < 16 && x + k < W; k++) d[k] = (uint8_t)(o[k >> 2] >> (8 * (k & 3)));
+        }
     }
 }
 
@@ -271,8 +291,27 @@ struct LmGroups {
     uint8_t* d_images = nullptr;
     long long* d_frame_item_off = nullptr;
     LmRenderItem* d_render_items = nullptr;
-    std::vector<void*> d_owned;
+    std::vector<void*> d_owned;                 // allocations that did not fit the arena
+    char* arena = nullptr;                      // bump arena (the stream's cached one when it was free)
+    size_t arena_cap = 0, arena_used = 0, arena_want = 0;
+    bool arena_cached = false;
 };
+
+// Device memory for one lm_group_run: bump allocation from the arena, hipMalloc only for what does not fit.
+static void* lm_galloc(LmGroups* g, size_t bytes)
+{
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    g->arena_want += need;
+    if (g->arena && g->arena_used + need <= g->arena_cap) {
+        void* p = g->arena + g->arena_used;
+        g->arena_used += need;
+        return p;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, need ? need : 256) != hipSuccess) { lm_set_error("lm_group_run: hipMalloc(%zu) failed", need); return nullptr; }
+    g->d_owned.push_back(p);
+    return p;
+}
 
 #define LM_G_ARRAYS 40
 enum {
@@ -283,12 +322,12 @@ enum {
     LM_G_GIMG_OFF, LM_G_GIMG_ITEM_OFF, LM_G_GIMG, LM_G_SCALARS
 };
 
-template <class T> static int lm_upload(LmGroups* g, const std::vector<T>& v, T** d)
+template <class T> static int lm_upload(LmGroups* g, const std::vector<T>& v, T** d, hipStream_t st)
 {
-    *d = nullptr;
-    LM_HIP(hipMalloc((void**)d, (v.size() ? v.size() : 1) * sizeof(T)));
-    g->d_owned.push_back(*d);
-    if (!v.empty()) LM_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *d = (T*)lm_galloc(g, (v.size() ? v.size() : 1) * sizeof(T));
+    if (!*d) return LM_ERR_HIP;
+    // the host vectors outlive the copy: they are members of g or locals that live until the final stream sync
+    if (!v.empty()) LM_HIP(hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
     return LM_OK;
 }
 
@@ -296,12 +335,41 @@ extern "C" void lm_group_destroy(LmGroups* g)
 {
     if (!g) return;
     for (void* p : g->d_owned) (void)hipFree(p);
+    if (g->arena) {
+        LmStream* s = g->s;
+        if (g->arena_cached) {
+            s->garena_busy = 0;
+            if (g->arena_want > s->garena_bytes) {          // grow for the next run
+                (void)hipFree(s->garena);
+                s->garena = nullptr; s->garena_bytes = 0;
+                size_t want = g->arena_want + g->arena_want / 4;
+                if (hipMalloc(&s->garena, want) == hipSuccess) s->garena_bytes = want;
+            }
+        } else {
+            (void)hipFree(g->arena);
+        }
+    }
     delete g;
 }
+
+// LM_GROUP_TIMING=1 prints the wall time of every phase of lm_group_run to stderr
+struct LmPhaseTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    LmPhaseTimer() : on(getenv("LM_GROUP_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void mark(const char* what)
+    {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[lm_group] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
 
 static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st)
 {
     LmStream* s = g->s;
+    LmPhaseTimer tm;
     int64_t k[7];
     int rc = lm_stream_counters(s, k, st);
     if (rc) return rc;
@@ -315,6 +383,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
     std::vector<int64_t> foff((size_t)F + 1);
     rc = lm_stream_read(s, rec.data(), foff.data(), nullptr, nullptr, nullptr, st);
     if (rc) return rc;
+    tm.mark("counters + records D2H");
     auto R = [&](long long c, int field) { return rec[(size_t)c * 8 + field]; };   // 0 cc_id 1 min_x 2 max_x 3 min_y 4 max_y 5 size 6 frame 7 assign
 
     // ---- per-unique entry lists (CC order == ascending frame, the reference's append order)
@@ -326,6 +395,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
         for (long long c = 0; c < n_cc; c++) lst[(size_t)pos[R(c, 7)]++] = (int32_t)c;
     }
+    tm.mark("entry lists");
     // ---- split_stable_cc_by_gaps (:181-228)
     g->assign.resize((size_t)std::max<long long>(n_cc, 1));
     for (long long c = 0; c < n_cc; c++) g->assign[(size_t)c] = R(c, 7);
@@ -366,6 +436,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
     auto usize = [&](int u) { return R(g->uniq_cc[u], 5); };
     auto ubox = [&](int u, int i) { return R(g->uniq_cc[u], 1 + i); };     // min_x max_x min_y max_y
 
+    tm.mark("split + CSR");
     // ---- stable set (:230-236)
     g->stable.clear();
     for (int u = 0; u < nU; u++)
@@ -384,28 +455,26 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
             hcc[i] = g->uniq_cc[u];
         }
         unsigned long long* d_box; int32_t* d_cc; int* d_np;
-        if (lm_upload(g, hbox, &d_box) || lm_upload(g, hcc, &d_cc)) return LM_ERR_HIP;
-        LM_HIP(hipMalloc((void**)&d_np, 64));
-        g->d_owned.push_back(d_np);
-        int cap_pairs = 1 << 22;
+        if (lm_upload(g, hbox, &d_box, st) || lm_upload(g, hcc, &d_cc, st)) return LM_ERR_HIP;
+        d_np = (int*)lm_galloc(g, 64);
+        if (!d_np) return LM_ERR_HIP;
+        int cap_pairs = 1 << 20;
         int2* d_pairs = nullptr;
         int np = 0;
         for (;;) {
-            LM_HIP(hipMalloc((void**)&d_pairs, (size_t)cap_pairs * sizeof(int2)));
+            d_pairs = (int2*)lm_galloc(g, (size_t)cap_pairs * sizeof(int2));
+            if (!d_pairs) return LM_ERR_HIP;
             LM_HIP(hipMemsetAsync(d_np, 0, sizeof(int), st));
             const int gx = std::min((nS + 255) / 256, LM_HIP_EMULATED ? 2 : 64), gy = std::min((nS + LM_SJ_TILE - 1) / LM_SJ_TILE, LM_HIP_EMULATED ? 2 : 64);
             hipLaunchKernelGGL(lm_k_selfjoin, dim3(gx, gy), dim3(256), 0, st, d_box, nS, d_np, d_pairs, cap_pairs);
             LM_HIP(hipMemcpyAsync(&np, d_np, sizeof(int), hipMemcpyDeviceToHost, st));
             LM_HIP(hipStreamSynchronize(st));
             if (np <= cap_pairs) break;
-            (void)hipFree(d_pairs);         // grow and redo (the join is cheap)
-            cap_pairs = np + (np >> 3);
+            cap_pairs = np + (np >> 3);     // grow and redo (the join is cheap; the small buffer stays in the arena)
         }
-        g->d_owned.push_back(d_pairs);
         if (np > 0) {
-            int32_t* d_match;
-            LM_HIP(hipMalloc((void**)&d_match, (size_t)np * sizeof(int32_t)));
-            g->d_owned.push_back(d_match);
+            int32_t* d_match = (int32_t*)lm_galloc(g, (size_t)np * sizeof(int32_t));
+            if (!d_match) return LM_ERR_HIP;
             hipLaunchKernelGGL(lm_k_pair_overlap, dim3(LM_HIP_EMULATED ? 2 : 1024), dim3(256), 0, st, s->cc, s->crop, d_cc, d_pairs, np, d_match);
             std::vector<int2> hp((size_t)np);
             std::vector<int32_t> hm((size_t)np);
@@ -422,6 +491,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
             }
         }
     }
+    tm.mark("self-join + overlaps (device)");
     // per-unique neighbour lists, filled in sorted pair order (== the reference's iteration order)
     struct Tov { int32_t other; double recall, precision; };
     struct Aov { int32_t other, matched, size_other, size_self; };
@@ -445,6 +515,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
             }
         }
     }
+    tm.mark("neighbour lists");
     // ---- compute_groups (:308-413): sequential, order-dependent
     std::vector<std::vector<int32_t>> groups;
     std::vector<int32_t> gid((size_t)nU, -1);
@@ -534,6 +605,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         for (const Aov& t : aov[u]) { g->aov_other.push_back(t.other); g->aov_matched.push_back(t.matched); g->aov_size_other.push_back(t.size_other); g->aov_size_self.push_back(t.size_self); }
         g->aov_off.push_back((int64_t)g->aov_other.size());
     }
+    tm.mark("groups/ages/conflicts/flatten");
     // ---- group images (:575-636)
     g->bounds.assign((size_t)nG * 4, 0);
     std::vector<LmGimgItem> items;
@@ -576,13 +648,13 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         g->gimg_item_off.push_back((int64_t)items.size());
     }
     const long long img_bytes = g->gimg_off.back();
-    LM_HIP(hipMalloc((void**)&g->d_images, (size_t)std::max<long long>(img_bytes, 1)));
-    g->d_owned.push_back(g->d_images);
+    g->d_images = (uint8_t*)lm_galloc(g, (size_t)std::max<long long>(img_bytes, 1));
+    if (!g->d_images) return LM_ERR_HIP;
     if (!items.empty()) {
         LmGimgItem* d_items; LmGimgMember* d_members; LmGimgUnit* d_units; int32_t* d_max;
-        if (lm_upload(g, items, &d_items) || lm_upload(g, members, &d_members) || lm_upload(g, units, &d_units)) return LM_ERR_HIP;
-        LM_HIP(hipMalloc((void**)&d_max, items.size() * sizeof(int32_t)));
-        g->d_owned.push_back(d_max);
+        if (lm_upload(g, items, &d_items, st) || lm_upload(g, members, &d_members, st) || lm_upload(g, units, &d_units, st)) return LM_ERR_HIP;
+        d_max = (int32_t*)lm_galloc(g, items.size() * sizeof(int32_t));
+        if (!d_max) return LM_ERR_HIP;
         LM_HIP(hipMemsetAsync(d_max, 0, items.size() * sizeof(int32_t), st));
         const int nb = (int)std::min<size_t>(units.size(), LM_HIP_EMULATED ? 2 : 4096);
         hipLaunchKernelGGL(lm_k_gimg_max, dim3(nb), dim3(256), 0, st, d_items, d_units, (int)units.size(), d_members, s->cc, s->crop, d_max);
@@ -590,6 +662,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
                            d_max, g->img_thr, g->d_images);
         LM_HIP(hipGetLastError());
     }
+    tm.mark("group images (host tables + device)");
     // ---- render tables for frames_from_groups (:638-681)
     if (reconstruct_tables) {
         std::vector<long long> fio((size_t)F + 1, 0);
@@ -611,9 +684,11 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
             }
             fio[(size_t)f + 1] = (long long)ritems.size();
         }
-        if (lm_upload(g, fio, &g->d_frame_item_off) || lm_upload(g, ritems, &g->d_render_items)) return LM_ERR_HIP;
+        if (lm_upload(g, fio, &g->d_frame_item_off, st) || lm_upload(g, ritems, &g->d_render_items, st)) return LM_ERR_HIP;
+        LM_HIP(hipStreamSynchronize(st));      // fio / ritems are locals: the async uploads must finish before they go out of scope
     }
     LM_HIP(hipStreamSynchronize(st));
+    tm.mark("render tables + final sync");
     return LM_OK;
 }
 
@@ -623,6 +698,13 @@ extern "C" LmGroups* lm_group_run(LmStream* s, int max_gap, int min_times, int t
     if (!s) { lm_set_error("lm_group_run: null stream"); return nullptr; }
     LmGroups* g = new LmGroups();
     g->s = s;
+    if (!s->garena_busy) {
+        if (!s->garena) {
+            const size_t first = (size_t)64 << 20;
+            if (hipMalloc(&s->garena, first) == hipSuccess) s->garena_bytes = first;
+        }
+        if (s->garena) { g->arena = (char*)s->garena; g->arena_cap = s->garena_bytes; g->arena_cached = true; s->garena_busy = 1; }
+    }
     g->max_gap = max_gap; g->min_times = min_times; g->t_window = t_window;
     g->min_recall = min_recall; g->img_thr = img_threshold;
     if (lm_group_run_impl(g, reconstruct_tables, (hipStream_t)stream) != LM_OK) {

@@ -181,7 +181,8 @@ LM_DEV bool lm_accept(int match, int size_cur, int size_uni, double min_recall, 
     return recall >= min_recall && precision >= min_precision;   // cc_stability_estimator.py:99
 }
 
-#define LM_SCAN_CCS 64      // CC boxes per tile (LDS), one active box per thread
+#define LM_SCAN_CCS 16      // CC boxes per tile (LDS); one active box per thread -> at most 16 * 256 hits per step
+#define LM_SCAN_PAIRS (LM_SCAN_CCS * 256)
 
 LM_DEV bool lm_box_hit_packed(unsigned long long c, unsigned long long u)
 {
@@ -196,98 +197,73 @@ LM_DEV unsigned long long lm_pack_box(const LmCcRec& r)
            ((unsigned long long)(unsigned short)r.min_y << 32) | ((unsigned long long)(unsigned short)r.max_y << 48);
 }
 
-// M1a: candidate scan = box join (current CCs of frame f) x (active uniques), tiled: a block walks its share
-// of (tile of LM_SCAN_CCS CC boxes in LDS) x (chunk of 256 active boxes, one per thread, alive-masked) twice:
-// pass 1 counts each thread's hits, ONE returning atomic per block reserves room in the frame's pair list
-// (a returning atomic on one address serialises at ~88/us on gfx950, so never one per hit), pass 2 writes
-// the pairs (cc index in frame, active position, first-seen CC of the unique).  Order is irrelevant: the
-// decision only needs the SMALLEST accepted position per CC (lm_k_match_eval's atomicMin).
-__global__ void __launch_bounds__(256) lm_k_match_scan(const LmCcRec* __restrict__ cc, const long long* __restrict__ frame_cc_off,
-                                                       int f, const unsigned long long* __restrict__ active_box,
-                                                       const int32_t* __restrict__ active_last, const int32_t* __restrict__ active_cc,
-                                                       LmCounters* __restrict__ cnt, int32_t* __restrict__ best_pos,
-                                                       int4* __restrict__ pairs, int cap_pairs, int max_gap)
+// best[] key of frame f: smaller for later frames, so one 64-bit atomicMin array serves the whole stream without being
+// re-initialised: a slot holds a decision of frame f iff its high word equals lm_frame_tag(f).
+LM_DEV unsigned long long lm_frame_tag(int f) { return (unsigned long long)(0x7fffffff - f) << 32; }
+
+// M1: candidate scan + evaluation, fused.  Box join (current CCs of frame f) x (active uniques), tiled: a step is
+// (tile of LM_SCAN_CCS CC boxes in LDS) x (chunk of 256 active boxes, one per thread, alive-masked).  Hits of a step go to
+// an LDS pair list (ds_add_rtn slot allocation), then the block evaluates them itself, 16 lanes per pair (AND + popcount on
+// the bit crops, float64 recall/precision), and keeps the SMALLEST accepted active position per CC with a device-scope
+// atomicMin -- the active list is ascending in unique index, so that is the reference's first match (:90-108).
+// No global pair list, no per-hit global atomics (a returning atomic on one address serialises at ~88/us on gfx950).
+__global__ void __launch_bounds__(256) lm_k_match(const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
+                                                  const long long* __restrict__ frame_cc_off, int f,
+                                                  const unsigned long long* __restrict__ active_box, const int32_t* __restrict__ active_last,
+                                                  const int32_t* __restrict__ active_cc, LmCounters* __restrict__ cnt,
+                                                  unsigned long long* __restrict__ best, double min_recall, double min_precision,
+                                                  int max_gap)
 {
     __shared__ unsigned long long s_cbox[LM_SCAN_CCS];
-    __shared__ int s_base;
+    __shared__ int2 s_pairs[LM_SCAN_PAIRS];          // (cc index in tile, active position)
+    __shared__ int s_np;
+    __shared__ unsigned s_hits;
     if (cnt->error) return;     // a capacity error leaves frame_cc_off unwritten: do not touch it
     const long long c0 = frame_cc_off[f], c1 = frame_cc_off[f + 1];
     const int nC = (int)(c1 - c0);
     const int nA = cnt->n_active;
-    unsigned mine = 0, off = 0;
-    for (int pass = 0; pass < 2; pass++) {
-        for (int ct = blockIdx.y * LM_SCAN_CCS; ct < nC; ct += gridDim.y * LM_SCAN_CCS) {
-            const int tile = (nC - ct < LM_SCAN_CCS) ? nC - ct : LM_SCAN_CCS;
+    const unsigned long long tag = lm_frame_tag(f);
+    const int sub = (int)(threadIdx.x & 15), grp = (int)(threadIdx.x >> 4);
+    if (threadIdx.x == 0) s_hits = 0;
+    for (int ct = blockIdx.y * LM_SCAN_CCS; ct < nC; ct += gridDim.y * LM_SCAN_CCS) {
+        const int tile = (nC - ct < LM_SCAN_CCS) ? nC - ct : LM_SCAN_CCS;
+        for (int a0 = blockIdx.x * 256; a0 < nA; a0 += gridDim.x * 256) {
             __syncthreads();
-            if ((int)threadIdx.x < tile) {
-                s_cbox[threadIdx.x] = lm_pack_box(cc[c0 + ct + threadIdx.x]);
-                if (pass == 0 && blockIdx.x == 0) best_pos[ct + threadIdx.x] = 0x7fffffff;
-            }
+            if ((int)threadIdx.x < tile) s_cbox[threadIdx.x] = lm_pack_box(cc[c0 + ct + threadIdx.x]);
+            if (threadIdx.x == 0) s_np = 0;
             __syncthreads();
-            for (int a0 = blockIdx.x * 256; a0 < nA; a0 += gridDim.x * 256) {
-                const int a = a0 + (int)threadIdx.x;
-                if (a >= nA) continue;
-                if (!((f <= 1) || ((f - 1) - active_last[a] < max_gap))) continue;     // retired (lazily)
+            const int a = a0 + (int)threadIdx.x;
+            if (a < nA && ((f <= 1) || ((f - 1) - active_last[a] < max_gap))) {        // lazily retired entries are skipped
                 const unsigned long long box = active_box[a];
-                if (pass == 0) {
-                    for (int j = 0; j < tile; j++) mine += lm_box_hit_packed(s_cbox[j], box) ? 1u : 0u;
-                } else {
-                    int ucc = -1;
-                    for (int j = 0; j < tile; j++)
-                        if (lm_box_hit_packed(s_cbox[j], box)) {
-                            if (ucc < 0) ucc = active_cc[a];
-                            if ((int)off < cap_pairs) pairs[off] = make_int4(ct + j, a, ucc, 0);
-                            off++;
-                        }
-                }
-            }
-        }
-        if (pass == 0) {
-            unsigned tot;
-            unsigned ex = lm_block_excl_scan<256>(mine, &tot);
-            if (threadIdx.x == 0) {
-                s_base = tot ? atomicAdd(&cnt->n_pairs, (int)tot) : 0;
-                if (tot) atomicAdd(&cnt->tempo_count, (unsigned long long)tot);
+                for (int j = 0; j < tile; j++)
+                    if (lm_box_hit_packed(s_cbox[j], box)) s_pairs[atomicAdd(&s_np, 1)] = make_int2(j, a);
             }
             __syncthreads();
-            if (tot == 0) return;       // block-uniform
-            off = (unsigned)s_base + ex;
-        }
-    }
-}
-
-// M1b: evaluate every candidate pair of the frame; 16 lanes share one pair.
-__global__ void __launch_bounds__(256) lm_k_match_eval(const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
-                                                       const long long* __restrict__ frame_cc_off, int f,
-                                                       const int32_t* __restrict__ active_cc, const LmCounters* __restrict__ cnt,
-                                                       const int4* __restrict__ pairs, int32_t* __restrict__ best_pos, int cap_pairs,
-                                                       double min_recall, double min_precision)
-{
-    if (cnt->error) return;
-    const long long c0 = frame_cc_off[f];
-    int np = cnt->n_pairs;
-    if (np > cap_pairs) np = cap_pairs;     // overflow is turned into LM_ERR_CAPACITY by lm_k_update
-    const int sub = (int)(threadIdx.x & 15);
-    const int group = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4);
-    const int ngroups = (int)((gridDim.x * blockDim.x) >> 4);
-    const int np_pad = (np + 3) & ~3;       // keep whole waves in the loop (4 groups per wave) for the shuffles
-    for (int p = group; p < np_pad; p += ngroups) {
-        int m = 0;
-        LmCcRec rec, urec;
-        int4 pr = make_int4(0, 0, 0, 0);
-        const bool live = p < np;
-        if (live) {
-            pr = pairs[p];
-            rec = cc[c0 + pr.x];
-            urec = cc[pr.z];
-            const LmIsect is = lm_isect(rec, urec);
-            m = lm_overlap_words(rec, urec, is, crop, sub, 16);
-        }
+            const int np = s_np;
+            if (threadIdx.x == 0) s_hits += (unsigned)np;
+            // evaluate the step's pairs: 16 groups of 16 lanes
+            const int np_pad = (np + 3) & ~3;       // whole waves stay in the loop for the shuffles
+            for (int p = grp; p < np_pad; p += 16) {
+                int m = 0;
+                LmCcRec rec, urec;
+                int2 pr = make_int2(0, 0);
+                const bool live = p < np;
+                if (live) {
+                    pr = s_pairs[p];
+                    rec = cc[c0 + ct + pr.x];
+                    urec = cc[active_cc[pr.y]];
+                    const LmIsect is = lm_isect(rec, urec);
+                    m = lm_overlap_words(rec, urec, is, crop, sub, 16);
+                }
 #pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) m += __shfl_xor(m, d, 16);
-        if (live && sub == 0 && lm_accept(m, rec.size, urec.size, min_recall, min_precision))
-            atomicMin(&best_pos[pr.x], pr.y);     // smallest position == smallest unique index == first match (:90-108)
+                for (int d = 8; d >= 1; d >>= 1) m += __shfl_xor(m, d, 16);
+                if (live && sub == 0 && lm_accept(m, rec.size, urec.size, min_recall, min_precision))
+                    atomicMin(&best[ct + pr.x], tag | (unsigned long long)(unsigned)pr.y);
+            }
+        }
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_hits) atomicAdd(&cnt->tempo_count, (unsigned long long)s_hits);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -301,8 +277,7 @@ __global__ void __launch_bounds__(1024) lm_k_update(const LmCcRec* __restrict__ 
                                                     int f, int32_t* __restrict__ active, int32_t* __restrict__ active_cc,
                                                     unsigned long long* __restrict__ active_box, int32_t* __restrict__ active_last,
                                                     LmCounters* __restrict__ cnt, int32_t* __restrict__ assign,
-                                                    const int32_t* __restrict__ best_pos, int cap_pairs, int max_gap, int cap_uniq,
-                                                    int compact)
+                                                    const unsigned long long* __restrict__ best, int max_gap, int cap_uniq, int compact)
 {
     if (cnt->error) return;
     const long long c0 = frame_cc_off[f], c1 = frame_cc_off[f + 1];
@@ -313,16 +288,17 @@ __global__ void __launch_bounds__(1024) lm_k_update(const LmCcRec* __restrict__ 
     if (threadIdx.x == 0) s_overflow = 0;
     __syncthreads();
     // ---- decisions
+    const unsigned long long tag = lm_frame_tag(f);
     for (int i = threadIdx.x; i < n; i += 1024) {
-        const int pos = best_pos[i];
+        const unsigned long long k = best[i];
         int found = -1;
-        if (pos != 0x7fffffff) {
+        if ((k & 0xffffffff00000000ull) == tag) {       // an accepted candidate of THIS frame
+            const int pos = (int)(unsigned)k;
             found = active[pos];
             active_last[pos] = f;             // several CCs may hit the same unique: same value
         }
         assign[c0 + i] = found;
     }
-    if (threadIdx.x == 0 && cnt->n_pairs > cap_pairs) s_overflow = 1;
     __syncthreads();
     // ---- optional compaction (entries that cannot be candidates at frame f + 1 any more)
     if (compact && f >= 1) {
@@ -394,7 +370,6 @@ __global__ void __launch_bounds__(1024) lm_k_update(const LmCcRec* __restrict__ 
             cnt->n_uniq = nU + (int)carry;
             cnt->n_active = nA + (int)carry;
             cnt->n_matched = f + 1;
-            cnt->n_pairs = 0;
         }
     }
 }

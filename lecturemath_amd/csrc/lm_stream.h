@@ -27,7 +27,7 @@ struct LmCounters {
     int n_uniq;
     int n_active;
     int error;           // sticky LM_ERR_* raised on device (capacity)
-    int n_pairs;         // candidate pairs of the frame being matched
+    int pad;
 };
 
 struct LmStream {
@@ -46,13 +46,17 @@ struct LmStream {
     int32_t* active_cc;         // global cc index of the unique's first-seen CC
     unsigned long long* active_box;   // min_x | max_x<<16 | min_y<<32 | max_y<<48
     int32_t* active_last;       // last frame the unique was matched
-    // per-frame candidate pairs (reused every frame)
-    int32_t* best_pos;          // [ctx cap] smallest accepted active-list position of the frame's i-th CC
-    int4* pairs;                // [cap_pairs] (cc index in frame, active-list position, unique's first-seen CC, 0), unordered
-    int cap_pairs;
+    // per-frame decisions (reused every frame; never re-initialised thanks to the frame tag)
+    unsigned long long* best;   // [ctx cap] frame tag << 32 | smallest accepted active-list position of the frame's i-th CC
     LmCounters* counters;       // device
     long long* batch_cc_base;   // [max_batch] staging for emit
     unsigned long long* batch_word_base;
+    // reusable device scratch (hipMalloc / hipFree are device-wide sync points: none in steady state)
+    void* rd_scratch;           // record packing for lm_stream_read
+    size_t rd_scratch_bytes;
+    void* garena;               // cached bump arena handed to lm_group_run
+    size_t garena_bytes;
+    int garena_busy;
     int frames_pushed;          // host-side mirrors (frames are pushed and matched in order)
     int frames_matched;
 };
