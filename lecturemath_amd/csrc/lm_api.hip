@@ -221,13 +221,11 @@ extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, i
         band_smem_configured = band_smem;
     }
 #endif
+    const unsigned long long magic_cpr = ((1ull << 40) / (unsigned)(g.WW * 4)) + 1, magic_ww = ((1ull << 40) / (unsigned)g.WW) + 1;
     hipLaunchKernelGGL(lm_k_band, dim3(nbands, n_frames), dim3(512), band_smem, st, d_binary, c->bits, c->starts, c->prefix, c->rowoff,
-                       c->band_runs, c->parent, c->band_fallback, g.W, g.H, g.WW, slot, g.cap, lm_debug_band_phases());
-    hipLaunchKernelGGL(lm_k_band_union_global, dim3(nbands, n_frames), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff,
+                       c->band_runs, c->parent, c->band_fallback, g.W, g.H, g.WW, slot, g.cap, lm_debug_band_phases(), magic_cpr, magic_ww);
+    hipLaunchKernelGGL(lm_k_seam_union, dim3(nbands, n_frames), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff,
                        c->band_fallback, c->parent, g.WW, g.H, g.cap);
-    if (nbands > 1)
-        hipLaunchKernelGGL(lm_k_seam_union, dim3(lm_blocks((long long)n_frames * (nbands - 1) * g.WW, 256)), dim3(256), 0, st,
-                           c->bits, c->starts, c->prefix, c->rowoff, c->parent, g.WW, g.H, g.cap, nbands - 1, n_frames);
     hipLaunchKernelGGL(lm_k_flatten_flag, dim3(nbands, n_frames), dim3(256), 0, st, c->parent, c->band_runs, c->rootbits, slot, g.cap, capw);
     hipLaunchKernelGGL(lm_k_rank, dim3(n_frames), dim3(1024), 0, st, c->rootbits, c->band_runs, c->wordprefix, c->band_base, c->n_labels,
                        nbands, slot, capw);

@@ -59,6 +59,11 @@ __global__ void __launch_bounds__(256) lm_k_threshold_invert(const float* __rest
 // ------------------------------------------------------------------------------------------------
 // K1 helper: non-zero bytes of a dword -> 4 bits (the bit packing itself is fused into lm_k_band)
 // ------------------------------------------------------------------------------------------------
+// n / d for n < 2^24, d < 2^16 with one 64-bit multiply: m = floor(2^40 / d) + 1 (host), q = (n * m) >> 40.
+// (Integer '/' is a 40-instruction (32-bit) or ~200-instruction (64-bit) software routine on the GPU; per-element divisions
+// made lm_k_write_labels and the pack loop of lm_k_band instruction-bound.)
+LM_DEV unsigned lm_fastdiv(unsigned n, unsigned long long m) { return (unsigned)(((unsigned long long)n * m) >> 40); }
+
 LM_DEV unsigned lm_nz_nibble(unsigned d)
 {
     // bit0 of every byte := OR of the byte's bits, then gather the four bits into a nibble
@@ -137,7 +142,8 @@ LM_DEV void lm_cell_contacts(const uint64_t* __restrict__ bits, const uint64_t* 
 __global__ void __launch_bounds__(512) lm_k_band(const uint8_t* __restrict__ img, uint64_t* __restrict__ bits, uint64_t* __restrict__ starts,
                                                  uint16_t* __restrict__ prefix, uint32_t* __restrict__ rowoff,
                                                  int32_t* __restrict__ band_runs, int32_t* __restrict__ parent,
-                                                 uint8_t* __restrict__ band_fallback, int W, int H, int WW, int slot, int cap, int phases)
+                                                 uint8_t* __restrict__ band_fallback, int W, int H, int WW, int slot, int cap, int phases,
+                                                 unsigned long long magic_cpr, unsigned long long magic_ww)
 {
     LM_DYN_SMEM(smem);
     const int b = blockIdx.y, band = blockIdx.x, nbands = gridDim.x;
@@ -167,7 +173,7 @@ __global__ void __launch_bounds__(512) lm_k_band(const uint8_t* __restrict__ img
                     const int c = c0 + k * (int)blockDim.x;
                     v[k] = make_uint4(0u, 0u, 0u, 0u);
                     if (c < total) {
-                        const int r = c / cpr, ch = c - r * cpr;
+                        const int r = (int)lm_fastdiv((unsigned)c, magic_cpr), ch = c - r * cpr;
                         if (ch * 16 < W) v[k] = *(const uint4*)(img + (row0 + r) * W + ch * 16);
                     }
                 }
@@ -175,7 +181,7 @@ __global__ void __launch_bounds__(512) lm_k_band(const uint8_t* __restrict__ img
                 for (int k = 0; k < 8; k++) {
                     const int c = c0 + k * (int)blockDim.x;
                     if (c < total) {
-                        const int r = c / cpr, ch = c - r * cpr;
+                        const int r = (int)lm_fastdiv((unsigned)c, magic_cpr), ch = c - r * cpr;
                         const unsigned m = lm_nz_nibble(v[k].x) | (lm_nz_nibble(v[k].y) << 4) | (lm_nz_nibble(v[k].z) << 8) | (lm_nz_nibble(v[k].w) << 12);
                         s_bits16[c] = (uint16_t)m;
                         g_bits16[(row0 + r) * cpr + ch] = (uint16_t)m;
@@ -249,7 +255,7 @@ __global__ void __launch_bounds__(512) lm_k_band(const uint8_t* __restrict__ img
     // Measured alternatives that were slower on MI355X (profiles/r01_label_experiments.md): run-centric parent stores +
     // barrier-separated pointer jumping + atomics only for merges (112 vs 76 us per 32 frames).
     for (int cell = threadIdx.x; cell < (nrows - 1) * WW; cell += blockDim.x) {
-        const int r = 1 + cell / WW, w = cell - (r - 1) * WW;
+        const int r = 1 + (int)lm_fastdiv((unsigned)cell, magic_ww), w = cell - (r - 1) * WW;
         const unsigned long long cur = s_bits[r * WW + w];
         if (!cur) continue;
         const unsigned long long v = cur & s_bits[(r - 1) * WW + w];
@@ -271,39 +277,26 @@ __global__ void __launch_bounds__(512) lm_k_band(const uint8_t* __restrict__ img
     for (int i = threadIdx.x; i < n; i += blockDim.x) par_g[i] = band * slot + lm_find(s_par, i);
 }
 
-// K4a': bands whose forest did not fit the LDS (very dense frames): the same unions with device-scope atomics.
-__global__ void __launch_bounds__(256) lm_k_band_union_global(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
-                                                              const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
-                                                              const uint8_t* __restrict__ band_fallback, int32_t* __restrict__ parent,
-                                                              int WW, int H, int cap)
+// K4b: seam rows between bands (device-scope atomics in L2), and -- for the rare bands whose forest did not fit the LDS
+// (very dense frames) -- all of the band's own contacts as well.  One block per (band, frame).
+__global__ void __launch_bounds__(256) lm_k_seam_union(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
+                                                       const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
+                                                       const uint8_t* __restrict__ band_fallback, int32_t* __restrict__ parent,
+                                                       int WW, int H, int cap)
 {
     const int b = blockIdx.y, band = blockIdx.x;
-    if (!band_fallback[b * gridDim.x + band]) return;
     const int y0 = band * LM_BAND_ROWS;
     const int y1 = (y0 + LM_BAND_ROWS < H) ? y0 + LM_BAND_ROWS : H;
     const long long row0 = (long long)b * H + y0;
     int32_t* par = parent + (long long)b * cap;
-    for (int cell = threadIdx.x; cell < (y1 - y0 - 1) * WW; cell += blockDim.x) {
-        const int r = cell / WW, w = cell - r * WW;
-        lm_cell_contacts(bits, starts, prefix, rowoff, row0 + 1 + r, w, WW, [&](int a, int c) { lm_union(par, a, c); });
-    }
-}
-
-__global__ void __launch_bounds__(256) lm_k_seam_union(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
-                                                       const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
-                                                       int32_t* __restrict__ parent, int WW, int H, int cap, int nseams, int B)
-{
-    // one thread per (frame, seam, word); seam k separates rows k*LM_BAND_ROWS-1 and k*LM_BAND_ROWS
-    long long total = (long long)B * nseams * WW;
-    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long long)gridDim.x * blockDim.x) {
-        int w = (int)(gid % WW);
-        long long t = gid / WW;
-        int k = (int)(t % nseams) + 1;
-        int b = (int)(t / nseams);
-        long long row = (long long)b * H + (long long)k * LM_BAND_ROWS;
-        int32_t* par = parent + (long long)b * cap;
-        lm_cell_contacts(bits, starts, prefix, rowoff, row, w, WW, [&](int a, int c) { lm_union(par, a, c); });
-    }
+    if (band > 0)       // contacts of the band's first row with the last row of the band above
+        for (int w = threadIdx.x; w < WW; w += blockDim.x)
+            lm_cell_contacts(bits, starts, prefix, rowoff, row0, w, WW, [&](int a, int c) { lm_union(par, a, c); });
+    if (band_fallback[b * gridDim.x + band])
+        for (int cell = threadIdx.x; cell < (y1 - y0 - 1) * WW; cell += blockDim.x) {
+            const int r = cell / WW, w = cell - r * WW;
+            lm_cell_contacts(bits, starts, prefix, rowoff, row0 + 1 + r, w, WW, [&](int a, int c) { lm_union(par, a, c); });
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -395,10 +388,6 @@ __global__ void __launch_bounds__(256) lm_k_apply_labels(const int32_t* __restri
 // (dependent) run-table lookups of the LM_WL_Q quads are independent of each other and issued phase by phase.
 // ------------------------------------------------------------------------------------------------
 #define LM_WL_Q 4
-
-// n / d for n < 2^24, d < 2^16 with one 64-bit multiply: m = floor(2^40 / d) + 1 (host), q = (n * m) >> 40.
-// (A plain 64-bit '/' is a ~200-instruction software routine on the GPU and made this kernel VALU bound.)
-LM_DEV unsigned lm_fastdiv(unsigned n, unsigned long long m) { return (unsigned)(((unsigned long long)n * m) >> 40); }
 
 __global__ void __launch_bounds__(256) lm_k_write_labels(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
                                                          const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,

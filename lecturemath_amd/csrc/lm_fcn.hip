@@ -389,10 +389,12 @@ template <int CK, int NT> static int lm_launch_conv_t(const LmConvArgs& a, hipSt
 
 static int lm_launch_conv(const LmConvArgs& a, int ck, hipStream_t st)
 {
-    // n-blocks per wave: as many as fit 160 KiB of LDS and divide the channel blocks evenly
+    // n-blocks per wave: as many as fit 160 KiB of LDS and divide the channel blocks evenly -- but the deep layers have few
+    // spatial tiles (33x60 -> 12), so fall back to a smaller NT until the grid has at least two blocks per CU
+    const int tiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
     int nt = 1;
     for (int cand : {4, 2}) {
-        if (a.nblocks % cand == 0 && lm_conv_smem(a.K, ck, cand) <= 150 * 1024) { nt = cand; break; }
+        if (a.nblocks % cand == 0 && lm_conv_smem(a.K, ck, cand) <= 150 * 1024 && tiles * (a.nblocks / cand) >= 512) { nt = cand; break; }
     }
     if (ck == 16) {
         if (nt == 4) return lm_launch_conv_t<16, 4>(a, st);

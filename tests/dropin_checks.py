@@ -130,3 +130,33 @@ def check_fcn_class(lib, name="k7_70x94"):
     assert worker.frame_times == [1000.0] and worker.frame_indices == [30] and worker.getWorkName()
     dec = png.decode_gray8(worker.compressed_frames[0])
     assert ((dec == 255 - g["binary"]) | edge).all()
+
+
+def check_fcn_4k_resize_branch(lib):
+    """binarize() on a 3840x2160 frame (> 2.5 MP, FCN_lecturenet.py:435-437,481-494): PIL LANCZOS halving, FCN at 1080p,
+    NEAREST x2 back -- against the oracle's torch forward on the same halved image.  Tiny network (the branch is about
+    the resize plumbing); pixels whose logit is within the fp32 tolerance of the threshold edge are exempt."""
+    use_library(lib)
+    import PIL.Image
+    import torch
+    from AM_CommonTools.configuration.configuration import Configuration
+    from AccessMath.lecturenet_v1.FCN_lecturenet import FCN_LectureNet
+    from lecturemath_amd import fcn, synth
+    from oracle import fcn as ofcn
+    widths = (8,) * 18
+    sd = ofcn.random_state_dict(widths, pixel_kernel=3, seed=5)
+    conf = Configuration({key: "8" for key, _ in fcn.WIDTH_KEYS})
+    net = FCN_LectureNet.CreateFromConfig(conf, 3, False)
+    net.load_state_dict(sd)
+    rgb, _ = synth.whiteboard_rgb(2160, 3840, n_glyphs=3000, seed=9)
+    pil = PIL.Image.fromarray(rgb)
+    binary, text_mask, rec_img = net.cuda().binarize(pil, return_others=True, force_binary=True)
+    assert binary.shape == (2160, 3840) and rec_img.shape == (2160, 3840, 3)
+    half = np.asarray(pil.resize((1920, 1080), PIL.Image.LANCZOS))
+    with torch.no_grad():
+        o, t, r = ofcn.forward(sd, ofcn.prepare_image(half))
+    exp = ((torch.sigmoid(o)[0, 0].numpy() * 255).astype(np.uint8) >= 128).astype(np.uint8) * 255
+    edge = np.abs(o[0, 0].numpy() - 0.01569) < 2e-3
+    up = lambda a: a[np.arange(2160) // 2][:, np.arange(3840) // 2]
+    assert ((binary == up(exp)) | up(edge)).all()
+    assert (binary[::2, ::2] == binary[1::2, 1::2]).all()          # NEAREST x2 structure

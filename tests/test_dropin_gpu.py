@@ -19,3 +19,7 @@ def test_steps_02_03(hip_lib, name):
 @pytest.mark.parametrize("name", ["k7_70x94", "k3_135x240"])
 def test_fcn_class_and_worker(hip_lib, name):
     dropin_checks.check_fcn_class(hip_lib, name)
+
+
+def test_fcn_4k_resize_branch(hip_lib):
+    dropin_checks.check_fcn_4k_resize_branch(hip_lib)
