@@ -44,6 +44,7 @@ struct LmConvArgs {
     int K;                              // kernel side (1, 3, 7), padding (K-1)/2
     int act;
     int tmode, dy, dx, OH, OW;          // transposed mode: input (y, x) -> output (2y+dy, 2x+dx) of an OH x OW grid
+    int tg;                             // f16x3 kernel: taps whose weights are staged together (divides K*K)
 };
 
 template <int CK, int NT>
@@ -146,6 +147,135 @@ __global__ void __launch_bounds__(256) lm_k_conv_mfma(const LmConvArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp16-split variant ("f16x3"): every fp32 operand is split as x = hi + lo with hi = (f16)x, lo = (f16)(x - hi) (about 22
+// significant bits together; products of two f16 are exact in fp32), and a.b is accumulated in fp32 as
+// hi_a.hi_b + hi_a.lo_b + lo_a.hi_b on v_mfma_f32_32x32x16_f16: 3 MFMAs of 32 cycles per 16 channels instead of 8 MFMAs of
+// 64 cycles -- 5.3x the fp32 MFMA rate at ~1e-6 relative error (the dropped lo.lo term is ~2^-22).
+// Same tiling as lm_k_conv_mfma; chunks are 16 logical channels; activations stay fp32 in HBM and are split while the
+// patch is staged (pixel stride in LDS: 16 hi + 16 lo halfs + 16 B pad = 80 B, conflict-free 16-B fragment reads);
+// weights are split and packed on the host: [chunk][tap][nblock][hi|lo][lane][8 halfs],
+// element j of lane l = W[co = nblock*32 + (l & 31)][ci = chunk*16 + 8*(l >> 5) + j].
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 lm_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 lm_h4 __attribute__((ext_vector_type(4)));
+
+#if LM_HIP_EMULATED
+lm_f32x16 hipemu_mfma_32x32x16f16(lm_h8 a, lm_h8 b, lm_f32x16 c);
+#define LM_MFMA_F16(a, b, c) hipemu_mfma_32x32x16f16(a, b, c)
+#else
+#define LM_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#endif
+
+template <int NT>
+__global__ void __launch_bounds__(256) lm_k_conv_mfma_h(const LmConvArgs a)
+{
+    LM_DYN_SMEM(smem);
+    constexpr int PB = 80;                  // bytes per pixel in LDS
+    const int K = a.K, pad = (K - 1) >> 1, taps = K * K;
+    const int PW = 16 + K - 1, PH = 16 + K - 1;
+    char* s_patch = smem;
+    char* s_w = s_patch + ((PH * PW * PB + 15) & ~15);          // [tap][NT][2][64] x 16 B
+    const int tiles_x = (a.W + 15) >> 4;
+    const int ty0 = (blockIdx.x / tiles_x) << 4, tx0 = (blockIdx.x % tiles_x) << 4;
+    const int nb0 = blockIdx.y * NT;
+    const int lane = lm_lane(), wave = (int)(threadIdx.x >> 6), half = lane >> 5;
+    const int ctot = a.c0 + a.c1;
+    const int nchunks = (ctot + 15) >> 4;
+
+    lm_f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][n][r] = 0.0f;
+    const int pi = lane & 31;
+    const int prow = wave * 4 + (pi >> 4), pcol = pi & 15;
+
+    for (int ch = 0; ch < nchunks; ch++) {
+        __syncthreads();
+        // ---- stage + split the input patch: 4 channels (one float4) per item, zero outside the image / channel range
+        for (int i = threadIdx.x; i < PH * PW * 4; i += blockDim.x) {
+            const int px = i >> 2, q = i & 3;
+            const int py = px / PW, pxx = px - py * PW;
+            const int y = ty0 + py - pad, x = tx0 + pxx - pad;
+            const int cl = ch * 16 + q * 4;                     // logical (concatenated) channel
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y >= 0 && y < a.H && x >= 0 && x < a.W && cl < ctot) {
+                const long long p = (long long)y * a.W + x;
+                v = (cl < a.c0) ? *(const float4*)(a.in0 + p * a.ps0 + cl) : *(const float4*)(a.in1 + p * a.ps1 + (cl - a.c0));
+            }
+            lm_h4 hi, lo;
+            hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+            lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
+            lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
+            *(lm_h4*)(s_patch + px * PB + q * 8) = hi;
+            *(lm_h4*)(s_patch + px * PB + 32 + q * 8) = lo;
+        }
+        // ---- weights are staged a.tg taps at a time (one kernel row for 7x7): a small LDS footprint lets ~3 blocks share a
+        // CU and hide each other's staging -- with f16 MFMAs the arithmetic of a chunk is shorter than its loads
+        for (int t0 = 0; t0 < taps; t0 += a.tg) {
+            if (t0) __syncthreads();
+            {
+                const uint4* wsrc = (const uint4*)a.wpk + (long long)ch * taps * a.nblocks * 128;
+                const int n16 = a.tg * NT * 128;
+                for (int i = threadIdx.x; i < n16; i += blockDim.x) {
+                    const int t = i / (NT * 128), rem = i - t * (NT * 128);
+                    const int nb = rem >> 7, u = rem & 127;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (nb0 + nb < a.nblocks) v = wsrc[(long long)((t0 + t) * a.nblocks + nb0 + nb) * 128 + u];
+                    *(uint4*)(s_w + (long long)i * 16) = v;
+                }
+            }
+            __syncthreads();
+            for (int tt = 0; tt < a.tg; tt++) {
+                const int t = t0 + tt;
+                const int kh = t / K, kw = t - kh * K;
+                lm_h8 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    const char* pp = s_patch + ((prow + m * 2 + kh) * PW + pcol + kw) * PB + half * 16;
+                    ah[m] = *(const lm_h8*)pp;
+                    al[m] = *(const lm_h8*)(pp + 32);
+                }
+#pragma unroll
+                for (int n = 0; n < NT; n++) {
+                    const char* wp = s_w + ((long long)(tt * NT + n) * 128 + lane) * 16;
+                    bh[n] = *(const lm_h8*)wp;
+                    bl[n] = *(const lm_h8*)(wp + 64 * 16);
+                }
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int n = 0; n < NT; n++) {
+                        acc[m][n] = LM_MFMA_F16(ah[m], bh[n], acc[m][n]);
+                        acc[m][n] = LM_MFMA_F16(ah[m], bl[n], acc[m][n]);
+                        acc[m][n] = LM_MFMA_F16(al[m], bh[n], acc[m][n]);
+                    }
+            }
+        }
+    }
+    const int cj = lane & 31;
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+        const int co = (nb0 + n) * 32 + cj;
+        if (nb0 + n >= a.nblocks || co >= a.Cout) continue;
+        const float b = a.bias[co];
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int y = ty0 + wave * 4 + m * 2 + (i >> 4), x = tx0 + (i & 15);
+                if (y >= a.H || x >= a.W) continue;
+                const float v = lm_act(acc[m][n][r] + b, a.act);
+                long long opix = a.tmode ? ((long long)(2 * y + a.dy) * a.OW + (2 * x + a.dx)) : ((long long)y * a.W + x);
+                a.out[opix * a.ops + a.ooff + co] = v;
+            }
+    }
+}
+
 // rows / columns of a transposed-conv output that no input pixel reaches (output_size = 2*in + 1): act(bias)
 __global__ void __launch_bounds__(256) lm_k_convT_border(float* out, int ops, int ooff, int OH, int OW, int H2, int W2, int Cout,
                                                          const float* __restrict__ bias, int act)
@@ -195,48 +325,78 @@ __global__ void __launch_bounds__(256) lm_k_prepare(const uint8_t* __restrict__ 
     }
 }
 
-// Direct convolution for Cout <= 4 (heads): one thread per output pixel, 16x16 px tile, input patch (all channels,
-// padded to a multiple of 4) and weights [tap][C][4] in LDS.
+// Direct convolution for Cout <= 4 (heads): 16 x TW px tile; the input patch is staged in LDS 8 channels at a time (pixel
+// stride 12 floats -> conflict-free 16-B reads) so that several blocks fit a CU and hide each other's LDS latency.
+// COUT == 1 (text mask, output logit): weights [chunk][tap][8], every thread computes TWO pixels 16 columns apart so one
+// weight read serves 8 FMAs.  COUT == 4 (3-channel reconstruction): weights [chunk][tap][8][4].
+template <int COUT>
 __global__ void __launch_bounds__(256) lm_k_conv_small(const float* __restrict__ in, int ips, int C, int H, int W,
-                                                       const float* __restrict__ w4, const float* __restrict__ bias, int K, int Cout,
+                                                       const float* __restrict__ wts, const float* __restrict__ bias, int K, int Cout,
                                                        int act, float* __restrict__ out, int ops)
 {
     LM_DYN_SMEM(smem);
-    const int pad = (K - 1) >> 1, taps = K * K, PW = 16 + K - 1, PH = 16 + K - 1;
-    const int CS = C + 4;                                   // padded pixel stride (floats)
+    constexpr int TW = (COUT == 1) ? 32 : 16;
+    constexpr int CS = 12;                                  // 8 channels + 4 pad (floats)
+    constexpr int WL = (COUT == 1) ? 1 : 4;                 // weight floats per (tap, channel)
+    const int pad = (K - 1) >> 1, taps = K * K, PW = TW + K - 1, PH = 16 + K - 1;
     float* s_patch = (float*)smem;
-    float* s_w = s_patch + PH * PW * CS;                    // [tap][C][4]
-    const int tiles_x = (W + 15) >> 4;
-    const int ty0 = (blockIdx.x / tiles_x) << 4, tx0 = (blockIdx.x % tiles_x) << 4;
-    for (int i = threadIdx.x; i < PH * PW * (C / 4); i += blockDim.x) {
-        const int px = i / (C / 4), q = i - px * (C / 4);
-        const int py = px / PW, pxx = px - py * PW;
-        const int y = ty0 + py - pad, x = tx0 + pxx - pad;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y >= 0 && y < H && x >= 0 && x < W) v = *(const float4*)(in + ((long long)y * W + x) * ips + q * 4);
-        *(float4*)(s_patch + px * CS + q * 4) = v;
-    }
-    for (int i = threadIdx.x; i < taps * C; i += blockDim.x) *(float4*)(s_w + i * 4) = *(const float4*)(w4 + (long long)i * 4);
-    __syncthreads();
+    float* s_w = s_patch + PH * PW * CS;                    // [tap][8][WL]
+    const int tiles_x = (W + TW - 1) / TW;
+    const int ty0 = (blockIdx.x / tiles_x) << 4, tx0 = (blockIdx.x % tiles_x) * TW;
     const int ly = (int)(threadIdx.x >> 4), lx = (int)(threadIdx.x & 15);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < taps; t++) {
-        const int kh = t / K, kw = t - kh * K;
-        const float* pp = s_patch + ((ly + kh) * PW + lx + kw) * CS;
-        const float* ww = s_w + (long long)t * C * 4;
-        for (int c = 0; c < C; c += 4) {
-            const float4 v = *(const float4*)(pp + c);
-            const float4 w0 = *(const float4*)(ww + (c + 0) * 4), w1 = *(const float4*)(ww + (c + 1) * 4),
-                         w2 = *(const float4*)(ww + (c + 2) * 4), w3 = *(const float4*)(ww + (c + 3) * 4);
-            acc[0] = fmaf(v.x, w0.x, acc[0]); acc[1] = fmaf(v.x, w0.y, acc[1]); acc[2] = fmaf(v.x, w0.z, acc[2]); acc[3] = fmaf(v.x, w0.w, acc[3]);
-            acc[0] = fmaf(v.y, w1.x, acc[0]); acc[1] = fmaf(v.y, w1.y, acc[1]); acc[2] = fmaf(v.y, w1.z, acc[2]); acc[3] = fmaf(v.y, w1.w, acc[3]);
-            acc[0] = fmaf(v.z, w2.x, acc[0]); acc[1] = fmaf(v.z, w2.y, acc[1]); acc[2] = fmaf(v.z, w2.z, acc[2]); acc[3] = fmaf(v.z, w2.w, acc[3]);
-            acc[0] = fmaf(v.w, w3.x, acc[0]); acc[1] = fmaf(v.w, w3.y, acc[1]); acc[2] = fmaf(v.w, w3.z, acc[2]); acc[3] = fmaf(v.w, w3.w, acc[3]);
+    float acc[(COUT == 1) ? 2 : 4];
+#pragma unroll
+    for (int i = 0; i < ((COUT == 1) ? 2 : 4); i++) acc[i] = 0.f;
+    for (int c0 = 0; c0 < C; c0 += 8) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < PH * PW * 2; i += blockDim.x) {
+            const int px = i >> 1, q = i & 1;
+            const int py = px / PW, pxx = px - py * PW;
+            const int y = ty0 + py - pad, x = tx0 + pxx - pad;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y >= 0 && y < H && x >= 0 && x < W) v = *(const float4*)(in + ((long long)y * W + x) * ips + c0 + q * 4);
+            *(float4*)(s_patch + px * CS + q * 4) = v;
+        }
+        const float* wsrc = wts + (long long)(c0 >> 3) * taps * 8 * WL;
+        for (int i = threadIdx.x; i < taps * 8 * WL / 4; i += blockDim.x) *(float4*)(s_w + i * 4) = *(const float4*)(wsrc + (long long)i * 4);
+        __syncthreads();
+        for (int t = 0; t < taps; t++) {
+            const int kh = t / K, kw = t - kh * K;
+            const float* p0 = s_patch + ((ly + kh) * PW + lx + kw) * CS;
+            if (COUT == 1) {
+                const float* p1 = p0 + 16 * CS;
+                const float4 wa = *(const float4*)(s_w + t * 8), wb = *(const float4*)(s_w + t * 8 + 4);
+                const float4 u0 = *(const float4*)p0, u1 = *(const float4*)(p0 + 4), v0 = *(const float4*)p1, v1 = *(const float4*)(p1 + 4);
+                acc[0] = fmaf(u0.x, wa.x, acc[0]); acc[0] = fmaf(u0.y, wa.y, acc[0]); acc[0] = fmaf(u0.z, wa.z, acc[0]); acc[0] = fmaf(u0.w, wa.w, acc[0]);
+                acc[0] = fmaf(u1.x, wb.x, acc[0]); acc[0] = fmaf(u1.y, wb.y, acc[0]); acc[0] = fmaf(u1.z, wb.z, acc[0]); acc[0] = fmaf(u1.w, wb.w, acc[0]);
+                acc[1] = fmaf(v0.x, wa.x, acc[1]); acc[1] = fmaf(v0.y, wa.y, acc[1]); acc[1] = fmaf(v0.z, wa.z, acc[1]); acc[1] = fmaf(v0.w, wa.w, acc[1]);
+                acc[1] = fmaf(v1.x, wb.x, acc[1]); acc[1] = fmaf(v1.y, wb.y, acc[1]); acc[1] = fmaf(v1.z, wb.z, acc[1]); acc[1] = fmaf(v1.w, wb.w, acc[1]);
+            } else {
+                const float* ww = s_w + t * 32;
+#pragma unroll
+                for (int c = 0; c < 8; c += 4) {
+                    const float4 v = *(const float4*)(p0 + c);
+                    const float4 w0 = *(const float4*)(ww + (c + 0) * 4), w1 = *(const float4*)(ww + (c + 1) * 4),
+                                 w2 = *(const float4*)(ww + (c + 2) * 4), w3 = *(const float4*)(ww + (c + 3) * 4);
+                    acc[0] = fmaf(v.x, w0.x, acc[0]); acc[1] = fmaf(v.x, w0.y, acc[1]); acc[2] = fmaf(v.x, w0.z, acc[2]); acc[3] = fmaf(v.x, w0.w, acc[3]);
+                    acc[0] = fmaf(v.y, w1.x, acc[0]); acc[1] = fmaf(v.y, w1.y, acc[1]); acc[2] = fmaf(v.y, w1.z, acc[2]); acc[3] = fmaf(v.y, w1.w, acc[3]);
+                    acc[0] = fmaf(v.z, w2.x, acc[0]); acc[1] = fmaf(v.z, w2.y, acc[1]); acc[2] = fmaf(v.z, w2.z, acc[2]); acc[3] = fmaf(v.z, w2.w, acc[3]);
+                    acc[0] = fmaf(v.w, w3.x, acc[0]); acc[1] = fmaf(v.w, w3.y, acc[1]); acc[2] = fmaf(v.w, w3.z, acc[2]); acc[3] = fmaf(v.w, w3.w, acc[3]);
+                }
+            }
         }
     }
-    const int y = ty0 + ly, x = tx0 + lx;
-    if (y < H && x < W)
-        for (int c = 0; c < Cout; c++) out[((long long)y * W + x) * ops + c] = lm_act(acc[c] + bias[c], act);
+    const int y = ty0 + ly;
+    if (y >= H) return;
+    if (COUT == 1) {
+        const float bb = bias[0];
+        if (tx0 + lx < W) out[((long long)y * W + tx0 + lx) * ops] = lm_act(acc[0] + bb, act);
+        if (tx0 + lx + 16 < W) out[((long long)y * W + tx0 + lx + 16) * ops] = lm_act(acc[1] + bb, act);
+    } else {
+        const int x = tx0 + lx;
+        if (x < W)
+            for (int c = 0; c < Cout; c++) out[((long long)y * W + x) * ops + c] = lm_act(acc[c] + bias[c], act);
+    }
 }
 
 // diff = (x0 - rec) * sigmoid(text)  (:379), written to channels 0..2 of three NHWC buffers
@@ -387,8 +547,43 @@ template <int CK, int NT> static int lm_launch_conv_t(const LmConvArgs& a, hipSt
     return LM_OK;
 }
 
+static int lm_conv_tg(int K) { return (K >= 5) ? K : K * K; }     // weights staged per kernel row for 5x5 / 7x7
+
+static size_t lm_conv_smem_h(int K, int NT)
+{
+    const int P = 16 + K - 1;
+    return (((size_t)P * P * 80 + 15) & ~(size_t)15) + (size_t)lm_conv_tg(K) * NT * 2048;
+}
+
+template <int NT> static int lm_launch_conv_h(const LmConvArgs& a, hipStream_t st)
+{
+    const size_t smem = lm_conv_smem_h(a.K, NT);
+#if !LM_HIP_EMULATED
+    static size_t configured = 0;
+    if (smem > configured) {
+        LM_HIP(hipFuncSetAttribute((const void*)lm_k_conv_mfma_h<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        configured = smem;
+    }
+#endif
+    const int tiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
+    LmConvArgs b = a;
+    b.tg = lm_conv_tg(a.K);
+    hipLaunchKernelGGL((lm_k_conv_mfma_h<NT>), dim3(tiles, (a.nblocks + NT - 1) / NT), dim3(256), smem, st, b);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
 static int lm_launch_conv(const LmConvArgs& a, int ck, hipStream_t st)
 {
+    if (ck == 0) {          // fp16-split packing
+        const int tiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
+        int nt = 1;
+        for (int cand : {4, 2})
+            if (a.nblocks % cand == 0 && lm_conv_smem_h(a.K, cand) <= 150 * 1024 && tiles * (a.nblocks / cand) >= 512) { nt = cand; break; }
+        if (nt == 4) return lm_launch_conv_h<4>(a, st);
+        if (nt == 2) return lm_launch_conv_h<2>(a, st);
+        return lm_launch_conv_h<1>(a, st);
+    }
     // n-blocks per wave: as many as fit 160 KiB of LDS and divide the channel blocks evenly -- but the deep layers have few
     // spatial tiles (33x60 -> 12), so fall back to a smaller NT until the grid has at least two blocks per CU
     const int tiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
@@ -424,7 +619,8 @@ static int lm_convT_layer(LmFcn* f, int layer, const float* in, int cin, int H, 
     const LmFcnLayer& l = f->layer[layer];
     if (!l.w) { lm_set_error("lm_fcn_forward: layer %d has no weights", layer); return LM_ERR_STATE; }
     const int nblocks = (l.cout + 31) / 32;
-    const long long per_set = (long long)(cin / l.ck) * (l.ck / 8) * nblocks * 256;
+    // floats per (dy, dx) weight set: fp32 packing [chunk][ks][nblock][64][4]; f16x3 packing [chunk][nblock][2][64] x 16 B
+    const long long per_set = l.ck ? (long long)(cin / l.ck) * (l.ck / 8) * nblocks * 256 : (long long)((cin + 15) / 16) * nblocks * 512;
     for (int d = 0; d < 4; d++) {
         LmConvArgs a;
         memset(&a, 0, sizeof(a));
@@ -442,23 +638,29 @@ static int lm_convT_layer(LmFcn* f, int layer, const float* in, int cin, int H, 
     return LM_OK;
 }
 
+template <int COUT> static int lm_small_launch(const LmFcnLayer& l, const float* in, int ips, int C, int H, int W, float* out, int ops, int act,
+                                               hipStream_t st)
+{
+    const int TW = (COUT == 1) ? 32 : 16;
+    const size_t smem = (size_t)(16 + l.k - 1) * (TW + l.k - 1) * 12 * 4 + (size_t)l.k * l.k * 8 * ((COUT == 1) ? 4 : 16);
+#if !LM_HIP_EMULATED
+    static size_t configured = 0;
+    if (smem > configured) {
+        LM_HIP(hipFuncSetAttribute((const void*)lm_k_conv_small<COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        configured = smem;
+    }
+#endif
+    const int tiles = ((W + TW - 1) / TW) * ((H + 15) / 16);
+    hipLaunchKernelGGL((lm_k_conv_small<COUT>), dim3(tiles), dim3(256), smem, st, in, ips, C, H, W, l.w, l.bias, l.k, l.cout, act, out, ops);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
 static int lm_small_layer(LmFcn* f, int layer, const float* in, int ips, int C, int H, int W, float* out, int ops, int act, hipStream_t st)
 {
     const LmFcnLayer& l = f->layer[layer];
     if (!l.w) { lm_set_error("lm_fcn_forward: layer %d has no weights", layer); return LM_ERR_STATE; }
-    const int P = 16 + l.k - 1;
-    const size_t smem = (size_t)P * P * (C + 4) * 4 + (size_t)l.k * l.k * C * 16;
-#if !LM_HIP_EMULATED
-    static size_t configured = 0;
-    if (smem > configured) {
-        LM_HIP(hipFuncSetAttribute((const void*)lm_k_conv_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        configured = smem;
-    }
-#endif
-    const int tiles = ((W + 15) / 16) * ((H + 15) / 16);
-    hipLaunchKernelGGL(lm_k_conv_small, dim3(tiles), dim3(256), smem, st, in, ips, C, H, W, l.w, l.bias, l.k, l.cout, act, out, ops);
-    LM_HIP(hipGetLastError());
-    return LM_OK;
+    return (l.cout == 1) ? lm_small_launch<1>(l, in, ips, C, H, W, out, ops, act, st) : lm_small_launch<4>(l, in, ips, C, H, W, out, ops, act, st);
 }
 
 // forward() of the non-reconstruction branch (:364-403) on one RGB frame resident on the device.

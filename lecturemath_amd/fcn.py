@@ -58,12 +58,33 @@ def pack_mfma(w_oikk, ck, cin_map, cin_padded):
     return np.ascontiguousarray(a).reshape(-1)
 
 
-def pack_small(w_oikk, cin_map, cin_padded):
-    """[Cout<=4][Cin][K][K] -> [tap][C padded][4]."""
+def pack_mfma_h(w_oikk, cin_map, cin_logical):
+    """fp16-split packing for lm_k_conv_mfma_h: [chunk][tap][nblock][hi|lo][lane 64][8 halfs], element j of lane l =
+    W[co = nblock*32 + (l & 31)][ci = chunk*16 + 8*(l >> 5) + j][tap]; hi = f16(w), lo = f16(w - hi).
+    cin_map[i] = position of weight input channel i among the cin_logical concatenated input channels (padded to 16 here).
+    Returned as a float32 view (two halfs per float) for lm_fcn_set_layer."""
     cout, cin, k, _ = w_oikk.shape
-    out = np.zeros((k * k, cin_padded, 4), np.float32)
+    nblocks = (cout + 31) // 32
+    cpad = ((cin_logical + 15) // 16) * 16
+    wp = np.zeros((nblocks * 32, cpad, k * k), np.float32)
+    wp[:cout][:, np.asarray(cin_map)] = w_oikk.reshape(cout, cin, k * k)
+    hi = wp.astype(np.float16)
+    lo = (wp - hi.astype(np.float32)).astype(np.float16)
+    both = np.stack([hi, lo])                                           # hl, co, ci, tap
+    a = both.reshape(2, nblocks, 32, cpad // 16, 2, 8, k * k)          # hl, nb, j, chunk, half, e, tap
+    a = a.transpose(3, 6, 1, 0, 4, 2, 5)                                # chunk, tap, nb, hl, half, j, e
+    return np.ascontiguousarray(a).reshape(-1).view(np.float32)
+
+
+def pack_small(w_oikk, cin_map, cin_padded):
+    """[Cout<=4][Cin][K][K] -> [chunk of 8 channels][tap][8] for Cout == 1, [chunk][tap][8][4] otherwise (lm_k_conv_small)."""
+    cout, cin, k, _ = w_oikk.shape
+    lanes = 1 if cout == 1 else 4
+    assert cin_padded % 8 == 0
+    out = np.zeros((k * k, cin_padded, lanes), np.float32)
     out[:, np.asarray(cin_map), :cout] = w_oikk.reshape(cout, cin, k * k).transpose(2, 1, 0)
-    return out.reshape(-1)
+    out = out.reshape(k * k, cin_padded // 8, 8, lanes).transpose(1, 0, 2, 3)
+    return np.ascontiguousarray(out).reshape(-1)
 
 
 def _pad8(c):
@@ -73,7 +94,11 @@ def _pad8(c):
 class FcnEngine:
     """Device network built from a reference state_dict."""
 
-    def __init__(self, widths, pixel_kernel, kernel, max_h, max_w, lib=None):
+    def __init__(self, widths, pixel_kernel, kernel, max_h, max_w, lib=None, precision="f16x3"):
+        """precision: "f16x3" (default; fp16-split operands, three f16 MFMAs per product, fp32 accumulate, ~1e-6 relative
+        error at 5x the fp32 MFMA rate) or "fp32" (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains)."""
+        assert precision in ("f16x3", "fp32")
+        self.precision = precision
         self.lib = lib or _lib.load()
         self.be = Backend(self.lib)
         self.widths = [int(v) for v in widths]
@@ -116,16 +141,25 @@ class FcnEngine:
         def ck_for(*chans):
             return 16 if all(c % 16 == 0 for c in chans) else 8
 
+        h = self.precision == "f16x3"
+
+        def mfma(w, cin_map, cin_padded):
+            """(packed weights, ck): ck = 0 selects the fp16-split kernel"""
+            if h:
+                return pack_mfma_h(w, cin_map, sum(cin_padded) if isinstance(cin_padded, tuple) else cin_padded), 0
+            ck = ck_for(cin_padded) if not isinstance(cin_padded, tuple) else ck_for(*cin_padded)
+            return pack_mfma(w, ck, cin_map, cin_padded if not isinstance(cin_padded, tuple) else sum(cin_padded)), ck
+
         # encoder + mid (layer 1 sees the 3 RGB channels padded to 8)
         cin = [3] + downs
         for n in range(5):
             w, b = conv_bn("conv_down_block_%d" % (n + 1))
             cpad = 8 if n == 0 else cin[n]
-            ck = ck_for(cpad)
-            self._set(L_DOWN + n, pack_mfma(w, ck, range(cin[n]), cpad), bias_pad(b), cpad, downs[n], self.kk, ck)
+            wpk, ck = mfma(w, range(cin[n]), cpad)
+            self._set(L_DOWN + n, wpk, bias_pad(b), cpad, downs[n], self.kk, ck)
         w, b = conv_bn("mid_block")
-        ck = ck_for(d5)
-        self._set(L_MID, pack_mfma(w, ck, range(d5), d5), bias_pad(b), d5, mid, self.kk, ck)
+        wpk, ck = mfma(w, range(d5), d5)
+        self._set(L_MID, wpk, bias_pad(b), d5, mid, self.kk, ck)
         # decoder: level 5 .. 1
         ups = {5: (mid, u5, c5, d5), 4: (c5, u4, c4, d4), 3: (c4, u3, c3, d3), 2: (c3, u2, c2, d2), 1: (c2, u1, c1, d1)}
         for i, lvl in enumerate((5, 4, 3, 2, 1)):
@@ -133,13 +167,11 @@ class FcnEngine:
             wt = _np(sd["transposed_conv_%d.weight" % lvl]).astype(np.float32)          # [Cin][Cout][2][2]
             bt = _np(sd["transposed_conv_%d.bias" % lvl]).astype(np.float32)
             wt, bt = fold_bn(wt, bt, sd, "upsample_block_%d.0" % lvl, 1)
-            ck = ck_for(tin)
-            sets = [pack_mfma(np.ascontiguousarray(wt[:, :, dy, dx].T)[:, :, None, None], ck, range(tin), tin)
-                    for dy in (0, 1) for dx in (0, 1)]
-            self._set(L_UPT + i, np.concatenate(sets), bias_pad(bt), tin, u, 1, ck)
+            sets = [mfma(np.ascontiguousarray(wt[:, :, dy, dx].T)[:, :, None, None], range(tin), tin) for dy in (0, 1) for dx in (0, 1)]
+            self._set(L_UPT + i, np.concatenate([p for p, _ in sets]), bias_pad(bt), tin, u, 1, sets[0][1])
             w, b = conv_bn("conv_up_block_%d" % lvl)                                      # input = cat(up, skip_pre)
-            ck = ck_for(u, skip)
-            self._set(L_UPC + i, pack_mfma(w, ck, range(u + skip), u + skip), bias_pad(b), u + skip, c, self.kk, ck)
+            wpk, ck = mfma(w, range(u + skip), (u, skip))
+            self._set(L_UPC + i, wpk, bias_pad(b), u + skip, c, self.kk, ck)
         # heads: inputs are (diff | features | zero pad) buffers
         s0, s1, s2 = _pad8(3 + c1), _pad8(3 + pm1), _pad8(3 + pm2)
         w, b = conv_bn("conv_text_mask_out")
@@ -147,9 +179,11 @@ class FcnEngine:
         w, b = conv_bn("conv_reconstruct")
         self._set(L_REC, pack_small(w, range(3, 3 + c1), s0), np.pad(b, (0, 4 - len(b))), s0, 3, self.kk, 0)
         w, b = conv_bn("conv_pixels_1")
-        self._set(L_PX1, pack_mfma(w, 8, range(3 + c1), s0), bias_pad(b), s0, pm1, self.pk, 8)
+        wpk, ck = (pack_mfma_h(w, range(3 + c1), s0), 0) if h else (pack_mfma(w, 8, range(3 + c1), s0), 8)
+        self._set(L_PX1, wpk, bias_pad(b), s0, pm1, self.pk, ck)
         w, b = conv_bn("conv_pixels_2")
-        self._set(L_PX2, pack_mfma(w, 8, range(3 + pm1), s1), bias_pad(b), s1, pm2, self.pk, 8)
+        wpk, ck = (pack_mfma_h(w, range(3 + pm1), s1), 0) if h else (pack_mfma(w, 8, range(3 + pm1), s1), 8)
+        self._set(L_PX2, wpk, bias_pad(b), s1, pm2, self.pk, ck)
         w, b = conv_bn("conv_out")
         self._set(L_OUT, pack_small(w, range(3 + pm2), s2), np.pad(b, (0, 4 - len(b))), s2, 1, self.pk, 0)
 

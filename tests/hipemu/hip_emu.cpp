@@ -219,3 +219,35 @@ lm_f32x4 hipemu_mfma_16x16x4f32(float a, float b, lm_f32x4 c)
     }
     return c;
 }
+
+// v_mfma_f32_32x32x16_f16: lane l holds A[row l&31][k = 8*(l>>5) + j] and B[k = 8*(l>>5) + j][col l&31], j = 0..7
+// (cdna_hip_programming.md section 3, bf16 map; the f16 form uses the same one); products exact in fp32, fp32 accumulate.
+typedef _Float16 emu_h8 __attribute__((ext_vector_type(8)));
+lm_f32x16 hipemu_mfma_32x32x16f16(emu_h8 a, emu_h8 b, lm_f32x16 c)
+{
+    static thread_local _Float16 A[64][8], B[64][8];
+    unsigned long long raw[4];
+    memcpy(raw, &a, 16);
+    memcpy(raw + 2, &b, 16);
+    unsigned long long act;
+    const int lane = hipemu::lane_id();
+    // four 8-byte gathers (the rendezvous returns every lane's value)
+    unsigned long long all[4][64];
+    for (int q = 0; q < 4; q++) {
+        const unsigned long long* v = hipemu::wave_gather(raw[q], &act);
+        memcpy(all[q], v, sizeof(all[q]));
+    }
+    for (int l = 0; l < 64; l++) {
+        memcpy(&A[l][0], &all[0][l], 8); memcpy(&A[l][4], &all[1][l], 8);
+        memcpy(&B[l][0], &all[2][l], 8); memcpy(&B[l][4], &all[3][l], 8);
+    }
+    const int col = lane & 31;
+    for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        for (int h = 0; h < 2; h++)
+            for (int j = 0; j < 8; j++) acc += (float)A[row + 32 * h][j] * (float)B[col + 32 * h][j];
+        c[r] = acc;
+    }
+    return c;
+}

@@ -159,14 +159,14 @@ def check_grouping_golden(lib, name, max_batch=16):
         fs.close()
 
 
-def check_fcn_golden(lib, name, tol=1e-3):
+def check_fcn_golden(lib, name, tol=1e-3, precision="f16x3"):
     """HIP FCN forward vs the reference module's outputs (G5 fixture); tolerance 1e-3 on logits (BASELINE.json)."""
     from lecturemath_amd import fcn
     g = np.load(os.path.join(GOLD, "g5_fcn_%s.npz" % name))
     sd = {k[3:]: g[k] for k in g.files if k.startswith("sd.")}
     rgb = g["rgb"]
     h, w = rgb.shape[:2]
-    eng = fcn.FcnEngine(g["widths"], int(g["pk"]), 3, h, w, lib)
+    eng = fcn.FcnEngine(g["widths"], int(g["pk"]), 3, h, w, lib, precision=precision)
     try:
         eng.load_state_dict(sd)
         out, text, rec = (eng.be.to_host(t) for t in eng.forward(rgb))

@@ -106,13 +106,16 @@ def test_grouping_golden(hip_lib, name):
     lm_checks.check_grouping_golden(hip_lib, name)
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
 @pytest.mark.parametrize("name", ["k7_70x94", "k3_135x240", "k7_66x130_wide"])
-def test_fcn_golden(hip_lib, name):
-    """FCN-LectureNet forward (fp32 MFMA conv stack) vs the reference module: max |logit diff| <= 1e-3."""
-    assert lm_checks.check_fcn_golden(hip_lib, name) < 1e-4
+def test_fcn_golden(hip_lib, name, precision):
+    """FCN-LectureNet forward (MFMA conv stack, both operand precisions) vs the reference module: max |logit diff| <= 1e-3
+    required by BASELINE.json; 1e-4 demanded here."""
+    assert lm_checks.check_fcn_golden(hip_lib, name, precision=precision) < 1e-4
 
 
-def test_fcn_shipped_config_vs_oracle(hip_lib):
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_fcn_shipped_config_vs_oracle(hip_lib, precision):
     """The shipped network widths (configs/FCN_LectureNet.conf:109-132, 15.8 M parameters, 7x7 pixel convs) on an
     odd-sized 270x478 frame (exercises every output_size padding) against the torch fp32 oracle."""
     import torch
@@ -120,7 +123,7 @@ def test_fcn_shipped_config_vs_oracle(hip_lib):
     from oracle import fcn as ofcn
     sd = ofcn.random_state_dict(ofcn.SHIPPED_WIDTHS, pixel_kernel=7, seed=0)
     rgb, _ = synth.whiteboard_rgb(270, 478, n_glyphs=120, seed=4)
-    eng = fcn.FcnEngine(ofcn.SHIPPED_WIDTHS, 7, 3, 270, 478, hip_lib)
+    eng = fcn.FcnEngine(ofcn.SHIPPED_WIDTHS, 7, 3, 270, 478, hip_lib, precision=precision)
     eng.load_state_dict(sd)
     out, text, rec = (t.cpu().numpy() for t in eng.forward(rgb))
     with torch.no_grad():

@@ -80,5 +80,6 @@ def test_grouping_golden_short_gap(emu_lib):
     lm_checks.check_grouping_golden(emu_lib, "short_gap_jitter")
 
 
-def test_fcn_golden_tiny(emu_lib):
-    assert lm_checks.check_fcn_golden(emu_lib, "k7_70x94") < 1e-4
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_fcn_golden_tiny(emu_lib, precision):
+    assert lm_checks.check_fcn_golden(emu_lib, "k7_70x94", precision=precision) < 1e-4
