@@ -126,7 +126,7 @@ extern "C" void lm_ctx_destroy(LmCtx* c)
 {
     if (!c) return;
     lm_profile_free(c);
-    void* ptrs[] = {c->bits, c->starts, c->prefix, c->rowoff, c->band_runs, c->band_base, c->band_fallback, c->parent, c->final_label,
+    void* ptrs[] = {c->bits, c->starts, c->prefix, c->rowoff, c->band_runs, c->band_base, c->band_roots, c->band_fallback, c->parent, c->final_label,
                     c->n_labels, c->rootbits, c->wordprefix, c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x, c->st_count, c->kept_label,
                     c->kept_cropoff, c->frame_kept, c->frame_cropwords, c->stage_u8, c->stage_i32, c->stage_f32};
     for (void* p : ptrs)
@@ -159,6 +159,7 @@ extern "C" LmCtx* lm_ctx_create(int width, int height, int max_batch)
     rc |= lm_alloc(&c->rowoff, R);
     rc |= lm_alloc(&c->band_runs, (size_t)max_batch * c->nbands);
     rc |= lm_alloc(&c->band_base, (size_t)max_batch * c->nbands);
+    rc |= lm_alloc(&c->band_roots, (size_t)max_batch * c->nbands);
     rc |= lm_alloc(&c->band_fallback, (size_t)max_batch * c->nbands);
     rc |= lm_alloc(&c->parent, BC);
     rc |= lm_alloc(&c->final_label, BC);
@@ -226,11 +227,10 @@ extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, i
                        c->band_runs, c->parent, c->band_fallback, g.W, g.H, g.WW, slot, g.cap, lm_debug_band_phases(), magic_cpr, magic_ww);
     hipLaunchKernelGGL(lm_k_seam_union, dim3(nbands, n_frames), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff,
                        c->band_fallback, c->parent, g.WW, g.H, g.cap);
-    hipLaunchKernelGGL(lm_k_flatten_flag, dim3(nbands, n_frames), dim3(256), 0, st, c->parent, c->band_runs, c->rootbits, slot, g.cap, capw);
-    hipLaunchKernelGGL(lm_k_rank, dim3(n_frames), dim3(1024), 0, st, c->rootbits, c->band_runs, c->wordprefix, c->band_base, c->n_labels,
-                       nbands, slot, capw);
+    hipLaunchKernelGGL(lm_k_flatten_flag, dim3(nbands, n_frames), dim3(256), 0, st, c->parent, c->band_runs, c->rootbits, c->wordprefix,
+                       c->band_roots, slot, g.cap, capw);
     hipLaunchKernelGGL(lm_k_apply_labels, dim3(nbands, n_frames), dim3(256), 0, st, c->parent, c->band_runs, c->rootbits, c->wordprefix,
-                       c->band_base, c->final_label, slot, g.cap, capw);
+                       c->band_roots, c->band_base, c->n_labels, c->final_label, slot, g.cap, capw);
     if (d_labels) {
         const unsigned Q = (unsigned)(g.W + 3) / 4;
         const unsigned long long magic_q = ((1ull << 40) / Q) + 1;       // lm_fastdiv: exact for H * Q < 2^24

@@ -306,79 +306,83 @@ __global__ void __launch_bounds__(256) lm_k_seam_union(const uint64_t* __restric
 //   K5b  per frame: exclusive scan of the root-mask popcounts                  one block per frame
 //   K5c  final[i] = rank(root(i)) + 1                                          grid (x, B)
 // ------------------------------------------------------------------------------------------------
+// K5a: one block per (band, frame): flatten, root flags (one ballot per 64 runs), and -- since the block sees all of its
+// band's flags -- the exclusive popcount prefix of the band's 64-run words and the band's root count.
 __global__ void __launch_bounds__(256) lm_k_flatten_flag(int32_t* __restrict__ parent, const int32_t* __restrict__ band_runs,
-                                                         unsigned long long* __restrict__ rootbits, int slot, int cap, int capw)
+                                                         unsigned long long* __restrict__ rootbits, uint32_t* __restrict__ wordprefix,
+                                                         uint32_t* __restrict__ band_roots, int slot, int cap, int capw)
 {
     const int b = blockIdx.y, band = blockIdx.x;
     const int n = band_runs[b * gridDim.x + band];
     int32_t* par = parent + (long long)b * cap;
     unsigned long long* rb = rootbits + (long long)b * capw + (band * slot >> 6);
+    uint32_t* wp = wordprefix + (long long)b * capw + (band * slot >> 6);
     const int lane = lm_lane();
-    for (int base = (int)(threadIdx.x & ~63u); base < n; base += (int)blockDim.x) {
-        const int i = base + lane;
-        bool flag = false;
-        if (i < n) {
-            const int gid = band * slot + i;
-            const int r = lm_find(par, gid);
-            par[gid] = r;
-            flag = (r == gid);
-        }
-        const unsigned long long m = __ballot(flag);
-        if (lane == 0) rb[base >> 6] = m;
-    }
-}
-
-// per frame: roots before every 64-run word (band-relative) and roots before every band; n_labels.  One block per frame.
-__global__ void __launch_bounds__(1024) lm_k_rank(const unsigned long long* __restrict__ rootbits, const int32_t* __restrict__ band_runs,
-                                                  uint32_t* __restrict__ wordprefix, uint32_t* __restrict__ band_base,
-                                                  int32_t* __restrict__ n_labels, int nbands, int slot, int capw)
-{
-    __shared__ unsigned s_tot[1024];       // roots per band (nbands <= 1024: frames up to 65536 rows)
-    const int b = blockIdx.x;
-    const int lane = lm_lane(), wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6);
-    for (int band = wave; band < nbands; band += nwaves) {
-        const int nw = (band_runs[b * nbands + band] + 63) >> 6;
-        const unsigned long long* rb = rootbits + (long long)b * capw + (band * slot >> 6);
-        uint32_t* wp = wordprefix + (long long)b * capw + (band * slot >> 6);
-        unsigned running = 0;
-        for (int w0 = 0; w0 < nw; w0 += 64) {
-            const int j = w0 + lane;
-            const unsigned v = (j < nw) ? (unsigned)__popcll(rb[j]) : 0u;
-            const unsigned incl = lm_wave_incl_scan(v);
-            if (j < nw) wp[j] = running + incl - v;
-            running += __shfl(incl, 63);
-        }
-        if (lane == 0) s_tot[band] = running;
-    }
-    __syncthreads();
+    __shared__ unsigned s_pc[256];
     unsigned carry = 0;
-    for (int base = 0; base < nbands; base += 1024) {
-        const int j = base + (int)threadIdx.x;
-        const unsigned v = (j < nbands) ? s_tot[j] : 0u;
+    const int wave = (int)(threadIdx.x >> 6);
+    for (int base = 0; base < n; base += 256 * 64) {          // 256 words of 64 runs per pass, words dealt round-robin to the waves
+        s_pc[threadIdx.x] = 0;
+        __syncthreads();
+        for (int k = 0; k < 64; k++) {
+            const int word = k * 4 + wave;                     // word index inside this pass
+            const int i0 = base + word * 64;
+            if (i0 >= n) break;                                // wave-uniform
+            const int i = i0 + lane;
+            bool flag = false;
+            if (i < n) {
+                const int gid = band * slot + i;
+                const int r = lm_find(par, gid);
+                par[gid] = r;
+                flag = (r == gid);
+            }
+            const unsigned long long m = __ballot(flag);
+            if (lane == 0) { rb[i0 >> 6] = m; s_pc[word] = (unsigned)__popcll(m); }
+        }
+        __syncthreads();
         unsigned tot;
-        const unsigned ex = lm_block_excl_scan<1024>(v, &tot);
-        if (j < nbands) band_base[b * nbands + j] = carry + ex;
+        const unsigned ex = lm_block_excl_scan<256>(s_pc[threadIdx.x], &tot);
+        const int myword = (base >> 6) + (int)threadIdx.x;
+        if (myword * 64 < n) wp[myword] = carry + ex;
         carry += tot;
     }
-    if (threadIdx.x == 0) n_labels[b] = (int32_t)carry;
+    if (threadIdx.x == 0) band_roots[b * gridDim.x + band] = carry;
 }
 
+// K5b: final[i] = (roots in the bands above) + (roots before the run's root inside its band) + 1.  One block per
+// (band, frame); the band bases are a 64-wide scan of the per-band root counts; block 0 of a frame also writes n_labels.
 __global__ void __launch_bounds__(256) lm_k_apply_labels(const int32_t* __restrict__ parent, const int32_t* __restrict__ band_runs,
                                                          const unsigned long long* __restrict__ rootbits,
-                                                         const uint32_t* __restrict__ wordprefix, const uint32_t* __restrict__ band_base,
+                                                         const uint32_t* __restrict__ wordprefix, const uint32_t* __restrict__ band_roots,
+                                                         uint32_t* __restrict__ band_base, int32_t* __restrict__ n_labels,
                                                          int32_t* __restrict__ final_label, int slot, int cap, int capw)
 {
+    __shared__ unsigned s_base[1024];
     const int b = blockIdx.y, band = blockIdx.x, nbands = gridDim.x;
+    // exclusive scan of the frame's band root counts (nbands <= 1024), redundantly per block: a few hundred loads from L2
+    unsigned carry = 0;
+    for (int base = 0; base < nbands; base += 256) {
+        const int j = base + (int)threadIdx.x;
+        const unsigned v = (j < nbands) ? band_roots[b * nbands + j] : 0u;
+        unsigned tot;
+        const unsigned ex = lm_block_excl_scan<256>(v, &tot);
+        if (j < nbands) s_base[j] = carry + ex;
+        carry += tot;
+    }
+    __syncthreads();
+    if (band == 0) {
+        for (int j = threadIdx.x; j < nbands; j += blockDim.x) band_base[b * nbands + j] = s_base[j];
+        if (threadIdx.x == 0) n_labels[b] = (int32_t)carry;
+    }
     const int n = band_runs[b * nbands + band];
     const int32_t* par = parent + (long long)b * cap;
     const unsigned long long* rb = rootbits + (long long)b * capw;
     const uint32_t* wp = wordprefix + (long long)b * capw;
-    const uint32_t* bb = band_base + b * nbands;
     int32_t* fin = final_label + (long long)b * cap;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int gid = band * slot + i;
         const int r = par[gid];
-        fin[gid] = (int32_t)(bb[r / slot] + wp[r >> 6] + (unsigned)__popcll(rb[r >> 6] & lm_lowmask_excl(r & 63)) + 1u);
+        fin[gid] = (int32_t)(s_base[r / slot] + wp[r >> 6] + (unsigned)__popcll(rb[r >> 6] & lm_lowmask_excl(r & 63)) + 1u);
     }
 }
 
@@ -445,7 +449,10 @@ __global__ void __launch_bounds__(256) lm_k_write_labels(const uint64_t* __restr
             if (gid < total) {
                 int32_t* dst = lab_frame + y[k] * (unsigned)W + x[k];
                 if (vec) {
-                    *(int4*)dst = make_int4(o0, o1, o2, o3);
+                    typedef int lm_i4 __attribute__((ext_vector_type(4)));
+                    lm_i4 v;
+                    v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
+                    __builtin_nontemporal_store(v, (lm_i4*)dst);      // write-once stream: keep it out of the L2 working set
                 } else {
                     const int oo[4] = {o0, o1, o2, o3};
                     for (unsigned j = 0; j < 4 && x[k] + j < (unsigned)W; j++) dst[j] = oo[j];

@@ -60,6 +60,7 @@ struct LmCtx {
     uint32_t* rowoff;        // [R] band * slot + runs of the band above the row
     int32_t* band_runs;      // [B][nbands] runs per band
     uint32_t* band_base;     // [B][nbands] labels (roots) in the bands above
+    uint32_t* band_roots;    // [B][nbands] roots per band
     uint8_t* band_fallback;  // [B][nbands] 1 = forest too large for LDS, unions done in L2
     int nbands, slot;        // bands of LM_BAND_ROWS rows; slot = id space per band (worst-case runs, multiple of 64)
     int32_t* parent;         // [B][cap]
