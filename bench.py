@@ -269,7 +269,7 @@ def main():
         tj = json.load(open(tpath))     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch sequence (not collectable live)
         traffic = int(tj["traffic_bytes_per_frame"] * frames_per_launch)
         traffic_src = "profiles/r01_label_traffic_pmc.json (separate rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes, gfx950 FETCH x2 correction on the image read)"
-    roofline = {"bound": "hbm", "kernel": "lm_label_batch[lm_k_band+lm_k_band_union_global+lm_k_seam_union+lm_k_flatten_flag+lm_k_rank+lm_k_apply_labels+lm_k_write_labels]",
+    roofline = {"bound": "hbm", "kernel": "lm_label_batch[lm_k_band+lm_k_seam_union+lm_k_flatten_flag+lm_k_apply_labels+lm_k_write_labels]",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_src, "launch_ms": round(launch_ms, 4), "frames_per_launch": frames_per_launch,
                 "algorithmic_bytes_per_launch": int(algo_bytes), "label_image_written": labels is not None}
