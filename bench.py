@@ -208,6 +208,8 @@ def main():
         pending = [None] * depth
         info = None
         for i in range(k):
+            if os.environ.get("LM_BENCH_VERBOSE"):
+                sys.stderr.write("step %d starts at %.3f ms\n" % (i, time.perf_counter() * 1e3))
             sl = slots[i % depth]
             if pending[i % depth] is not None:
                 info = pending[i % depth].result()          # the slot's previous step must be finished before it is reused

@@ -112,6 +112,10 @@ int lm_stream_push(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* 
 int lm_stream_push_records(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* d_labels, void* stream);
 int lm_stream_match(LmStream* s, int n_frames, void* stream);
 
+/* Diagnostic: sizes of the last batch handed to the batched matcher (lm_match_batch.hip):
+ * out5 = {in-batch sources, CC tiles, pairs against earlier uniques, pairs against in-batch sources, frames}. Synchronises. */
+int lm_stream_match_stats(LmStream* s, int64_t* out5, void* stream);
+
 /* Synchronise and read the stream's counters: out[0]=n_frames, [1]=n_cc, [2]=n_crop_words, [3]=n_unique,
  * [4]=n_active, [5]=tempo_count, [6]=device error code. */
 int lm_stream_counters(LmStream* s, int64_t* h_out7, void* stream);

@@ -12,6 +12,7 @@
 
 #include "lm_cc_kernels.hip"
 #include "lm_match_kernels.hip"
+#include "lm_match_batch.hip"
 #include "lm_group.hip"
 #include "lm_fcn.hip"
 
@@ -382,6 +383,14 @@ extern "C" void lm_stream_destroy(LmStream* s)
                     s->batch_cc_base, s->batch_word_base};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (s->mb) {
+        LmMatchBatch* m = s->mb;
+        void* mp[] = {m->ftile, m->s_prefix, m->tcount[0], m->tcount[1], m->toff[0], m->toff[1], m->pairs[0], m->pairs[1], m->pair_u[0],
+                      m->pair_u[1], m->sidx, m->s_list, m->s_box, m->newpos, m->n_src};
+        for (void* p : mp)
+            if (p) (void)hipFree(p);
+        delete m;
+    }
     if (s->rd_scratch) (void)hipFree(s->rd_scratch);
     if (s->garena) (void)hipFree(s->garena);
     delete s;
@@ -436,6 +445,36 @@ extern "C" LmStream* lm_stream_create(LmCtx* ctx, int max_frames, int64_t max_cc
     rc |= lm_alloc(&s->counters, (size_t)1);
     rc |= lm_alloc(&s->batch_cc_base, (size_t)ctx->max_batch);
     rc |= lm_alloc(&s->batch_word_base, (size_t)ctx->max_batch);
+    {
+        LmMatchBatch* m = new LmMatchBatch();
+        memset(m, 0, sizeof(*m));
+        s->mb = m;
+        m->cap_tiles = (int)(max_ccs / LM_MB_TILE) + max_frames + 2;
+        long long cp = 16 * (long long)max_ccs;
+        if (cp < (1 << 16)) cp = 1 << 16;
+        if (cp > (1 << 23)) cp = 1 << 23;
+        m->cap_pairs = (uint32_t)cp;
+        rc |= lm_alloc(&m->ftile, (size_t)max_frames + 2);
+        rc |= lm_alloc(&m->s_prefix, (size_t)max_frames + 2);
+        for (int k = 0; k < 2; k++) {
+            rc |= lm_alloc(&m->tcount[k], (size_t)m->cap_tiles + 1);
+            rc |= lm_alloc(&m->toff[k], (size_t)m->cap_tiles + 1);
+            rc |= lm_alloc(&m->pairs[k], (size_t)m->cap_pairs);
+            rc |= lm_alloc(&m->pair_u[k], (size_t)m->cap_pairs);
+        }
+        rc |= lm_alloc(&m->sidx, (size_t)max_ccs);
+        rc |= lm_alloc(&m->s_list, (size_t)max_ccs);
+        rc |= lm_alloc(&m->s_box, (size_t)max_ccs);
+        rc |= lm_alloc(&m->newpos, (size_t)max_ccs);
+        rc |= lm_alloc(&m->n_src, (size_t)1);
+#if !LM_HIP_EMULATED
+        if (rc == LM_OK &&
+            hipFuncSetAttribute((const void*)lm_k_mb_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LM_MB_RESOLVE_SMEM) != hipSuccess)
+            rc = LM_ERR_HIP;
+#endif
+        const char* e = getenv("LM_MATCH_PER_FRAME");
+        s->match_per_frame = (e && atoi(e) == 1) ? 1 : 0;
+    }
     if (rc == LM_OK) rc = lm_stream_reset(s, nullptr);
     if (rc == LM_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = LM_ERR_HIP;
     if (rc != LM_OK) {
@@ -452,6 +491,36 @@ static void lm_launch_match(LmStream* s, int f, hipStream_t st)
     // compact the active list every 16 frames (purely an optimisation: retirement is evaluated lazily)
     hipLaunchKernelGGL(lm_k_update, dim3(1), dim3(1024), 0, st, s->cc, s->frame_cc_off, f, s->active, s->active_cc, s->active_box,
                        s->active_last, s->counters, s->assign, s->best, s->max_gap, s->cap_uniq, (f & 15) == 15 ? 1 : 0);
+}
+
+// Matches frames [f0, f0 + n) (all emitted already) in chunks of at most LM_MB_MAX_FRAMES frames.
+static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st)
+{
+    if (s->match_per_frame) {
+        for (int i = 0; i < n; i++) lm_launch_match(s, f0 + i, st);
+        return;
+    }
+    const LmMatchBatch mb = *s->mb;
+    const dim3 gj(LM_HIP_EMULATED ? 2 : 1024), ge(LM_HIP_EMULATED ? 2 : 2048);
+    for (int done = 0; done < n;) {
+        const int B = (n - done < LM_MB_MAX_FRAMES) ? n - done : LM_MB_MAX_FRAMES;
+        const int f = f0 + done;
+        s->last_match_frames = B;
+        hipLaunchKernelGGL(lm_k_mb_prologue, dim3(1), dim3(1024), 0, st, s->frame_cc_off, f, B, s->active, s->active_cc, s->active_box,
+                           s->active_last, s->counters, mb, s->max_gap);
+        hipLaunchKernelGGL((lm_k_mb_join<0, 0>), gj, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->counters, mb);
+        hipLaunchKernelGGL((lm_k_mb_join<0, 1>), gj, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->counters, mb);
+        hipLaunchKernelGGL((lm_k_mb_eval<0>), ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->active_last, s->counters, mb,
+                           s->min_recall, s->min_precision, s->max_gap);
+        hipLaunchKernelGGL(lm_k_mb_sources, dim3(1), dim3(1024), 0, st, s->cc, s->frame_cc_off, f, B, s->counters, mb);
+        hipLaunchKernelGGL((lm_k_mb_join<1, 0>), gj, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->counters, mb);
+        hipLaunchKernelGGL((lm_k_mb_join<1, 1>), gj, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->counters, mb);
+        hipLaunchKernelGGL((lm_k_mb_eval<1>), ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->active_last, s->counters, mb,
+                           s->min_recall, s->min_precision, s->max_gap);
+        hipLaunchKernelGGL(lm_k_mb_resolve, dim3(1), dim3(1024), LM_MB_RESOLVE_SMEM, st, s->cc, s->frame_cc_off, f, B, s->active, s->active_cc,
+                           s->active_box, s->active_last, s->counters, s->assign, mb, s->max_gap, s->cap_uniq);
+        done += B;
+    }
 }
 
 static int lm_stream_push_impl(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* d_labels, int do_match, void* stream)
@@ -485,7 +554,7 @@ static int lm_stream_push_impl(LmStream* s, const uint8_t* d_binary, int n_frame
                            c->frame_kept, s->batch_cc_base, s->batch_word_base, s->cc, s->crop, s->frames_pushed, g.WW, g.H,
                            g.cap);
         if (do_match) {
-            for (int b = 0; b < B; b++) lm_launch_match(s, s->frames_pushed + b, st);
+            lm_launch_match_frames(s, s->frames_pushed, B, st);
             s->frames_matched += B;
         }
         LM_HIP(hipGetLastError());
@@ -511,9 +580,32 @@ extern "C" int lm_stream_match(LmStream* s, int n_frames, void* stream)
         lm_set_error("lm_stream_match: %d frames requested, %d pushed, %d matched", n_frames, s ? s->frames_pushed : 0, s ? s->frames_matched : 0);
         return LM_ERR_ARG;
     }
-    for (int i = 0; i < n_frames; i++) lm_launch_match(s, s->frames_matched + i, (hipStream_t)stream);
+    lm_launch_match_frames(s, s->frames_matched, n_frames, (hipStream_t)stream);
     s->frames_matched += n_frames;
     LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+// Diagnostic: sizes of the LAST matching batch {sources, tiles, pairs vs earlier uniques, pairs vs in-batch sources, frames}.
+extern "C" int lm_stream_match_stats(LmStream* s, int64_t* out5, void* stream)
+{
+    if (!s || !out5 || !s->mb) { lm_set_error("lm_stream_match_stats: bad arguments"); return LM_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const LmMatchBatch* m = s->mb;
+    const int B = s->last_match_frames;
+    int32_t nsrc = 0, nt = 0;
+    uint32_t ta = 0, tb = 0;
+    if (B > 0) {
+        LM_HIP(hipMemcpyAsync(&nsrc, m->n_src, 4, hipMemcpyDeviceToHost, st));
+        LM_HIP(hipMemcpyAsync(&nt, m->ftile + B, 4, hipMemcpyDeviceToHost, st));
+        LM_HIP(hipStreamSynchronize(st));
+        if (nt > 0) {
+            LM_HIP(hipMemcpyAsync(&ta, m->toff[0] + nt, 4, hipMemcpyDeviceToHost, st));
+            LM_HIP(hipMemcpyAsync(&tb, m->toff[1] + nt, 4, hipMemcpyDeviceToHost, st));
+            LM_HIP(hipStreamSynchronize(st));
+        }
+    }
+    out5[0] = nsrc; out5[1] = nt; out5[2] = ta; out5[3] = tb; out5[4] = B;
     return LM_OK;
 }
 

@@ -139,5 +139,39 @@ template <int BLOCK> LM_DEV unsigned lm_block_excl_scan(unsigned v, unsigned* to
     return res;
 }
 
+// Workgroup barrier that only orders LDS traffic: waits for this wave's outstanding LDS operations (lgkmcnt), not for its
+// global loads / stores (vmcnt) as __syncthreads() does.  For phases that communicate through LDS alone while global loads
+// (prefetch) and write-through stores stay in flight.
+LM_DEV void lm_lds_barrier()
+{
+#if LM_HIP_EMULATED
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+// lm_block_excl_scan with LDS-only barriers (the scan itself communicates through LDS only).
+template <int BLOCK> LM_DEV unsigned lm_block_excl_scan_lds(unsigned v, unsigned* total)
+{
+    __shared__ unsigned wsum[BLOCK / 64];
+    __shared__ unsigned wtot;
+    const int lane = lm_lane(), wid = (int)(threadIdx.x >> 6);
+    unsigned incl = lm_wave_incl_scan(v);
+    if (lane == 63) wsum[wid] = incl;
+    lm_lds_barrier();
+    if (wid == 0) {
+        unsigned t = (lane < BLOCK / 64) ? wsum[lane] : 0u;
+        unsigned ti = lm_wave_incl_scan(t);
+        if (lane < BLOCK / 64) wsum[lane] = ti - t;
+        if (lane == BLOCK / 64 - 1) wtot = ti;
+    }
+    lm_lds_barrier();
+    unsigned res = wsum[wid] + incl - v;
+    *total = wtot;
+    lm_lds_barrier();
+    return res;
+}
+
 LM_DEV uint64_t lm_lowmask_incl(int p) { return (p >= 63) ? ~0ull : ((1ull << (p + 1)) - 1ull); }
 LM_DEV uint64_t lm_lowmask_excl(int p) { return (p <= 0) ? 0ull : ((p >= 64) ? ~0ull : ((1ull << p) - 1ull)); }

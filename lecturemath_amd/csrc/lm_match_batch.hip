@@ -1,0 +1,550 @@
+// lm_match_batch.hip -- temporal CC matching for a whole batch of frames in a constant number of launches.
+//
+// Replaces (paths relative to /root/reference/ACCESS2021_release) CCStabilityEstimator.add_frame,
+// content/cc_stability_estimator.py:41-155, for frames f0 .. f0+B-1 at once.  What makes that legal:
+//   * whether a current CC c and a unique u "match" (getOverlapFMeasure + the recall/precision thresholds, :92-99) is a
+//     function of the two bit crops alone (the unique keeps its FIRST-seen CC, :110-123) -- no stream state involved;
+//   * the state only decides WHICH uniques are candidates at frame f: those that exist (created in an earlier frame) and
+//     have not been retired (:126-145), and the first accepted one in ascending unique index wins (:84-108).
+// So the expensive part (box join + AND/popcount on the crops) runs for all B frames in wide launches, and only a cheap
+// replay of the decisions -- list lookups, no pixels -- is sequential over the frames, inside ONE workgroup:
+//   P  lm_k_mb_prologue   compact the active list (entries retired before f0), tile table (64 CCs per tile, tiles never
+//                         straddle a frame), reset per-batch tables
+//   A  lm_k_mb_join<0,*>  (tile of 64 CCs) x (uniques active at f0): count pass, then fill pass (exact offsets, no
+//                         atomics between workgroups: one workgroup owns a tile)
+//   E  lm_k_mb_eval<0>    every pair, 8 lanes each: overlap + float64 thresholds -> accepted bit; a CC with an accepted
+//                         candidate that stays alive whatever happens in the batch is "surely matched"
+//   S  lm_k_mb_sources    the other CCs of the batch are the only ones that CAN become new uniques: compact them (S)
+//   B  lm_k_mb_join<1,*> + lm_k_mb_eval<1>: the same join against S, restricted to sources of EARLIER frames
+//   C  lm_k_mb_resolve    frames in order: a pair counts if its unique exists and is alive; smallest accepted active
+//                         position per CC (ascending unique index == the reference's first match) or a new unique,
+//                         numbered in CC order; `last` and the active list are updated as the reference does.
+// In-batch uniques get active positions behind all earlier ones in creation order, so "smallest position" is still
+// "smallest unique index".  tempo_count (:85) counts the same (cur, alive unique) box pairs as the per-frame kernels.
+#include "lm_stream.h"
+
+#define LM_MB_TILE 64
+#define LM_MB_CHUNK 4096        // source boxes filtered per round (LDS survivors list)
+#define LM_MB_MAX_FRAMES 64     // frames per batch (per-frame tables of the replay kernel live in LDS)
+#define LM_MB_CH 4096           // CCs of one frame resolved per LDS pass
+#define LM_MB_LA 16384          // active positions whose last-matched frame is cached in LDS by the replay kernel
+#define LM_MB_LS 16384          // sources whose active position is cached in LDS by the replay kernel
+#define LM_MB_PF 8              // pairs per thread and list prefetched one frame ahead
+#define LM_MB_RESOLVE_SMEM ((size_t)LM_MB_CH * 4 + (size_t)LM_MB_LA * 4 + (size_t)LM_MB_LS * 4)
+
+struct LmMatchBatch {
+    int32_t* ftile;             // [cap_frames + 2] first tile of every frame of the batch; ftile[B] = number of tiles
+    int32_t* s_prefix;          // [cap_frames + 2] number of sources that belong to frames before frame b of the batch
+    uint32_t* tcount[2];        // [cap_tiles + 1]  pairs per tile (A: vs actives, B: vs in-batch sources)
+    uint32_t* toff[2];          // [cap_tiles + 1]  exclusive prefix, toff[nt] = total
+    uint2* pairs[2];            // x = (cc - C0) | accepted << 31, y = active position (A) / source index (B)
+    int32_t* pair_u[2];         // cc index of the unique's first-seen CC (what the pair is evaluated against)
+    int32_t* sidx;              // [cap_cc] per global cc: -2 undecided, -1 surely matched; after lm_k_mb_sources: k >= 0 index into
+                                // the source list, or -1 - (number of sources before this CC)
+    int32_t* s_list;            // [cap_cc] cc index of source k (ascending)
+    unsigned long long* s_box;  // packed box of source k
+    int32_t* newpos;            // active position source k was given when it became a unique, else -1
+    int32_t* n_src;             // [1]
+    uint32_t cap_pairs;
+    int cap_tiles;
+};
+
+LM_DEV bool lm_mb_alive(int f, int last, int max_gap) { return f <= 1 || (f - 1) - last < max_gap; }
+
+// ------------------------------------------------------------------------------------------------
+// P: one block.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) lm_k_mb_prologue(const long long* __restrict__ frame_cc_off, int f0, int B,
+                                                         int32_t* __restrict__ active, int32_t* __restrict__ active_cc,
+                                                         unsigned long long* __restrict__ active_box, int32_t* __restrict__ active_last,
+                                                         LmCounters* __restrict__ cnt, LmMatchBatch mb, int max_gap)
+{
+    if (cnt->error) return;
+    // ---- drop actives that cannot be candidates at f0 (order preserved)
+    int nA = cnt->n_active;
+    if (f0 > 1) {
+        unsigned kept = 0;
+        for (int base = 0; base < nA; base += 1024 * LM_UPD_ITEMS) {
+            int32_t u[LM_UPD_ITEMS], uc[LM_UPD_ITEMS], ul[LM_UPD_ITEMS];
+            unsigned long long ub[LM_UPD_ITEMS];
+            unsigned keep[LM_UPD_ITEMS], mine = 0;
+#pragma unroll
+            for (int k = 0; k < LM_UPD_ITEMS; k++) {
+                int i = base + (int)threadIdx.x * LM_UPD_ITEMS + k;
+                keep[k] = 0;
+                if (i < nA) {
+                    u[k] = active[i]; uc[k] = active_cc[i]; ub[k] = active_box[i]; ul[k] = active_last[i];
+                    keep[k] = lm_mb_alive(f0, ul[k], max_gap) ? 1u : 0u;
+                }
+                mine += keep[k];
+            }
+            unsigned tot;
+            unsigned ex = lm_block_excl_scan<1024>(mine, &tot);   // barriers inside: this pass's reads precede its writes
+            unsigned o = kept + ex;
+#pragma unroll
+            for (int k = 0; k < LM_UPD_ITEMS; k++)
+                if (keep[k]) { active[o] = u[k]; active_cc[o] = uc[k]; active_box[o] = ub[k]; active_last[o] = ul[k]; o++; }
+            kept += tot;
+        }
+        nA = (int)kept;
+    }
+    // ---- tile table
+    const int b = threadIdx.x;
+    unsigned nt_b = 0;
+    if (b < B) nt_b = (unsigned)((frame_cc_off[f0 + b + 1] - frame_cc_off[f0 + b] + LM_MB_TILE - 1) / LM_MB_TILE);
+    unsigned nt;
+    unsigned ex = lm_block_excl_scan<1024>(nt_b, &nt);
+    if (b < B) mb.ftile[b] = (int32_t)ex;
+    if (b == 0) {
+        mb.ftile[B] = (int32_t)nt;
+        *mb.n_src = 0;
+        cnt->n_active = nA;
+        if ((int)nt > mb.cap_tiles) cnt->error = LM_ERR_CAPACITY;
+    }
+    if ((int)nt > mb.cap_tiles) return;
+    for (unsigned t = threadIdx.x; t <= nt; t += 1024) { mb.tcount[0][t] = 0; mb.tcount[1][t] = 0; }
+    const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
+    for (long long i = C0 + threadIdx.x; i < C1; i += 1024) mb.sidx[i] = -2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A / B: box join of one tile of CCs against a source list.  SRC 0: actives; SRC 1: in-batch sources of earlier frames
+// (a prefix of the ascending source list).  256 threads = 64 CCs x 4 quarters of the surviving sources.  Sources are first
+// filtered against the tile's union box (CCs are in raster order of their first pixel, so 64 consecutive ones cover a
+// thin strip of the frame).
+// ------------------------------------------------------------------------------------------------
+LM_DEV int lm_mb_tile_frame(const int32_t* __restrict__ ftile, int B, int t)
+{
+    int lo = 0, hi = B;       // largest b with ftile[b] <= t (frames without CCs own no tile and are skipped by the search)
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (ftile[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <int SRC, int FILL>
+__global__ void __launch_bounds__(256) lm_k_mb_join(const LmCcRec* __restrict__ cc, const long long* __restrict__ frame_cc_off, int f0,
+                                                    int B, const unsigned long long* __restrict__ active_box,
+                                                    const int32_t* __restrict__ active_cc, LmCounters* __restrict__ cnt, LmMatchBatch mb)
+{
+    __shared__ unsigned long long s_sbox[LM_MB_CHUNK];
+    __shared__ int s_spos[LM_MB_CHUNK];
+    __shared__ int s_ub[4];
+    __shared__ int s_nsurv;
+    __shared__ unsigned s_count;
+    if (cnt->error) return;
+    const int nt = mb.ftile[B];
+    const unsigned long long* src_box = SRC == 0 ? active_box : mb.s_box;
+    const int32_t* src_cc = SRC == 0 ? active_cc : mb.s_list;
+    const long long C0 = frame_cc_off[f0];
+    const int ccl = (int)(threadIdx.x & 63), q = (int)(threadIdx.x >> 6);
+    for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+        const int b = lm_mb_tile_frame(mb.ftile, B, t);
+        const int n_src = SRC == 0 ? cnt->n_active : mb.s_prefix[b];
+        const long long cf0 = frame_cc_off[f0 + b], cf1 = frame_cc_off[f0 + b + 1];
+        const long long c_first = cf0 + (long long)(t - mb.ftile[b]) * LM_MB_TILE;
+        const int ncc = (cf1 - c_first < LM_MB_TILE) ? (int)(cf1 - c_first) : LM_MB_TILE;
+        __syncthreads();        // previous tile done with the shared scalars
+        if (threadIdx.x == 0) { s_ub[0] = 0x7fff; s_ub[1] = -1; s_ub[2] = 0x7fff; s_ub[3] = -1; s_count = 0; }
+        unsigned off = 0;
+        if (FILL) {
+            // exclusive prefix of the tile counts, recomputed by the owner (a few hundred tiles per batch)
+            unsigned part = 0;
+            for (int i = threadIdx.x; i < t; i += 256) part += mb.tcount[SRC][i];
+            unsigned tot;
+            (void)lm_block_excl_scan<256>(part, &tot);
+            off = tot;
+        }
+        __syncthreads();
+        unsigned long long mybox = 0;
+        const bool have = ccl < ncc;
+        if (have) {
+            const LmCcRec r = cc[c_first + ccl];
+            mybox = lm_pack_box(r);
+            if (q == 0) {
+                atomicMin(&s_ub[0], (int)r.min_x); atomicMax(&s_ub[1], (int)r.max_x);
+                atomicMin(&s_ub[2], (int)r.min_y); atomicMax(&s_ub[3], (int)r.max_y);
+            }
+        }
+        __syncthreads();
+        const unsigned long long ubox = (unsigned long long)(unsigned short)s_ub[0] | ((unsigned long long)(unsigned short)s_ub[1] << 16) |
+                                        ((unsigned long long)(unsigned short)s_ub[2] << 32) | ((unsigned long long)(unsigned short)s_ub[3] << 48);
+        const unsigned tc = FILL ? mb.tcount[SRC][t] : 0u;
+        if (FILL && threadIdx.x == 0) {
+            if ((unsigned long long)off + tc > mb.cap_pairs) cnt->error = LM_ERR_CAPACITY;
+            mb.toff[SRC][t] = off;
+            if (t == nt - 1) mb.toff[SRC][nt] = off + tc;
+        }
+        const bool room = !FILL || (unsigned long long)off + tc <= mb.cap_pairs;
+        unsigned mycount = 0;
+        for (int base = 0; base < n_src; base += LM_MB_CHUNK) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_nsurv = 0;
+            __syncthreads();
+#pragma unroll 4
+            for (int k = 0; k < LM_MB_CHUNK / 256; k++) {
+                const int i = base + k * 256 + (int)threadIdx.x;
+                if (i < n_src) {
+                    const unsigned long long sb = src_box[i];
+                    if (lm_box_hit_packed(ubox, sb)) {
+                        const int slot = atomicAdd(&s_nsurv, 1);
+                        s_sbox[slot] = sb;
+                        s_spos[slot] = i;
+                    }
+                }
+            }
+            __syncthreads();
+            const int ns = s_nsurv;
+            // the wave's trip count is uniform (q and ns are), so the hits of one trip can share one LDS slot allocation
+            for (int j = q; j < ns; j += 4) {
+                const bool hit = have && lm_box_hit_packed(mybox, s_sbox[j]);
+                if (FILL) {
+                    const unsigned long long bal = __ballot(hit);
+                    if (bal) {
+                        unsigned basep = 0;
+                        if (lm_lane() == 0) basep = atomicAdd(&s_count, (unsigned)__popcll(bal));
+                        basep = (unsigned)__shfl((int)basep, 0);
+                        if (hit && room) {
+                            const unsigned slot = off + basep + (unsigned)__popcll(bal & lm_lowmask_excl(lm_lane()));
+                            const int pos = s_spos[j];
+                            mb.pairs[SRC][slot] = make_uint2((unsigned)(c_first + ccl - C0), (unsigned)pos);
+                            mb.pair_u[SRC][slot] = src_cc[pos];
+                        }
+                    }
+                } else {
+                    mycount += hit ? 1u : 0u;
+                }
+            }
+        }
+        if (!FILL) {
+            if (mycount) atomicAdd(&s_count, mycount);
+            __syncthreads();
+            if (threadIdx.x == 0) mb.tcount[SRC][t] = s_count;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// E: evaluate every pair (8 lanes each).
+// ------------------------------------------------------------------------------------------------
+template <int SRC>
+__global__ void __launch_bounds__(256) lm_k_mb_eval(const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
+                                                    const long long* __restrict__ frame_cc_off, int f0, int B,
+                                                    const int32_t* __restrict__ active_last, LmCounters* __restrict__ cnt,
+                                                    LmMatchBatch mb, double min_recall, double min_precision, int max_gap)
+{
+    if (cnt->error) return;
+    const int nt = mb.ftile[B];
+    const unsigned total = nt > 0 ? mb.toff[SRC][nt] : 0u;
+    const long long C0 = frame_cc_off[f0];
+    const int sub = (int)(threadIdx.x & 7);
+    const unsigned grp = (blockIdx.x * 256u + threadIdx.x) >> 3, ngrp = (gridDim.x * 256u) >> 3;
+    const unsigned rounds = (total + ngrp - 1) / ngrp;      // whole waves stay in the loop for the shuffles
+    for (unsigned it = 0; it < rounds; it++) {
+        const unsigned p = it * ngrp + grp;
+        const bool live = p < total;
+        int m = 0;
+        LmCcRec rec, urec;
+        uint2 pr = make_uint2(0u, 0u);
+        long long ci = 0;
+        if (live) {
+            pr = mb.pairs[SRC][p];
+            const int ui = mb.pair_u[SRC][p];
+            ci = C0 + (long long)pr.x;
+            rec = cc[ci];
+            urec = cc[ui];
+            const LmIsect is = lm_isect(rec, urec);
+            // lane `sub` takes rows sub, sub + 8, ... of the intersection (no integer divisions)
+            for (int y = is.y0 + sub; y <= is.y1; y += 8) {
+                const unsigned long long ra = rec.crop_off + (unsigned long long)((y - rec.min_y) * is.anw + (is.wc0 - is.awx0));
+                const unsigned long long ru = urec.crop_off + (unsigned long long)((y - urec.min_y) * is.unw + (is.wc0 - is.uwx0));
+                for (int j = 0; j < is.nwc; j++) m += __popc(crop[ra + j] & crop[ru + j]);
+            }
+        }
+#pragma unroll
+        for (int d = 4; d >= 1; d >>= 1) m += __shfl_xor(m, d, 8);
+        if (live && sub == 0 && lm_accept(m, rec.size, urec.size, min_recall, min_precision)) {
+            mb.pairs[SRC][p].x = pr.x | 0x80000000u;
+            // alive at rec.frame even if the unique is never matched again: c cannot become a new unique
+            if (SRC == 0 && lm_mb_alive(rec.frame, active_last[pr.y], max_gap)) mb.sidx[ci] = -1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S: compact the CCs that are not surely matched.  One block; 32 CCs per thread and pass, all loads of a pass in flight
+// together, positions from per-wave ballots.
+// ------------------------------------------------------------------------------------------------
+#define LM_MB_SRC_R 32
+
+__global__ void __launch_bounds__(1024) lm_k_mb_sources(const LmCcRec* __restrict__ cc, const long long* __restrict__ frame_cc_off,
+                                                        int f0, int B, LmCounters* __restrict__ cnt, LmMatchBatch mb)
+{
+    __shared__ unsigned s_tab[LM_MB_SRC_R * 16];
+    __shared__ unsigned s_tot;
+    if (cnt->error) return;
+    const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
+    const int lane = lm_lane(), wid = (int)(threadIdx.x >> 6);
+    unsigned carry = 0;
+    for (long long base = C0; base < C1; base += 1024 * LM_MB_SRC_R) {
+        int v[LM_MB_SRC_R];
+#pragma unroll
+        for (int k = 0; k < LM_MB_SRC_R; k++) {
+            const long long i = base + (long long)k * 1024 + threadIdx.x;
+            v[k] = (i < C1) ? mb.sidx[i] : 0;
+        }
+        unsigned fm = 0;
+#pragma unroll
+        for (int k = 0; k < LM_MB_SRC_R; k++) {
+            const int flag = v[k] == -2;
+            fm |= (unsigned)flag << k;
+            const unsigned long long bal = __ballot(flag);
+            if (lane == 0) s_tab[k * 16 + wid] = (unsigned)__popcll(bal);
+        }
+        __syncthreads();
+        if (wid == 0) {     // exclusive scan of the 512 (pass-row, wave) counts: 8 per lane
+            unsigned loc[8], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { loc[j] = s_tab[lane * 8 + j]; sum += loc[j]; }
+            const unsigned incl = lm_wave_incl_scan(sum);
+            unsigned run = incl - sum;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { s_tab[lane * 8 + j] = run; run += loc[j]; }
+            if (lane == 63) s_tot = incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LM_MB_SRC_R; k++) {
+            const int flag = (int)((fm >> k) & 1u);
+            const unsigned long long bal = __ballot(flag);
+            const long long i = base + (long long)k * 1024 + threadIdx.x;
+            if (i < C1) {
+                const unsigned o = carry + s_tab[k * 16 + wid] + (unsigned)__popcll(bal & lm_lowmask_excl(lane));
+                if (flag) {
+                    mb.sidx[i] = (int32_t)o;
+                    mb.s_list[o] = (int32_t)i;
+                    mb.s_box[o] = lm_pack_box(cc[i]);
+                    mb.newpos[o] = -1;
+                } else {
+                    mb.sidx[i] = -1 - (int32_t)o;
+                }
+            }
+        }
+        carry += s_tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *mb.n_src = (int)carry;
+    // sources that belong to frames before frame b: the count in front of the frame's first CC
+    if ((int)threadIdx.x <= B) {
+        const long long i = frame_cc_off[f0 + threadIdx.x];
+        int pfx = (int)carry;
+        if (i < C1) { const int sv = mb.sidx[i]; pfx = sv >= 0 ? sv : -1 - sv; }
+        mb.s_prefix[threadIdx.x] = pfx;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C: replay the frames in order.  One block.  Everything the replay re-reads lives in LDS: the last-matched frame per
+// active position, the active position of every source, the per-frame pair ranges; a frame's pair lists (and the source
+// indices of its CCs) are fetched into registers while the previous frame is being decided.  Global state is written
+// through as the replay goes (positions / sources beyond the LDS tables fall back to it).
+// ------------------------------------------------------------------------------------------------
+#define LM_MB_ITEMS (LM_MB_CH / 1024)
+
+LM_DEV void lm_mb_prefetch(const LmMatchBatch& mb, unsigned pA0, unsigned pA1, unsigned pB0, unsigned pB1, long long c_abs0, int n,
+                           uint2 (&ra)[LM_MB_PF], uint2 (&rb)[LM_MB_PF], int (&rs)[LM_MB_ITEMS])
+{
+#pragma unroll
+    for (int k = 0; k < LM_MB_PF; k++) {
+        const unsigned pa = pA0 + (unsigned)k * 1024u + threadIdx.x, pb = pB0 + (unsigned)k * 1024u + threadIdx.x;
+        ra[k] = (pa < pA1) ? mb.pairs[0][pa] : make_uint2(0u, 0xffffffffu);
+        rb[k] = (pb < pB1) ? mb.pairs[1][pb] : make_uint2(0u, 0xffffffffu);
+    }
+#pragma unroll
+    for (int k = 0; k < LM_MB_ITEMS; k++) {
+        const int i = (int)threadIdx.x * LM_MB_ITEMS + k;
+        rs[k] = (i < n && n <= LM_MB_CH) ? mb.sidx[c_abs0 + i] : -1;
+    }
+}
+
+LM_DEV void lm_mb_pair_old(uint2 pr, int f, int max_gap, unsigned rel0, unsigned* s_best, const int* s_last,
+                           const int32_t* __restrict__ active_last, unsigned& tempo)
+{
+    const int last = pr.y < LM_MB_LA ? s_last[pr.y] : active_last[pr.y];
+    if (lm_mb_alive(f, last, max_gap)) {
+        tempo++;
+        if (pr.x >> 31) atomicMin(&s_best[(pr.x & 0x7fffffffu) - rel0], pr.y);
+    }
+}
+
+LM_DEV void lm_mb_pair_new(uint2 pr, int f, int max_gap, unsigned rel0, unsigned* s_best, const int* s_last, const int* s_newpos,
+                           const int32_t* __restrict__ active_last, const int32_t* __restrict__ newpos, unsigned& tempo)
+{
+    const int pos = pr.y < LM_MB_LS ? s_newpos[pr.y] : newpos[pr.y];
+    if (pos < 0) return;        // that source never became a unique
+    const int last = pos < LM_MB_LA ? s_last[pos] : active_last[pos];
+    if (lm_mb_alive(f, last, max_gap)) {
+        tempo++;
+        if (pr.x >> 31) atomicMin(&s_best[(pr.x & 0x7fffffffu) - rel0], (unsigned)pos);
+    }
+}
+
+__global__ void __launch_bounds__(1024) lm_k_mb_resolve(const LmCcRec* __restrict__ cc, const long long* __restrict__ frame_cc_off,
+                                                        int f0, int B, int32_t* __restrict__ active, int32_t* __restrict__ active_cc,
+                                                        unsigned long long* __restrict__ active_box, int32_t* __restrict__ active_last,
+                                                        LmCounters* __restrict__ cnt, int32_t* __restrict__ assign, LmMatchBatch mb,
+                                                        int max_gap, int cap_uniq)
+{
+    LM_DYN_SMEM(smem);
+    unsigned* s_best = (unsigned*)smem;                 // [LM_MB_CH]
+    int* s_last = (int*)(smem + (size_t)LM_MB_CH * 4);  // [LM_MB_LA]
+    int* s_newpos = s_last + LM_MB_LA;                  // [LM_MB_LS]
+    __shared__ int s_c0[LM_MB_MAX_FRAMES + 1];
+    __shared__ unsigned s_tA[LM_MB_MAX_FRAMES + 1], s_tB[LM_MB_MAX_FRAMES + 1];
+    __shared__ int s_fail;
+    __shared__ unsigned long long s_tempo;
+    if (cnt->error) return;
+    const int nt = mb.ftile[B];
+    const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
+    const int nA0 = cnt->n_active;
+    const int nS = *mb.n_src;
+    int nA = nA0;
+    int nU = cnt->n_uniq;
+    unsigned tempo = 0;
+    // every position / source the replay can touch is covered by the LDS tables: the loop then never re-reads global memory
+    // it wrote, and its barriers only need to order LDS (prefetch loads and write-through stores stay in flight)
+    const bool lds_only = (long long)nA0 + nS <= LM_MB_LA && nS <= LM_MB_LS;
+    if (threadIdx.x == 0) { s_fail = 0; s_tempo = 0; }
+    if ((int)threadIdx.x <= B) {
+        s_c0[threadIdx.x] = (int)(frame_cc_off[f0 + threadIdx.x] - C0);
+        const int t = mb.ftile[threadIdx.x];
+        s_tA[threadIdx.x] = nt > 0 ? mb.toff[0][t] : 0u;
+        s_tB[threadIdx.x] = nt > 0 ? mb.toff[1][t] : 0u;
+    }
+    for (int i = threadIdx.x; i < nA0 && i < LM_MB_LA; i += 1024) s_last[i] = active_last[i];
+    for (int k = threadIdx.x; k < nS && k < LM_MB_LS; k += 1024) s_newpos[k] = -1;
+    __syncthreads();
+    uint2 ra[LM_MB_PF], rb[LM_MB_PF];
+    int rs[LM_MB_ITEMS];
+    lm_mb_prefetch(mb, s_tA[0], s_tA[1], s_tB[0], s_tB[1], C0 + s_c0[0], s_c0[1] - s_c0[0], ra, rb, rs);
+
+    for (int b = 0; b < B; b++) {
+        const int f = f0 + b;
+        const int n = s_c0[b + 1] - s_c0[b];
+        const long long c0 = C0 + s_c0[b];
+        const int t0 = mb.ftile[b];
+        const bool single = n <= LM_MB_CH;
+        for (int cb = 0; cb < n || cb == 0; cb += LM_MB_CH) {
+            const int nch = (n - cb < LM_MB_CH) ? n - cb : LM_MB_CH;
+            const unsigned rel0 = (unsigned)s_c0[b] + (unsigned)cb;
+            unsigned pA0, pA1, pB0, pB1;
+            if (single) {
+                pA0 = s_tA[b]; pA1 = s_tA[b + 1]; pB0 = s_tB[b]; pB1 = s_tB[b + 1];
+            } else {        // a frame with more CCs than one LDS pass: tile-aligned sub-ranges, everything from global
+                const int ta = t0 + cb / LM_MB_TILE;
+                const int tb = (t0 + (cb + LM_MB_CH) / LM_MB_TILE < mb.ftile[b + 1]) ? t0 + (cb + LM_MB_CH) / LM_MB_TILE : mb.ftile[b + 1];
+                pA0 = mb.toff[0][ta]; pA1 = mb.toff[0][tb]; pB0 = mb.toff[1][ta]; pB1 = mb.toff[1][tb];
+            }
+            for (int i = threadIdx.x; i < nch; i += 1024) s_best[i] = 0xffffffffu;
+            if (lds_only) lm_lds_barrier(); else __syncthreads();
+            // ---- pairs against uniques that existed before the batch / born inside it
+            if (single) {
+#pragma unroll
+                for (int k = 0; k < LM_MB_PF; k++) {
+                    if (ra[k].y != 0xffffffffu) lm_mb_pair_old(ra[k], f, max_gap, rel0, s_best, s_last, active_last, tempo);
+                    if (rb[k].y != 0xffffffffu) lm_mb_pair_new(rb[k], f, max_gap, rel0, s_best, s_last, s_newpos, active_last, mb.newpos, tempo);
+                }
+            }
+            const unsigned skip = single ? (unsigned)LM_MB_PF * 1024u : 0u;
+            for (unsigned p = pA0 + skip + threadIdx.x; p < pA1; p += 1024)
+                lm_mb_pair_old(mb.pairs[0][p], f, max_gap, rel0, s_best, s_last, active_last, tempo);
+            for (unsigned p = pB0 + skip + threadIdx.x; p < pB1; p += 1024)
+                lm_mb_pair_new(mb.pairs[1][p], f, max_gap, rel0, s_best, s_last, s_newpos, active_last, mb.newpos, tempo);
+            int cur_s[LM_MB_ITEMS];
+#pragma unroll
+            for (int k = 0; k < LM_MB_ITEMS; k++) {
+                const int i = (int)threadIdx.x * LM_MB_ITEMS + k;
+                cur_s[k] = single ? rs[k] : (i < nch ? mb.sidx[c0 + cb + i] : -1);
+            }
+            if (cb + LM_MB_CH >= n && b + 1 < B)        // next frame's lists: in flight while this one is decided
+                lm_mb_prefetch(mb, s_tA[b + 1], s_tA[b + 2], s_tB[b + 1], s_tB[b + 2], C0 + s_c0[b + 1], s_c0[b + 2] - s_c0[b + 1], ra, rb, rs);
+            if (lds_only) lm_lds_barrier(); else __syncthreads();
+            // ---- decisions; matched CCs keep the active POSITION for now (-2 - pos), translated after the replay
+            unsigned isnew[LM_MB_ITEMS], mine = 0;
+#pragma unroll
+            for (int k = 0; k < LM_MB_ITEMS; k++) {
+                const int i = (int)threadIdx.x * LM_MB_ITEMS + k;
+                isnew[k] = 0;
+                if (i < nch) {
+                    const unsigned best = s_best[i];
+                    if (best != 0xffffffffu) {
+                        assign[c0 + cb + i] = -2 - (int32_t)best;
+                        if (best < LM_MB_LA) s_last[best] = f;      // several CCs may hit the same unique: same value
+                        active_last[best] = f;
+                    } else {
+                        isnew[k] = 1;
+                    }
+                }
+                mine += isnew[k];
+            }
+            unsigned tot;
+            unsigned o = lds_only ? lm_block_excl_scan_lds<1024>(mine, &tot) : lm_block_excl_scan<1024>(mine, &tot);
+#pragma unroll
+            for (int k = 0; k < LM_MB_ITEMS; k++) {
+                if (!isnew[k]) continue;
+                const long long ci = c0 + cb + (long long)threadIdx.x * LM_MB_ITEMS + k;
+                const long long idx = (long long)nU + o;
+                const int src = cur_s[k];
+                if (idx < cap_uniq && src >= 0) {
+                    const int pos = nA + (int)o;
+                    assign[ci] = (int32_t)idx;
+                    active[pos] = (int32_t)idx;
+                    active_cc[pos] = (int32_t)ci;
+                    active_last[pos] = f;
+                    if (pos < LM_MB_LA) s_last[pos] = f;
+                    mb.newpos[src] = pos;
+                    if (src < LM_MB_LS) s_newpos[src] = pos;
+                } else {
+                    s_fail = idx < cap_uniq ? LM_ERR_STATE : LM_ERR_CAPACITY;   // STATE: a surely matched CC found no match (bug)
+                }
+                o++;
+            }
+            nA += (int)tot;
+            nU += (int)tot;
+            if (lds_only) lm_lds_barrier(); else __syncthreads();
+        }
+    }
+    __syncthreads();        // everything the replay wrote is visible to the whole block
+    // ---- after the replay: positions -> unique indices, boxes of the new actives
+    if (!s_fail) {
+        for (long long base = C0; base < C1; base += 1024 * 12) {     // 12 independent lookups in flight per thread
+            int v[12], u[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                const long long i = base + (long long)k * 1024 + threadIdx.x;
+                v[k] = (i < C1) ? assign[i] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 12; k++) u[k] = (v[k] <= -2) ? active[-2 - v[k]] : 0;
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                const long long i = base + (long long)k * 1024 + threadIdx.x;
+                if (v[k] <= -2) assign[i] = u[k];
+            }
+        }
+        for (int pos = nA0 + (int)threadIdx.x; pos < nA; pos += 1024) active_box[pos] = lm_pack_box(cc[active_cc[pos]]);
+    }
+    if (tempo) atomicAdd(&s_tempo, (unsigned long long)tempo);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_fail) {
+            cnt->error = s_fail;
+        } else {
+            cnt->n_uniq = nU;
+            cnt->n_active = nA;
+            cnt->n_matched = f0 + B;
+            cnt->tempo_count += s_tempo;
+        }
+    }
+}

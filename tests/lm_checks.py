@@ -6,7 +6,7 @@ import os
 
 import numpy as np
 
-from lecturemath_amd import device
+from lecturemath_amd import device, synth
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 STREAMS = ["accumulate_erase", "occluder_return", "short_gap_jitter"]
@@ -67,11 +67,14 @@ def state_equal_oracle(r, o):
         assert a.shape == b.shape and (a == b).all()
 
 
-def run_stream(lib, frames, w, h, max_gap, max_batch=7, split=None, **kw):
+def run_stream(lib, frames, w, h, max_gap, max_batch=7, split=None, records_then_match=False, **kw):
     fs = device.FrameStream(w, h, len(frames), 0.85, 0.85, max_gap, 20, max_batch=max_batch, lib=lib, **kw)
     try:
         dev = fs.be.from_host(frames)
-        if split:
+        if records_then_match:      # all records first, then ONE matching call (chunks of 64 frames inside the library)
+            fs.push_records(dev)
+            fs.match(len(frames))
+        elif split:
             fs.push(dev[:split])
             fs.push(dev[split:])
         else:
@@ -96,6 +99,28 @@ def check_stream_oracle(lib, frames, max_gap, max_batch=5, **kw):
     r = run_stream(lib, np.stack(frames), w, h, max_gap, max_batch=max_batch, **kw)
     state_equal_oracle(r, st.result())
     return r
+
+
+def check_stream_match_paths(lib, n_frames=80, max_gap=2, seed=11):
+    """The batched matcher (default), the per-frame kernels (LM_MATCH_PER_FRAME=1) and the oracle agree on a stream whose
+    uniques are created, retired (small max_gap) and re-created inside one matching batch, for several batch shapes."""
+    frames = list(synth.binary_stream(n_frames, 64, 96, seed=seed, glyphs_per_add=3, erase_every=5, jitter_p=0.5, occluder=True,
+                                      max_ext=12))
+    r1 = check_stream_oracle(lib, frames, max_gap, max_batch=32)
+    r2 = check_stream_oracle(lib, frames, max_gap, max_batch=1)
+    r3 = check_stream_oracle(lib, frames, max_gap, max_batch=16, records_then_match=True)
+    old = os.environ.get("LM_MATCH_PER_FRAME")
+    os.environ["LM_MATCH_PER_FRAME"] = "1"
+    try:
+        r4 = check_stream_oracle(lib, frames, max_gap, max_batch=32)
+    finally:
+        if old is None:
+            del os.environ["LM_MATCH_PER_FRAME"]
+        else:
+            os.environ["LM_MATCH_PER_FRAME"] = old
+    for r in (r2, r3, r4):
+        state_equal_oracle(r, r1)
+    assert len(r1["unique_recs"]) > 30 and len(r1["active"]) < len(r1["unique_recs"])
 
 
 def check_label_vs_oracle(lib, img):

@@ -32,6 +32,11 @@ def test_stream_golden(hip_lib, name):
     lm_checks.check_stream_golden(hip_lib, name, max_batch=16)
 
 
+def test_stream_match_paths_agree(hip_lib, oracle_built):
+    lm_checks.check_stream_match_paths(hip_lib, n_frames=150)
+    lm_checks.check_stream_match_paths(hip_lib, n_frames=97, max_gap=1, seed=4)
+
+
 def test_stream_vs_oracle_random_noise(hip_lib, oracle_built):
     rng = np.random.default_rng(11)
     base = (rng.random((120, 200)) < 0.5)

@@ -32,6 +32,10 @@ def test_stream_vs_oracle_small(emu_lib, oracle_built):
     assert len(r["unique_recs"]) > 20
 
 
+def test_stream_match_paths_agree(emu_lib, oracle_built):
+    lm_checks.check_stream_match_paths(emu_lib, n_frames=72)
+
+
 def test_stream_golden_short_gap(emu_lib):
     lm_checks.check_stream_golden(emu_lib, "short_gap_jitter", max_batch=16)
 

@@ -20,6 +20,10 @@ for rep in range(3):
     lib.check(lib.lm_threshold_invert(logits.data_ptr(), binary.data_ptr(), F * H * W, 128, st)); t1 = sync()
     for f0 in range(0, F, B):
         lib.check(lib.lm_stream_push(fs.handle, binary[f0:f0 + B].data_ptr(), B, labels.data_ptr(), st))
+        if rep == 2 and os.environ.get("LM_MATCH_STATS"):
+            k = np.zeros(5, np.int64)
+            lib.check(lib.lm_stream_match_stats(fs.handle, k.ctypes.data, st))
+            print("   batch at frame %d: sources %d tiles %d pairsA %d pairsB %d" % (f0, k[0], k[1], k[2], k[3]), fs.counters()["n_active"])
     t2h = time.perf_counter(); t2 = sync()
     gr = device.Grouping(fs, reconstruct=True); t3 = sync()
     for f0 in range(0, F, B): gr.render(f0, B, clean)
