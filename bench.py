@@ -32,8 +32,8 @@ ALGO_BYTES_PER_PX = 5           # 1 B uint8 in + 4 B int32 label
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=5)
-    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--frames", type=int, default=256, help="frames per stream (= per step)")
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--width", type=int, default=1920)
@@ -41,6 +41,7 @@ def parse():
     p.add_argument("--cpu-frames", type=int, default=200, help="prefix of the stream timed on the CPU oracle (0 = skip)")
     p.add_argument("--no-labels", action="store_true", help="do not materialise the int32 label image")
     p.add_argument("--no-pipeline", action="store_true", help="do not overlap step 03 of one stream with steps 01-02 of the next")
+    p.add_argument("--depth", type=int, default=2, help="streams in flight (pipeline slots); depth-1 host workers run step 03")
     p.add_argument("--seed", type=int, default=20213)
     p.add_argument("--fcn-precision", default="f16x3", choices=["f16x3", "fp32"],
                    help="MFMA operand format of the FCN conv stack (fp32 accumulate in both)")
@@ -166,21 +167,26 @@ def main():
     # its own HIP stream, driven by a worker thread -- ctypes releases the GIL), slot B labels and matches the next stream.
     # Every step still does all of its work inside the timed region; only consecutive, independent steps overlap.
     import concurrent.futures
-    depth = 1 if a.no_pipeline else 2
+    depth = 1 if a.no_pipeline else max(2, a.depth)
     slots = []
     for _ in range(depth):
         fs = device.FrameStream(W, H, F, 0.85, 0.85, 85, 20, max_batch=a.batch, lib=lib)
         slots.append({"fs": fs, "binary": torch.empty((F, H, W), dtype=torch.uint8, device="cuda"),
                       "labels": None if a.no_labels else torch.empty((a.batch, H, W), dtype=torch.int32, device="cuda"),
                       "clean": torch.empty((a.batch, H, W), dtype=torch.uint8, device="cuda"),
-                      "s_front": torch.cuda.Stream(), "s_back": torch.cuda.Stream(), "done": torch.cuda.Event()})
-    pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+                      "s_front": torch.cuda.Stream(), "s_back": torch.cuda.Stream(), "done": torch.cuda.Event(),
+                      "rdone": torch.cuda.Event(), "gr": None})
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, depth - 1))
 
     def front(sl):
         """steps 01 (threshold) + 02 (label, records, matching) of one stream"""
         fs, binary, labels = sl["fs"], sl["binary"], sl["labels"]
         with torch.cuda.stream(sl["s_front"]):
             stream = sl["s_front"].cuda_stream
+            if sl.get("gr") is not None:            # the previous step of this slot: its rendering must be done before
+                sl["rdone"].synchronize()           # its tables go away and its buffers are reused
+                sl["gr"].close()
+                sl["gr"] = None
             fs.reset()
             lib.check(lib.lm_threshold_invert(logits.data_ptr(), binary.data_ptr(), F * H * W, 128, stream))
             for f0 in range(0, F, a.batch):
@@ -200,8 +206,13 @@ def main():
                 n = min(a.batch, F - f0)
                 gr.render(f0, n, sl["clean"][:n])
             info = gr.array("scalars")
-            sl["s_back"].synchronize()
-            gr.close()
+            # rendering is only enqueued here: the worker goes on to the next stream's step 03 while the GPU draws
+            sl["rdone"].record(sl["s_back"])
+            if os.environ.get("LM_BENCH_SYNC_RENDER"):
+                sl["s_back"].synchronize()
+                gr.close()
+            else:
+                sl["gr"] = gr
         return info
 
     def run_steps(k):
@@ -218,6 +229,11 @@ def main():
         for p in pending:
             if p is not None:
                 info = p.result()
+        for sl in slots:
+            if sl["gr"] is not None:
+                sl["rdone"].synchronize()
+                sl["gr"].close()
+                sl["gr"] = None
         return info
 
     run_steps(max(a.warmup, 0))

@@ -101,6 +101,7 @@ struct LmGimgItem {
     int32_t x0, y0, w, h;        // group box origin and size
     int32_t mem_off, mem_cnt;    // slice of the member list
     long long img_off;           // byte offset of the item's (h x w) uint8 image
+    long long bits_off;          // word offset of the same image as bit rows (ceil(w / 32) words per row), what the renderer reads
 };
 struct LmGimgMember { int32_t cc; int32_t count; };
 struct LmGimgUnit { int32_t item; int16_t tx, ty; };
@@ -163,7 +164,8 @@ __global__ void __launch_bounds__(256) lm_k_gimg_max(const LmGimgItem* __restric
 __global__ void __launch_bounds__(256) lm_k_gimg_write(const LmGimgItem* __restrict__ items, const LmGimgUnit* __restrict__ units,
                                                        int n_units, const LmGimgMember* __restrict__ members,
                                                        const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
-                                                       const int32_t* __restrict__ item_max, double thr, uint8_t* __restrict__ images)
+                                                       const int32_t* __restrict__ item_max, double thr, uint8_t* __restrict__ images,
+                                                       uint32_t* __restrict__ bits)
 {
     __shared__ int s_mask[LM_GT * LM_GT];
     for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
@@ -178,6 +180,18 @@ __global__ void __launch_bounds__(256) lm_k_gimg_write(const LmGimgItem* __restr
             const double v = (double)s_mask[yy * LM_GT + xx] / mx;      // float64 like numpy (:630); max >= 1 by construction
             images[it.img_off + (long long)(un.ty * LM_GT + yy) * it.w + (un.tx * LM_GT + xx)] = (v >= thr) ? 255 : 0;
         }
+        // the same decisions as bit rows: a 64-px tile row is two whole words of the item's row
+        const int bw = (it.w + 31) >> 5;
+        for (int i = threadIdx.x; i < th * 2; i += blockDim.x) {
+            const int yy = i >> 1, hf = i & 1;
+            if (un.tx * 2 + hf >= bw) continue;
+            unsigned word = 0;
+            for (int b = 0; b < 32; b++) {
+                const int xx = hf * 32 + b;
+                if (xx < tw && (double)s_mask[yy * LM_GT + xx] / mx >= thr) word |= 1u << b;
+            }
+            bits[it.bits_off + (long long)(un.ty * LM_GT + yy) * bw + un.tx * 2 + hf] = word;
+        }
         __syncthreads();
     }
 }
@@ -188,52 +202,81 @@ __global__ void __launch_bounds__(256) lm_k_gimg_write(const LmGimgItem* __restr
 // (-k) mod 256 with k = number of contributing segment pixels.  Block = (frame, 64-row x 256-col tile),
 // k counted in LDS.
 // ------------------------------------------------------------------------------------------------
-struct LmRenderItem { int32_t x0, y0, w, h; long long img_off; };
+struct LmRenderItem { int32_t x0, y0, w, h; long long bits_off; };
 
 #define LM_RT_ROWS 64
 #define LM_RT_COLS 256
+#define LM_RT_MAXHIT 96     // items of one frame that touch one tile and are painted cooperatively (more: painted by their finder)
+#define LM_RT_WPL 4         // image words per lane in flight while painting
+
+// paints the part of `it` inside the tile at (X0, Y0) from its bit rows; lanes `lane` of `nl` share the (row, word) cells,
+// LM_RT_WPL independent loads in flight per lane, rows from a float reciprocal (exact after one correction step)
+LM_DEV void lm_render_paint(const LmRenderItem& it, int X0, int Y0, const uint32_t* __restrict__ bits, unsigned* s_cnt, int lane, int nl)
+{
+    const int xa = it.x0 > X0 ? it.x0 : X0, xb = (it.x0 + it.w < X0 + LM_RT_COLS) ? it.x0 + it.w : X0 + LM_RT_COLS;
+    const int ya = it.y0 > Y0 ? it.y0 : Y0, yb = (it.y0 + it.h < Y0 + LM_RT_ROWS) ? it.y0 + it.h : Y0 + LM_RT_ROWS;
+    const int bw = (it.w + 31) >> 5;
+    const int wlo = (xa - it.x0) >> 5, nw = ((xb - 1 - it.x0) >> 5) - wlo + 1;
+    const int total = nw * (yb - ya);
+    const float inv = 1.0f / (float)nw;
+    const uint32_t* src = bits + it.bits_off + (long long)(ya - it.y0) * bw + wlo;
+    for (int idx0 = lane; idx0 < total; idx0 += nl * LM_RT_WPL) {
+        unsigned v[LM_RT_WPL];
+        int px[LM_RT_WPL], prow[LM_RT_WPL];
+#pragma unroll
+        for (int u = 0; u < LM_RT_WPL; u++) {
+            const int idx = idx0 + u * nl;
+            int yy = (int)((float)idx * inv);
+            int j = idx - yy * nw;
+            if (j < 0) { yy--; j += nw; }
+            if (j >= nw) { yy++; j -= nw; }
+            v[u] = (idx < total) ? src[(long long)yy * bw + j] : 0u;
+            px[u] = it.x0 + 32 * (wlo + j);                  // frame column of bit 0
+            prow[u] = (ya - Y0 + yy) * LM_RT_COLS - X0;
+        }
+#pragma unroll
+        for (int u = 0; u < LM_RT_WPL; u++) {
+            unsigned m = v[u];
+            if (px[u] < xa) m &= 0xffffffffu << (xa - px[u]);               // clip to the tile / item intersection in x
+            if (px[u] + 32 > xb) m &= 0xffffffffu >> (px[u] + 32 - xb);
+            while (m) {
+                const int bpos = __ffs((int)m) - 1;
+                m &= m - 1;
+                const int p = prow[u] + px[u] + bpos;
+                atomicAdd(&s_cnt[p >> 1], 1u << (16 * (p & 1)));
+            }
+        }
+    }
+}
 
 __global__ void __launch_bounds__(256) lm_k_render_frames(const long long* __restrict__ frame_item_off,
-                                                          const LmRenderItem* __restrict__ items, const uint8_t* __restrict__ images,
+                                                          const LmRenderItem* __restrict__ items, const uint32_t* __restrict__ bits,
                                                           int first_frame, int W, int H, uint8_t* __restrict__ out)
 {
     // k per pixel in 16-bit lanes, two pixels per LDS word (a pixel would need 65536 overlapping groups to overflow its lane)
     __shared__ unsigned s_cnt[LM_RT_ROWS * LM_RT_COLS / 2];
+    __shared__ LmRenderItem s_hit[LM_RT_MAXHIT];
+    __shared__ int s_nhit;
     const int f = first_frame + blockIdx.z;
     const int X0 = blockIdx.x * LM_RT_COLS, Y0 = blockIdx.y * LM_RT_ROWS;
     for (int i = threadIdx.x; i < LM_RT_ROWS * LM_RT_COLS / 2; i += blockDim.x) s_cnt[i] = 0;
+    if (threadIdx.x == 0) s_nhit = 0;
     __syncthreads();
     const long long i0 = frame_item_off[f], i1 = frame_item_off[f + 1];
-    const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6), lane = lm_lane();
-    // each wave screens 64 items at a time (one box test per lane), then paints the few that touch the tile
-    for (long long ib = i0 + (long long)wave * 64; ib < i1; ib += (long long)nwaves * 64) {
-        LmRenderItem mine;
-        mine.x0 = 0; mine.y0 = 0; mine.w = 0; mine.h = 0; mine.img_off = 0;
-        bool hit = false;
-        if (ib + lane < i1) {
-            mine = items[ib + lane];
-            hit = mine.x0 < X0 + LM_RT_COLS && mine.x0 + mine.w > X0 && mine.y0 < Y0 + LM_RT_ROWS && mine.y0 + mine.h > Y0;
-        }
-        unsigned long long mask = __ballot(hit);
-        while (mask) {
-            const int l = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            LmRenderItem it;
-            it.x0 = __shfl(mine.x0, l); it.y0 = __shfl(mine.y0, l); it.w = __shfl(mine.w, l); it.h = __shfl(mine.h, l);
-            it.img_off = __shfl(mine.img_off, l);
-            const int xa = it.x0 > X0 ? it.x0 : X0, xb = (it.x0 + it.w < X0 + LM_RT_COLS) ? it.x0 + it.w : X0 + LM_RT_COLS;
-            const int ya = it.y0 > Y0 ? it.y0 : Y0, yb = (it.y0 + it.h < Y0 + LM_RT_ROWS) ? it.y0 + it.h : Y0 + LM_RT_ROWS;
-            const int tw = xb - xa, total = tw * (yb - ya);
-            for (int idx = lane; idx < total; idx += 64) {
-                const int yy = idx / tw, xx = idx - yy * tw;
-                const int y = ya + yy, x = xa + xx;
-                if (images[it.img_off + (long long)(y - it.y0) * it.w + (x - it.x0)]) {
-                    const int p = (y - Y0) * LM_RT_COLS + (x - X0);
-                    atomicAdd(&s_cnt[p >> 1], 1u << (16 * (p & 1)));
-                }
-            }
+    // screen the frame's items (one per thread and trip), collect the few that touch the tile
+#pragma unroll 2
+    for (long long ib = i0 + threadIdx.x; ib < i1; ib += blockDim.x) {
+        const LmRenderItem mine = items[ib];
+        if (mine.x0 < X0 + LM_RT_COLS && mine.x0 + mine.w > X0 && mine.y0 < Y0 + LM_RT_ROWS && mine.y0 + mine.h > Y0) {
+            const int slot = atomicAdd(&s_nhit, 1);
+            if (slot < LM_RT_MAXHIT) s_hit[slot] = mine;
+            else lm_render_paint(mine, X0, Y0, bits, s_cnt, 0, 1);      // crowded tile: the finder paints it alone
         }
     }
+    __syncthreads();
+    const int nhit = s_nhit < LM_RT_MAXHIT ? s_nhit : LM_RT_MAXHIT;
+    const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6), lane = lm_lane();
+    for (int h = wave; h < nhit; h += nwaves) lm_render_paint(s_hit[h], X0, Y0, bits, s_cnt, lane, 64);
     __syncthreads();
     uint8_t* dst = out + (long long)blockIdx.z * W * H;
     const bool vec = ((W & 15) == 0) && ((((uintptr_t)out) & 15) == 0);
@@ -289,6 +332,8 @@ struct LmGroups {
     std::vector<uint8_t> gimg_host;             // filled on demand
     // ---- device
     uint8_t* d_images = nullptr;
+    uint32_t* d_gbits = nullptr;                // the same images as bit rows (renderer input)
+    std::vector<int64_t> gbits_off;             // [n_items] word offsets into d_gbits
     long long* d_frame_item_off = nullptr;
     LmRenderItem* d_render_items = nullptr;
     std::vector<void*> d_owned;                 // allocations that did not fit the arena
@@ -612,6 +657,8 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
     std::vector<LmGimgMember> members;
     std::vector<LmGimgUnit> units;
     g->gimg_off.assign(1, 0);
+    g->gbits_off.clear();
+    long long bit_words = 0;
     g->gimg_item_off.assign(1, 0);
     for (int gi = 0; gi < nG; gi++) {
         int x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
@@ -639,6 +686,9 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
             }
             it.mem_cnt = (int32_t)members.size() - it.mem_off;
             it.img_off = g->gimg_off.back();
+            it.bits_off = bit_words;
+            g->gbits_off.push_back(bit_words);
+            bit_words += (long long)h * ((w + 31) >> 5);
             const int item_idx = (int)items.size();
             items.push_back(it);
             g->gimg_off.push_back(it.img_off + (int64_t)w * h);
@@ -649,7 +699,8 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
     }
     const long long img_bytes = g->gimg_off.back();
     g->d_images = (uint8_t*)lm_galloc(g, (size_t)std::max<long long>(img_bytes, 1));
-    if (!g->d_images) return LM_ERR_HIP;
+    g->d_gbits = (uint32_t*)lm_galloc(g, (size_t)std::max<long long>(bit_words, 1) * sizeof(uint32_t));
+    if (!g->d_images || !g->d_gbits) return LM_ERR_HIP;
     if (!items.empty()) {
         LmGimgItem* d_items; LmGimgMember* d_members; LmGimgUnit* d_units; int32_t* d_max;
         if (lm_upload(g, items, &d_items, st) || lm_upload(g, members, &d_members, st) || lm_upload(g, units, &d_units, st)) return LM_ERR_HIP;
@@ -659,7 +710,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         const int nb = (int)std::min<size_t>(units.size(), LM_HIP_EMULATED ? 2 : 4096);
         hipLaunchKernelGGL(lm_k_gimg_max, dim3(nb), dim3(256), 0, st, d_items, d_units, (int)units.size(), d_members, s->cc, s->crop, d_max);
         hipLaunchKernelGGL(lm_k_gimg_write, dim3(nb), dim3(256), 0, st, d_items, d_units, (int)units.size(), d_members, s->cc, s->crop,
-                           d_max, g->img_thr, g->d_images);
+                           d_max, g->img_thr, g->d_images, g->d_gbits);
         LM_HIP(hipGetLastError());
     }
     tm.mark("group images (host tables + device)");
@@ -679,7 +730,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
                 LmRenderItem ri;
                 ri.x0 = g->bounds[(size_t)gi * 4 + 0]; ri.y0 = g->bounds[(size_t)gi * 4 + 2];
                 ri.w = g->bounds[(size_t)gi * 4 + 1] - ri.x0 + 1; ri.h = g->bounds[(size_t)gi * 4 + 3] - ri.y0 + 1;
-                ri.img_off = g->gimg_off[(size_t)item];
+                ri.bits_off = g->gbits_off[(size_t)item];
                 ritems.push_back(ri);
             }
             fio[(size_t)f + 1] = (long long)ritems.size();
@@ -723,7 +774,7 @@ extern "C" int lm_group_render(LmGroups* g, int first, int n, uint8_t* d_out, vo
     }
     const LmGeom gm = g->s->ctx->g;
     hipLaunchKernelGGL(lm_k_render_frames, dim3((gm.W + LM_RT_COLS - 1) / LM_RT_COLS, (gm.H + LM_RT_ROWS - 1) / LM_RT_ROWS, n), dim3(256), 0,
-                       (hipStream_t)stream, g->d_frame_item_off, g->d_render_items, g->d_images, first, gm.W, gm.H, d_out);
+                       (hipStream_t)stream, g->d_frame_item_off, g->d_render_items, g->d_gbits, first, gm.W, gm.H, d_out);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }

@@ -184,6 +184,55 @@ def check_grouping_golden(lib, name, max_batch=16):
         fs.close()
 
 
+def check_grouping_oracle(lib, frames, gap2=85, gap3=85, max_batch=8):
+    """Step 03 of an arbitrary stream vs the oracle: groups, ages, group images and every reconstructed frame."""
+    from oracle import cc as occ
+    from oracle import grouping as og
+    h, w = frames[0].shape
+    st = occ.Stability(w, h, 0.85, 0.85, gap2)
+    for f in frames:
+        st.add_frame(f)
+    o = og.run_step03(st.result(), max_gap=gap3)
+    fs = device.FrameStream(w, h, len(frames), 0.85, 0.85, gap2, 20, max_batch=max_batch, lib=lib, max_ccs=len(frames) * h * w // 24,
+                            max_crop_words=len(frames) * h * w // 4)
+    try:
+        fs.push(fs.be.from_host(np.stack(frames)))
+        gr = device.Grouping(fs, max_gap=gap3, min_times=3, t_window=5, min_recall=0.5, img_threshold=0.5)
+        try:
+            r = gr.result()
+        finally:
+            gr.close()
+    finally:
+        fs.close()
+    assert r["cc_groups"] == o["cc_groups"] and len(r["cc_groups"]) > 0
+    ng = len(o["cc_groups"])
+    assert [list(r["group_ages"][k]) for k in range(ng)] == [list(o["group_ages"][k]) for k in range(ng)]
+    assert [list(fr) for fr in r["groups_per_frame"]] == [list(fr) for fr in o["groups_per_frame"]]
+    for k in range(ng):
+        assert len(r["group_images"][k]) == len(o["group_images"][k])
+        for a, b in zip(r["group_images"][k], o["group_images"][k]):
+            assert a.shape == b.shape and (a == b).all()
+    assert (np.stack(r["clean_binary"]) == np.stack(o["clean_binary"])).all()
+    return r
+
+
+def dot_grid_stream(n_frames=6, h=72, w=520, seed=3):
+    """Hundreds of 5x4-pixel dots per 64x256 tile (more stable groups in one render tile than its cooperative hit list
+    holds), a few of them blinking."""
+    rng = np.random.default_rng(seed)
+    ys, xs = np.arange(2, h - 5, 6), np.arange(2, w - 6, 7)
+    frames = []
+    for f in range(n_frames):
+        img = np.zeros((h, w), np.uint8)
+        on = rng.random((len(ys), len(xs))) > (0.03 if f else 0.0)
+        for i, y in enumerate(ys):
+            for j, x in enumerate(xs):
+                if on[i, j]:
+                    img[y:y + 4, x:x + 5] = 255
+        frames.append(img)
+    return frames
+
+
 def check_fcn_golden(lib, name, tol=1e-3, precision="f16x3"):
     """HIP FCN forward vs the reference module's outputs (G5 fixture); tolerance 1e-3 on logits (BASELINE.json)."""
     from lecturemath_amd import fcn

@@ -111,6 +111,12 @@ def test_grouping_golden(hip_lib, name):
     lm_checks.check_grouping_golden(hip_lib, name)
 
 
+def test_grouping_crowded_tiles_vs_oracle(hip_lib, oracle_built):
+    """~800 stable groups on a 72x520 frame: render tiles with more items than the cooperative hit list (96)."""
+    r = lm_checks.check_grouping_oracle(hip_lib, lm_checks.dot_grid_stream())
+    assert len(r["cc_groups"]) > 500
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "fp32"])
 @pytest.mark.parametrize("name", ["k7_70x94", "k3_135x240", "k7_66x130_wide"])
 def test_fcn_golden(hip_lib, name, precision):

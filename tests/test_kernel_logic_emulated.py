@@ -80,6 +80,11 @@ def test_dense_wide_noise_band_fallback(emu_lib, oracle_built):
     lm_checks.check_label_vs_oracle(emu_lib, img)
 
 
+def test_grouping_crowded_tiles_vs_oracle(emu_lib, oracle_built):
+    r = lm_checks.check_grouping_oracle(emu_lib, lm_checks.dot_grid_stream(n_frames=4, h=40, w=520))
+    assert len(r["cc_groups"]) > 200
+
+
 def test_grouping_golden_short_gap(emu_lib):
     lm_checks.check_grouping_golden(emu_lib, "short_gap_jitter")
 
