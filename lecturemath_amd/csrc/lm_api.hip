@@ -386,7 +386,7 @@ extern "C" void lm_stream_destroy(LmStream* s)
     if (s->mb) {
         LmMatchBatch* m = s->mb;
         void* mp[] = {m->ftile, m->s_prefix, m->tcount[0], m->tcount[1], m->toff[0], m->toff[1], m->pairs[0], m->pairs[1], m->pair_u[0],
-                      m->pair_u[1], m->sidx, m->s_list, m->s_box, m->newpos, m->n_src};
+                      m->pair_u[1], m->sidx, m->s_list, m->s_box, m->newpos, m->n_src, m->ttab, m->tkey, m->twin};
         for (void* p : mp)
             if (p) (void)hipFree(p);
         delete m;
@@ -467,6 +467,9 @@ extern "C" LmStream* lm_stream_create(LmCtx* ctx, int max_frames, int64_t max_cc
         rc |= lm_alloc(&m->s_box, (size_t)max_ccs);
         rc |= lm_alloc(&m->newpos, (size_t)max_ccs);
         rc |= lm_alloc(&m->n_src, (size_t)1);
+        rc |= lm_alloc(&m->ttab, (size_t)LM_MB_TTAB);
+        rc |= lm_alloc(&m->tkey, (size_t)max_ccs);
+        rc |= lm_alloc(&m->twin, (size_t)max_ccs);
 #if !LM_HIP_EMULATED
         if (rc == LM_OK &&
             hipFuncSetAttribute((const void*)lm_k_mb_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LM_MB_RESOLVE_SMEM) != hipSuccess)
@@ -475,6 +478,7 @@ extern "C" LmStream* lm_stream_create(LmCtx* ctx, int max_frames, int64_t max_cc
         const char* e = getenv("LM_MATCH_PER_FRAME");
         s->match_per_frame = (e && atoi(e) == 1) ? 1 : 0;
     }
+    if (rc == LM_OK && hipMemset(s->mb->twin, 0, (size_t)max_ccs) != hipSuccess) rc = LM_ERR_HIP;   // stays 0 when twin detection is off
     if (rc == LM_OK) rc = lm_stream_reset(s, nullptr);
     if (rc == LM_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = LM_ERR_HIP;
     if (rc != LM_OK) {
@@ -508,6 +512,11 @@ static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st)
         s->last_match_frames = B;
         hipLaunchKernelGGL(lm_k_mb_prologue, dim3(1), dim3(1024), 0, st, s->frame_cc_off, f, B, s->active, s->active_cc, s->active_box,
                            s->active_last, s->counters, mb, s->max_gap);
+        if (s->min_recall <= 1.0 && s->min_precision <= 1.0) {     // the twin rule needs "identical crops are accepted"
+            (void)hipMemsetAsync(mb.ttab, 0xff, (size_t)LM_MB_TTAB * sizeof(unsigned long long), st);
+            hipLaunchKernelGGL(lm_k_mb_twin_insert, ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->counters, mb);
+            hipLaunchKernelGGL(lm_k_mb_twin_find, ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->counters, mb, s->max_gap);
+        }
         hipLaunchKernelGGL((lm_k_mb_join<0, 0>), gj, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->counters, mb);
         hipLaunchKernelGGL((lm_k_mb_join<0, 1>), gj, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->counters, mb);
         hipLaunchKernelGGL((lm_k_mb_eval<0>), ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->active_last, s->counters, mb,

@@ -14,6 +14,11 @@
 //                         atomics between workgroups: one workgroup owns a tile)
 //   E  lm_k_mb_eval<0>    every pair, 8 lanes each: overlap + float64 thresholds -> accepted bit; a CC with an accepted
 //                         candidate that stays alive whatever happens in the batch is "surely matched"
+//   T  lm_k_mb_twin_*     a CC that is a bit-identical twin (box, size, crop) of an EARLIER CC of the batch, at most max_gap
+//                         frames before it, can never become a new unique: it accepts whatever its twin matched -- or
+//                         the twin itself -- with recall = precision = 1 (thresholds <= 1), and that unique is still
+//                         alive.  Twins are found with a hash table (min CC index per key) and verified word by word;
+//                         a missed twin only costs time.  Static video: almost every CC is a twin
 //   S  lm_k_mb_sources    the other CCs of the batch are the only ones that CAN become new uniques: compact them (S)
 //   B  lm_k_mb_join<1,*> + lm_k_mb_eval<1>: the same join against S, restricted to sources of EARLIER frames
 //   C  lm_k_mb_resolve    frames in order: a pair counts if its unique exists and is alive; smallest accepted active
@@ -24,6 +29,7 @@
 #include "lm_stream.h"
 
 #define LM_MB_TILE 64
+#define LM_MB_TTAB (1 << 18)     // twin table slots; batches with more than LM_MB_TTAB / 2 CCs skip twin detection
 #define LM_MB_CHUNK 4096        // source boxes filtered per round (LDS survivors list)
 #define LM_MB_MAX_FRAMES 64     // frames per batch (per-frame tables of the replay kernel live in LDS)
 #define LM_MB_CH 4096           // CCs of one frame resolved per LDS pass
@@ -45,6 +51,9 @@ struct LmMatchBatch {
     unsigned long long* s_box;  // packed box of source k
     int32_t* newpos;            // active position source k was given when it became a unique, else -1
     int32_t* n_src;             // [1]
+    unsigned long long* ttab;   // [LM_MB_TTAB] twin table: key32 << 32 | smallest batch-relative cc index with that key
+    uint32_t* tkey;             // [cap_cc] per global cc: key32 of (box, size, crop)
+    uint8_t* twin;              // [cap_cc] per global cc: 1 = exact twin of an earlier CC of the batch
     uint32_t cap_pairs;
     int cap_tiles;
 };
@@ -273,6 +282,89 @@ __global__ void __launch_bounds__(256) lm_k_mb_eval(const LmCcRec* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// T: exact twins.  8 lanes per CC.
+// ------------------------------------------------------------------------------------------------
+LM_DEV unsigned lm_mix32(unsigned h) { h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16; return h; }
+
+__global__ void __launch_bounds__(256) lm_k_mb_twin_insert(const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
+                                                           const long long* __restrict__ frame_cc_off, int f0, int B,
+                                                           LmCounters* __restrict__ cnt, LmMatchBatch mb)
+{
+    if (cnt->error) return;
+    const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
+    const long long n = C1 - C0;
+    if (n * 2 > LM_MB_TTAB) return;
+    const int sub = (int)(threadIdx.x & 7);
+    const long long grp = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3, ngrp = ((long long)gridDim.x * 256) >> 3;
+    const long long rounds = (n + ngrp - 1) / ngrp;     // whole waves stay in the loop for the shuffles
+    for (long long it = 0; it < rounds; it++) {
+        const long long i = it * ngrp + grp;
+        const bool live = i < n;
+        unsigned h = 0;
+        LmCcRec r;
+        if (live) {
+            r = cc[C0 + i];
+            const int nw = (r.max_x >> 5) - (r.min_x >> 5) + 1, total = nw * (r.max_y - r.min_y + 1);
+            for (int k = sub; k < total; k += 8) h += lm_mix32(crop[r.crop_off + k] + 0x9e3779b9u * (unsigned)k);
+        }
+#pragma unroll
+        for (int d = 4; d >= 1; d >>= 1) h += (unsigned)__shfl_xor((int)h, d, 8);
+        if (live && sub == 0) {
+            const unsigned long long box = lm_pack_box(r);
+            unsigned key = lm_mix32(h ^ lm_mix32((unsigned)box) ^ lm_mix32((unsigned)(box >> 32) + 0x85ebca6bu) ^ lm_mix32((unsigned)r.size + 0xc2b2ae35u));
+            if (key == 0xffffffffu) key = 0;
+            mb.tkey[C0 + i] = key;
+            const unsigned long long val = ((unsigned long long)key << 32) | (unsigned long long)(unsigned)i;
+            for (unsigned probe = 0; probe < LM_MB_TTAB; probe++) {
+                const unsigned slot = (key + probe) & (LM_MB_TTAB - 1);
+                const unsigned long long old = atomicCAS(&mb.ttab[slot], ~0ull, val);
+                if (old == ~0ull) break;
+                if ((unsigned)(old >> 32) == key) { atomicMin(&mb.ttab[slot], val); break; }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) lm_k_mb_twin_find(const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
+                                                         const long long* __restrict__ frame_cc_off, int f0, int B,
+                                                         LmCounters* __restrict__ cnt, LmMatchBatch mb, int max_gap)
+{
+    if (cnt->error) return;
+    const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
+    const long long n = C1 - C0;
+    const bool enabled = n * 2 <= LM_MB_TTAB;
+    const int sub = (int)(threadIdx.x & 7);
+    const long long grp = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3, ngrp = ((long long)gridDim.x * 256) >> 3;
+    const long long rounds = (n + ngrp - 1) / ngrp;
+    for (long long it = 0; it < rounds; it++) {
+        const long long i = it * ngrp + grp;
+        const bool live = i < n;
+        int diff = 1;       // 0 after a complete, equal comparison
+        if (live && enabled) {
+            const unsigned key = mb.tkey[C0 + i];
+            long long root = -1;
+            for (unsigned probe = 0; probe < LM_MB_TTAB; probe++) {
+                const unsigned long long e = mb.ttab[(key + probe) & (LM_MB_TTAB - 1)];
+                if (e == ~0ull) break;
+                if ((unsigned)(e >> 32) == key) { root = (long long)(unsigned)e; break; }
+            }
+            if (root >= 0 && root < i) {
+                const LmCcRec r = cc[C0 + i], q = cc[C0 + root];
+                if (r.size == q.size && r.min_x == q.min_x && r.max_x == q.max_x && r.min_y == q.min_y && r.max_y == q.max_y &&
+                    q.frame < r.frame && r.frame - q.frame <= max_gap) {
+                    const int nw = (r.max_x >> 5) - (r.min_x >> 5) + 1, total = nw * (r.max_y - r.min_y + 1);
+                    diff = 0;
+                    for (int k = sub; k < total; k += 8) diff |= (crop[r.crop_off + k] != crop[q.crop_off + k]) ? 1 : 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 4; d >= 1; d >>= 1) diff |= __shfl_xor(diff, d, 8);
+        if (live && sub == 0) mb.twin[C0 + i] = diff ? 0 : 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // S: compact the CCs that are not surely matched.  One block; 32 CCs per thread and pass, all loads of a pass in flight
 // together, positions from per-wave ballots.
 // ------------------------------------------------------------------------------------------------
@@ -292,7 +384,7 @@ __global__ void __launch_bounds__(1024) lm_k_mb_sources(const LmCcRec* __restric
 #pragma unroll
         for (int k = 0; k < LM_MB_SRC_R; k++) {
             const long long i = base + (long long)k * 1024 + threadIdx.x;
-            v[k] = (i < C1) ? mb.sidx[i] : 0;
+            v[k] = (i < C1 && !mb.twin[i]) ? mb.sidx[i] : 0;
         }
         unsigned fm = 0;
 #pragma unroll
