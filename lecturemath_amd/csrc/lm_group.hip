@@ -249,6 +249,36 @@ LM_DEV void lm_render_paint(const LmRenderItem& it, int X0, int Y0, const uint32
     }
 }
 
+// one LmRenderItem per (frame, live group): the group's current segment image (:650-652 `while ages[ptr+1] < f: ptr += 1`)
+__global__ void __launch_bounds__(256) lm_k_render_items(const long long* __restrict__ frame_item_off, int F, const int32_t* __restrict__ gpf,
+                                                         const int32_t* __restrict__ ages, const int32_t* __restrict__ ages_off,
+                                                         const int32_t* __restrict__ bounds, const int64_t* __restrict__ gitem_first,
+                                                         const int64_t* __restrict__ gbits_off, LmRenderItem* __restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= frame_item_off[F]) return;
+    int lo = 0, hi = F;         // frame of item i: largest f with frame_item_off[f] <= i
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (frame_item_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    const int f = lo, gi = gpf[i];
+    const int32_t* a = ages + ages_off[gi];
+    const int na = ages_off[gi + 1] - ages_off[gi];
+    LmRenderItem ri;
+    ri.x0 = bounds[gi * 4 + 0]; ri.y0 = bounds[gi * 4 + 2];
+    ri.w = bounds[gi * 4 + 1] - ri.x0 + 1; ri.h = bounds[gi * 4 + 3] - ri.y0 + 1;
+    ri.bits_off = 0;
+    if (na < 2) {               // no segment image (the reference would raise IndexError at :650 here): an item that hits no tile
+        ri.w = 0; ri.h = 0;
+    } else {
+        int sidx = 0;
+        while (sidx + 1 < na - 1 && a[sidx + 1] < f) sidx++;
+        ri.bits_off = gbits_off[gitem_first[gi] + sidx];
+    }
+    out[i] = ri;
+}
+
 __global__ void __launch_bounds__(256) lm_k_render_frames(const long long* __restrict__ frame_item_off,
                                                           const LmRenderItem* __restrict__ items, const uint32_t* __restrict__ bits,
                                                           int first_frame, int W, int H, uint8_t* __restrict__ out)
@@ -430,20 +460,22 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
     if (rc) return rc;
     tm.mark("counters + records D2H");
     auto R = [&](long long c, int field) { return rec[(size_t)c * 8 + field]; };   // 0 cc_id 1 min_x 2 max_x 3 min_y 4 max_y 5 size 6 frame 7 assign
+    // the two fields every per-CC loop below needs, as dense arrays (one sequential pass over the records)
+    std::vector<int32_t> cc_frame((size_t)std::max<long long>(n_cc, 1)), cc_assign((size_t)std::max<long long>(n_cc, 1));
+    for (long long c = 0; c < n_cc; c++) { cc_frame[(size_t)c] = rec[(size_t)c * 8 + 6]; cc_assign[(size_t)c] = rec[(size_t)c * 8 + 7]; }
 
     // ---- per-unique entry lists (CC order == ascending frame, the reference's append order)
     std::vector<int64_t> cnt((size_t)nU0 + 1, 0);
-    for (long long c = 0; c < n_cc; c++) cnt[(size_t)R(c, 7) + 1]++;
+    for (long long c = 0; c < n_cc; c++) cnt[(size_t)cc_assign[(size_t)c] + 1]++;
     for (int u = 0; u < nU0; u++) cnt[(size_t)u + 1] += cnt[u];
     std::vector<int32_t> lst((size_t)std::max<long long>(n_cc, 1));
     {
         std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
-        for (long long c = 0; c < n_cc; c++) lst[(size_t)pos[R(c, 7)]++] = (int32_t)c;
+        for (long long c = 0; c < n_cc; c++) lst[(size_t)pos[cc_assign[(size_t)c]]++] = (int32_t)c;
     }
     tm.mark("entry lists");
     // ---- split_stable_cc_by_gaps (:181-228)
-    g->assign.resize((size_t)std::max<long long>(n_cc, 1));
-    for (long long c = 0; c < n_cc; c++) g->assign[(size_t)c] = R(c, 7);
+    g->assign = cc_assign;
     g->uniq_cc.resize(nU0);
     std::vector<std::pair<int64_t, int64_t>> seg((size_t)nU0);      // [begin, end) in lst of every unique
     for (int u = 0; u < nU0; u++) {
@@ -456,7 +488,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         const int64_t n_local = e - b;
         std::vector<int64_t> cuts;              // starts of later runs
         for (int64_t i = b + 1; i < e; i++)
-            if (R(lst[(size_t)i], 6) - R(lst[(size_t)i - 1], 6) > g->max_gap) cuts.push_back(i);
+            if (cc_frame[(size_t)lst[(size_t)i]] - cc_frame[(size_t)lst[(size_t)i - 1]] > g->max_gap) cuts.push_back(i);
         if (cuts.empty() || n_local < g->min_times) continue;
         seg[u].second = cuts[0];
         for (size_t ci = 0; ci < cuts.size(); ci++) {
@@ -476,8 +508,8 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         for (int64_t i = seg[u].first; i < seg[u].second; i++) g->ulist_cc.push_back(lst[(size_t)i]);
         g->ulist_off[(size_t)u + 1] = (int64_t)g->ulist_cc.size();
     }
-    auto first_frame = [&](int u) { return R(g->ulist_cc[(size_t)g->ulist_off[u]], 6); };
-    auto last_frame = [&](int u) { return R(g->ulist_cc[(size_t)g->ulist_off[(size_t)u + 1] - 1], 6); };
+    auto first_frame = [&](int u) { return cc_frame[(size_t)g->ulist_cc[(size_t)g->ulist_off[u]]]; };
+    auto last_frame = [&](int u) { return cc_frame[(size_t)g->ulist_cc[(size_t)g->ulist_off[(size_t)u + 1] - 1]]; };
     auto usize = [&](int u) { return R(g->uniq_cc[u], 5); };
     auto ubox = [&](int u, int i) { return R(g->uniq_cc[u], 1 + i); };     // min_x max_x min_y max_y
 
@@ -540,26 +572,49 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
     // per-unique neighbour lists, filled in sorted pair order (== the reference's iteration order)
     struct Tov { int32_t other; double recall, precision; };
     struct Aov { int32_t other, matched, size_other, size_self; };
-    std::vector<std::vector<Tov>> tov((size_t)nU);
-    std::vector<std::vector<Aov>> aov((size_t)nU);
+    const size_t npairs = g->pair_a.size();
+    std::vector<uint8_t> pkind(npairs, 0);              // 1: all-overlap only, 2: also inside the time window
+    std::vector<double> precall(npairs), pprec(npairs);
+    std::vector<int64_t> tov_cnt((size_t)nU + 1, 0), aov_cnt((size_t)nU + 1, 0);
     g->total_intersections = 0;
-    for (size_t i = 0; i < g->pair_a.size(); i++) {
+    for (size_t i = 0; i < npairs; i++) {
         const int a = g->pair_a[i], b = g->pair_b[i];
         const int match = g->pair_match[i];
-        const int sa = usize(a), sb = usize(b);
-        const double recall = (double)match / (double)sa;           // connected_component.py:239
-        const double precision = (double)match / (double)sb;        // :240
+        const double recall = (double)match / (double)usize(a);         // connected_component.py:239
+        const double precision = (double)match / (double)usize(b);      // :240
+        precall[i] = recall; pprec[i] = precision;
         if (recall > 0.0 || precision > 0.0) {
-            const int matched_pixels = (int)((double)sa * recall);   // float64 round trip, can be match-1 (:294)
-            aov[a].push_back({b, matched_pixels, sb, sa});
-            aov[b].push_back({a, matched_pixels, sa, sb});
+            pkind[i] = 1;
+            aov_cnt[(size_t)a + 1]++; aov_cnt[(size_t)b + 1]++;
             if (last_frame(a) + g->t_window >= first_frame(b) && last_frame(b) >= first_frame(a) - g->t_window) {
-                tov[a].push_back({b, recall, precision});
-                tov[b].push_back({a, precision, recall});
+                pkind[i] = 2;
+                tov_cnt[(size_t)a + 1]++; tov_cnt[(size_t)b + 1]++;
                 g->total_intersections++;
             }
         }
     }
+    for (int u = 0; u < nU; u++) { tov_cnt[(size_t)u + 1] += tov_cnt[u]; aov_cnt[(size_t)u + 1] += aov_cnt[u]; }
+    std::vector<Tov> tov_flat((size_t)tov_cnt[nU]);
+    std::vector<Aov> aov_flat((size_t)aov_cnt[nU]);
+    {
+        std::vector<int64_t> tp(tov_cnt.begin(), tov_cnt.end() - 1), ap(aov_cnt.begin(), aov_cnt.end() - 1);
+        for (size_t i = 0; i < npairs; i++) {
+            if (!pkind[i]) continue;
+            const int a = g->pair_a[i], b = g->pair_b[i];
+            const int sa = usize(a), sb = usize(b);
+            const int matched_pixels = (int)((double)sa * precall[i]);   // float64 round trip, can be match-1 (:294)
+            aov_flat[(size_t)ap[a]++] = {b, matched_pixels, sb, sa};
+            aov_flat[(size_t)ap[b]++] = {a, matched_pixels, sa, sb};
+            if (pkind[i] == 2) {
+                tov_flat[(size_t)tp[a]++] = {b, precall[i], pprec[i]};
+                tov_flat[(size_t)tp[b]++] = {a, pprec[i], precall[i]};
+            }
+        }
+    }
+    struct TovRange { const Tov *b, *e; const Tov* begin() const { return b; } const Tov* end() const { return e; } };
+    struct AovRange { const Aov *b, *e; const Aov* begin() const { return b; } const Aov* end() const { return e; } };
+    auto tov = [&](int u) { return TovRange{tov_flat.data() + tov_cnt[u], tov_flat.data() + tov_cnt[(size_t)u + 1]}; };
+    auto aov = [&](int u) { return AovRange{aov_flat.data() + aov_cnt[u], aov_flat.data() + aov_cnt[(size_t)u + 1]}; };
     tm.mark("neighbour lists");
     // ---- compute_groups (:308-413): sequential, order-dependent
     std::vector<std::vector<int32_t>> groups;
@@ -568,7 +623,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         int gi;
         if (gid[a] >= 0) gi = gid[a];
         else { gi = (int)groups.size(); groups.push_back({a}); gid[a] = gi; }
-        for (const Tov& t : tov[a]) {
+        for (const Tov& t : tov(a)) {
             if (t.recall < g->min_recall) continue;
             const int b = t.other;
             if (gid[b] < 0) { gid[b] = gi; groups[gi].push_back(b); }
@@ -589,9 +644,11 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         g->grp_off.push_back((int64_t)g->grp_members.size());
     }
     const int nG = (int)g->grp_off.size() - 1;
+    tm.mark("compute_groups");
     // ---- temporal information (:415-444)
     g->ages_off.assign(1, 0); g->ages.clear();
-    std::vector<std::vector<int32_t>> gpf((size_t)F);
+    std::vector<int32_t> g_from((size_t)nG), g_to((size_t)nG);      // live frame range [from, to) of every group
+    std::vector<int64_t> fcnt((size_t)F + 2, 0);
     for (int gi = 0; gi < nG; gi++) {
         std::vector<int32_t> a;
         for (int64_t i = g->grp_off[gi]; i < g->grp_off[(size_t)gi + 1]; i++) {
@@ -603,10 +660,20 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         a.erase(std::unique(a.begin(), a.end()), a.end());
         for (int v : a) g->ages.push_back(v);
         g->ages_off.push_back((int64_t)g->ages.size());
-        for (int f = a.front(); f < std::min(a.back() + 1, F); f++) gpf[f].push_back(gi);
+        g_from[gi] = a.front(); g_to[gi] = std::max(a.front(), std::min(a.back() + 1, F));
+        if (g_to[gi] > g_from[gi]) { fcnt[(size_t)g_from[gi] + 1]++; fcnt[(size_t)g_to[gi] + 1]--; }
     }
-    g->gpf_off.assign(1, 0); g->gpf.clear();
-    for (int f = 0; f < F; f++) { for (int v : gpf[f]) g->gpf.push_back(v); g->gpf_off.push_back((int64_t)g->gpf.size()); }
+    // per-frame lists in ascending group index: difference array -> counts -> offsets -> fill
+    g->gpf_off.assign((size_t)F + 1, 0);
+    {
+        int64_t live = 0;
+        for (int f = 0; f < F; f++) { live += fcnt[(size_t)f + 1]; g->gpf_off[(size_t)f + 1] = g->gpf_off[f] + live; }
+        g->gpf.assign((size_t)g->gpf_off[F], 0);
+        std::vector<int64_t> cur(g->gpf_off.begin(), g->gpf_off.end() - 1);
+        for (int gi = 0; gi < nG; gi++)
+            for (int f = g_from[gi]; f < g_to[gi]; f++) g->gpf[(size_t)cur[f]++] = gi;
+    }
+    tm.mark("ages + groups_per_frame");
     // ---- conflicts (:446-500); emitted grouped by g1 in first-insertion order of g2
     {
         struct Acc { int64_t matched = 0, unmatched = 0, area_union = 0; double inter = 0; };
@@ -620,7 +687,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         };
         auto area = [&](int u) { return (int64_t)(ubox(u, 1) - ubox(u, 0) + 1) * (ubox(u, 3) - ubox(u, 2) + 1); };
         for (int a : g->stable)
-            for (const Aov& t : aov[a]) {
+            for (const Aov& t : aov(a)) {
                 const int b = t.other;
                 if (!(a < b)) continue;
                 const int64_t unmatched = (int64_t)t.size_self + t.size_other - (int64_t)t.matched * 2;
@@ -641,17 +708,20 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
                 g->conf_unmatched.push_back(e.second.unmatched); g->conf_union.push_back(e.second.area_union); g->conf_inter.push_back(e.second.inter);
             }
     }
+    tm.mark("conflicts");
     // flatten the neighbour lists
     g->tov_off.assign(1, 0); g->tov_other.clear(); g->tov_recall.clear(); g->tov_precision.clear();
     g->aov_off.assign(1, 0); g->aov_other.clear(); g->aov_matched.clear(); g->aov_size_other.clear(); g->aov_size_self.clear();
     for (int u = 0; u < nU; u++) {
-        for (const Tov& t : tov[u]) { g->tov_other.push_back(t.other); g->tov_recall.push_back(t.recall); g->tov_precision.push_back(t.precision); }
+        for (const Tov& t : tov(u)) { g->tov_other.push_back(t.other); g->tov_recall.push_back(t.recall); g->tov_precision.push_back(t.precision); }
         g->tov_off.push_back((int64_t)g->tov_other.size());
-        for (const Aov& t : aov[u]) { g->aov_other.push_back(t.other); g->aov_matched.push_back(t.matched); g->aov_size_other.push_back(t.size_other); g->aov_size_self.push_back(t.size_self); }
+        for (const Aov& t : aov(u)) { g->aov_other.push_back(t.other); g->aov_matched.push_back(t.matched); g->aov_size_other.push_back(t.size_other); g->aov_size_self.push_back(t.size_self); }
         g->aov_off.push_back((int64_t)g->aov_other.size());
     }
-    tm.mark("groups/ages/conflicts/flatten");
+    tm.mark("flatten neighbour lists");
     // ---- group images (:575-636)
+    std::vector<int32_t> ulist_frame(g->ulist_cc.size());
+    for (size_t e = 0; e < g->ulist_cc.size(); e++) ulist_frame[e] = cc_frame[(size_t)g->ulist_cc[e]];
     g->bounds.assign((size_t)nG * 4, 0);
     std::vector<LmGimgItem> items;
     std::vector<LmGimgMember> members;
@@ -676,12 +746,10 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
             it.mem_off = (int32_t)members.size();
             for (int64_t i = g->grp_off[gi]; i < g->grp_off[(size_t)gi + 1]; i++) {
                 const int u = g->grp_members[(size_t)i];
-                int count = 0;                              // entries with t0 <= frame <= t1, duplicates counted (:619)
-                for (int64_t e = g->ulist_off[u]; e < g->ulist_off[(size_t)u + 1]; e++) {
-                    const int fr = R(g->ulist_cc[(size_t)e], 6);
-                    if (fr > t1) break;
-                    if (fr >= t0) count++;
-                }
+                // entries with t0 <= frame <= t1, duplicates counted (:619); a unique's entries are in ascending frame order
+                const int32_t* fb = ulist_frame.data() + g->ulist_off[u];
+                const int32_t* fe = ulist_frame.data() + g->ulist_off[(size_t)u + 1];
+                const int count = (int)(std::upper_bound(fb, fe, t1) - std::lower_bound(fb, fe, t0));
                 if (count) members.push_back({g->uniq_cc[u], count});
             }
             it.mem_cnt = (int32_t)members.size() - it.mem_off;
@@ -714,29 +782,26 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         LM_HIP(hipGetLastError());
     }
     tm.mark("group images (host tables + device)");
-    // ---- render tables for frames_from_groups (:638-681)
+    // ---- render tables for frames_from_groups (:638-681): one item per (frame, live group), built on the device
     if (reconstruct_tables) {
-        std::vector<long long> fio((size_t)F + 1, 0);
-        std::vector<LmRenderItem> ritems;
-        for (int f = 0; f < F; f++) {
-            for (int64_t i = g->gpf_off[f]; i < g->gpf_off[(size_t)f + 1]; i++) {
-                const int gi = g->gpf[(size_t)i];
-                const int32_t* a = g->ages.data() + g->ages_off[gi];
-                const int na = (int)(g->ages_off[(size_t)gi + 1] - g->ages_off[gi]);
-                if (na < 2) continue;       // no segment image (the reference would raise IndexError at :650 here)
-                int sidx = 0;
-                while (sidx + 1 < na - 1 && a[sidx + 1] < f) sidx++;   // while ages[ptr+1] < img_idx: ptr += 1 (:650-652)
-                const int64_t item = g->gimg_item_off[gi] + sidx;
-                LmRenderItem ri;
-                ri.x0 = g->bounds[(size_t)gi * 4 + 0]; ri.y0 = g->bounds[(size_t)gi * 4 + 2];
-                ri.w = g->bounds[(size_t)gi * 4 + 1] - ri.x0 + 1; ri.h = g->bounds[(size_t)gi * 4 + 3] - ri.y0 + 1;
-                ri.bits_off = g->gbits_off[(size_t)item];
-                ritems.push_back(ri);
-            }
-            fio[(size_t)f + 1] = (long long)ritems.size();
+        std::vector<long long> fio(g->gpf_off.begin(), g->gpf_off.end());
+        std::vector<int32_t> ages_off32(g->ages_off.begin(), g->ages_off.end());
+        std::vector<int64_t> gitem_first(g->gimg_item_off.begin(), g->gimg_item_off.end() - 1);
+        int32_t *d_gpf, *d_ages, *d_ages_off, *d_bounds;
+        int64_t *d_gitem_first, *d_gbits_off;
+        const size_t n_ritems = g->gpf.size();
+        g->d_render_items = (LmRenderItem*)lm_galloc(g, std::max<size_t>(n_ritems, 1) * sizeof(LmRenderItem));
+        if (!g->d_render_items) return LM_ERR_HIP;
+        if (lm_upload(g, fio, &g->d_frame_item_off, st)) return LM_ERR_HIP;
+        if (n_ritems) {
+            if (lm_upload(g, g->gpf, &d_gpf, st) || lm_upload(g, g->ages, &d_ages, st) || lm_upload(g, ages_off32, &d_ages_off, st) ||
+                lm_upload(g, g->bounds, &d_bounds, st) || lm_upload(g, gitem_first, &d_gitem_first, st) ||
+                lm_upload(g, g->gbits_off, &d_gbits_off, st))
+                return LM_ERR_HIP;
+            hipLaunchKernelGGL(lm_k_render_items, dim3((unsigned)((n_ritems + 255) / 256)), dim3(256), 0, st, g->d_frame_item_off, F, d_gpf,
+                               d_ages, d_ages_off, d_bounds, d_gitem_first, d_gbits_off, g->d_render_items);
         }
-        if (lm_upload(g, fio, &g->d_frame_item_off, st) || lm_upload(g, ritems, &g->d_render_items, st)) return LM_ERR_HIP;
-        LM_HIP(hipStreamSynchronize(st));      // fio / ritems are locals: the async uploads must finish before they go out of scope
+        LM_HIP(hipStreamSynchronize(st));      // the uploaded vectors are locals: the async copies must finish before they go away
     }
     LM_HIP(hipStreamSynchronize(st));
     tm.mark("render tables + final sync");
