@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -427,6 +428,8 @@ extern "C" void lm_group_destroy(LmGroups* g)
     delete g;
 }
 
+#define LM_GROUP_THREADS 4     // host threads tabulating group images
+
 // LM_GROUP_TIMING=1 prints the wall time of every phase of lm_group_run to stderr
 struct LmPhaseTimer {
     bool on;
@@ -722,6 +725,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
     // ---- group images (:575-636)
     std::vector<int32_t> ulist_frame(g->ulist_cc.size());
     for (size_t e = 0; e < g->ulist_cc.size(); e++) ulist_frame[e] = cc_frame[(size_t)g->ulist_cc[e]];
+    tm.mark("  gimg: entry frames");
     g->bounds.assign((size_t)nG * 4, 0);
     std::vector<LmGimgItem> items;
     std::vector<LmGimgMember> members;
@@ -730,41 +734,91 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
     g->gbits_off.clear();
     long long bit_words = 0;
     g->gimg_item_off.assign(1, 0);
-    for (int gi = 0; gi < nG; gi++) {
-        int x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
-        for (int64_t i = g->grp_off[gi]; i < g->grp_off[(size_t)gi + 1]; i++) {
-            const int u = g->grp_members[(size_t)i];
-            x0 = std::min(x0, (int)ubox(u, 0)); x1 = std::max(x1, (int)ubox(u, 1));
-            y0 = std::min(y0, (int)ubox(u, 2)); y1 = std::max(y1, (int)ubox(u, 3));
-        }
-        g->bounds[(size_t)gi * 4 + 0] = x0; g->bounds[(size_t)gi * 4 + 1] = x1; g->bounds[(size_t)gi * 4 + 2] = y0; g->bounds[(size_t)gi * 4 + 3] = y1;
-        const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-        for (int64_t ai = g->ages_off[gi]; ai + 1 < g->ages_off[(size_t)gi + 1]; ai++) {
-            const int t0 = g->ages[(size_t)ai], t1 = g->ages[(size_t)ai + 1];
-            LmGimgItem it;
-            it.x0 = x0; it.y0 = y0; it.w = w; it.h = h;
-            it.mem_off = (int32_t)members.size();
+    // Groups are independent here: contiguous chunks of groups are tabulated by a few host threads into local tables
+    // (offsets relative to the chunk), then concatenated in group order.
+    struct Chunk {
+        std::vector<LmGimgItem> items; std::vector<LmGimgMember> members; std::vector<LmGimgUnit> units;
+        std::vector<int64_t> item_end;          // items of the chunk up to and including each group
+        long long img_bytes = 0, bit_words = 0;
+    };
+    const int n_chunks = std::max(1, std::min(LM_GROUP_THREADS, nG / 64));
+    std::vector<Chunk> chunks((size_t)n_chunks);
+    auto tabulate = [&](int ci) {
+        Chunk& ck = chunks[(size_t)ci];
+        std::vector<int32_t> seg_cnt;
+        const int g_lo = (int)((long long)nG * ci / n_chunks), g_hi = (int)((long long)nG * (ci + 1) / n_chunks);
+        for (int gi = g_lo; gi < g_hi; gi++) {
+            int x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
             for (int64_t i = g->grp_off[gi]; i < g->grp_off[(size_t)gi + 1]; i++) {
                 const int u = g->grp_members[(size_t)i];
-                // entries with t0 <= frame <= t1, duplicates counted (:619); a unique's entries are in ascending frame order
-                const int32_t* fb = ulist_frame.data() + g->ulist_off[u];
-                const int32_t* fe = ulist_frame.data() + g->ulist_off[(size_t)u + 1];
-                const int count = (int)(std::upper_bound(fb, fe, t1) - std::lower_bound(fb, fe, t0));
-                if (count) members.push_back({g->uniq_cc[u], count});
+                x0 = std::min(x0, (int)ubox(u, 0)); x1 = std::max(x1, (int)ubox(u, 1));
+                y0 = std::min(y0, (int)ubox(u, 2)); y1 = std::max(y1, (int)ubox(u, 3));
             }
-            it.mem_cnt = (int32_t)members.size() - it.mem_off;
-            it.img_off = g->gimg_off.back();
-            it.bits_off = bit_words;
-            g->gbits_off.push_back(bit_words);
-            bit_words += (long long)h * ((w + 31) >> 5);
-            const int item_idx = (int)items.size();
-            items.push_back(it);
-            g->gimg_off.push_back(it.img_off + (int64_t)w * h);
-            for (int ty = 0; ty * LM_GT < h; ty++)
-                for (int tx = 0; tx * LM_GT < w; tx++) units.push_back({item_idx, (int16_t)tx, (int16_t)ty});
+            g->bounds[(size_t)gi * 4 + 0] = x0; g->bounds[(size_t)gi * 4 + 1] = x1; g->bounds[(size_t)gi * 4 + 2] = y0; g->bounds[(size_t)gi * 4 + 3] = y1;
+            const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+            // entries of every member inside every segment [ages[j], ages[j+1]] (both ends included, duplicates counted, :619):
+            // a unique's entries and the ages are ascending, so one two-pointer walk per member serves all segments
+            const int nm = (int)(g->grp_off[(size_t)gi + 1] - g->grp_off[gi]);
+            const int ns = (int)(g->ages_off[(size_t)gi + 1] - g->ages_off[gi]) - 1;
+            const int32_t* ag = g->ages.data() + g->ages_off[gi];
+            seg_cnt.assign((size_t)std::max(ns, 0) * nm, 0);
+            for (int mi = 0; mi < nm && ns > 0; mi++) {
+                const int u = g->grp_members[(size_t)g->grp_off[gi] + mi];
+                const int32_t* fe = ulist_frame.data() + g->ulist_off[(size_t)u + 1];
+                const int32_t *lo = ulist_frame.data() + g->ulist_off[u], *hi = lo;
+                for (int j = 0; j < ns; j++) {
+                    while (lo < fe && *lo < ag[j]) lo++;
+                    if (hi < lo) hi = lo;
+                    while (hi < fe && *hi <= ag[j + 1]) hi++;
+                    seg_cnt[(size_t)j * nm + mi] = (int32_t)(hi - lo);
+                }
+            }
+            for (int j = 0; j < ns; j++) {
+                LmGimgItem it;
+                it.x0 = x0; it.y0 = y0; it.w = w; it.h = h;
+                it.mem_off = (int32_t)ck.members.size();
+                for (int mi = 0; mi < nm; mi++) {
+                    const int count = seg_cnt[(size_t)j * nm + mi];
+                    if (count) ck.members.push_back({g->uniq_cc[g->grp_members[(size_t)g->grp_off[gi] + mi]], count});
+                }
+                it.mem_cnt = (int32_t)ck.members.size() - it.mem_off;
+                it.img_off = ck.img_bytes;
+                it.bits_off = ck.bit_words;
+                ck.img_bytes += (long long)w * h;
+                ck.bit_words += (long long)h * ((w + 31) >> 5);
+                const int item_idx = (int)ck.items.size();
+                ck.items.push_back(it);
+                for (int ty = 0; ty * LM_GT < h; ty++)
+                    for (int tx = 0; tx * LM_GT < w; tx++) ck.units.push_back({item_idx, (int16_t)tx, (int16_t)ty});
+            }
+            ck.item_end.push_back((int64_t)ck.items.size());
         }
-        g->gimg_item_off.push_back((int64_t)items.size());
+    };
+    tm.mark("  gimg: setup");
+    {
+        std::vector<std::thread> workers;
+        for (int ci = 1; ci < n_chunks; ci++) workers.emplace_back(tabulate, ci);
+        tabulate(0);
+        for (auto& t : workers) t.join();
     }
+    tm.mark("  gimg: threads");
+    for (const Chunk& ck : chunks) {
+        const int64_t item0 = (int64_t)items.size();
+        const int32_t mem0 = (int32_t)members.size();
+        const long long img0 = g->gimg_off.back();
+        for (LmGimgItem it : ck.items) {
+            it.mem_off += mem0; it.img_off += img0; it.bits_off += bit_words;
+            g->gbits_off.push_back(it.bits_off);
+            g->gimg_off.push_back(it.img_off + (int64_t)it.w * it.h);
+            items.push_back(it);
+        }
+        members.insert(members.end(), ck.members.begin(), ck.members.end());
+        for (LmGimgUnit un : ck.units) { un.item += (int32_t)item0; units.push_back(un); }
+        for (int64_t e : ck.item_end) g->gimg_item_off.push_back(item0 + e);
+        bit_words += ck.bit_words;
+    }
+    if (tm.on) fprintf(stderr, "[lm_group]   groups %d items %zu members %zu units %zu chunks %d pairs %zu\n", nG, items.size(), members.size(), units.size(), n_chunks, g->pair_a.size());
+    tm.mark("  gimg: item tables");
     const long long img_bytes = g->gimg_off.back();
     g->d_images = (uint8_t*)lm_galloc(g, (size_t)std::max<long long>(img_bytes, 1));
     g->d_gbits = (uint32_t*)lm_galloc(g, (size_t)std::max<long long>(bit_words, 1) * sizeof(uint32_t));
@@ -772,6 +826,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
     if (!items.empty()) {
         LmGimgItem* d_items; LmGimgMember* d_members; LmGimgUnit* d_units; int32_t* d_max;
         if (lm_upload(g, items, &d_items, st) || lm_upload(g, members, &d_members, st) || lm_upload(g, units, &d_units, st)) return LM_ERR_HIP;
+        tm.mark("  gimg: uploads");
         d_max = (int32_t*)lm_galloc(g, items.size() * sizeof(int32_t));
         if (!d_max) return LM_ERR_HIP;
         LM_HIP(hipMemsetAsync(d_max, 0, items.size() * sizeof(int32_t), st));
