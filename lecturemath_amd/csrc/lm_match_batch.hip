@@ -32,10 +32,11 @@
 #define LM_MB_TTAB (1 << 18)     // twin table slots; batches with more than LM_MB_TTAB / 2 CCs skip twin detection
 #define LM_MB_CHUNK 4096        // source boxes filtered per round (LDS survivors list)
 #define LM_MB_MAX_FRAMES 64     // frames per batch (per-frame tables of the replay kernel live in LDS)
-#define LM_MB_CH 4096           // CCs of one frame resolved per LDS pass
+#define LM_MB_CH 2048           // CCs of one frame resolved per LDS pass
 #define LM_MB_LA 16384          // active positions whose last-matched frame is cached in LDS by the replay kernel
 #define LM_MB_LS 16384          // sources whose active position is cached in LDS by the replay kernel
-#define LM_MB_PF 8              // pairs per thread and list prefetched one frame ahead
+#define LM_MB_PFA 6             // pairs per thread prefetched one frame ahead: against earlier uniques ...
+#define LM_MB_PFB 2             // ... and against in-batch sources
 #define LM_MB_RESOLVE_SMEM ((size_t)LM_MB_CH * 4 + (size_t)LM_MB_LA * 4 + (size_t)LM_MB_LS * 4)
 
 struct LmMatchBatch {
@@ -445,12 +446,16 @@ __global__ void __launch_bounds__(1024) lm_k_mb_sources(const LmCcRec* __restric
 #define LM_MB_ITEMS (LM_MB_CH / 1024)
 
 LM_DEV void lm_mb_prefetch(const LmMatchBatch& mb, unsigned pA0, unsigned pA1, unsigned pB0, unsigned pB1, long long c_abs0, int n,
-                           uint2 (&ra)[LM_MB_PF], uint2 (&rb)[LM_MB_PF], int (&rs)[LM_MB_ITEMS])
+                           uint2 (&ra)[LM_MB_PFA], uint2 (&rb)[LM_MB_PFB], int (&rs)[LM_MB_ITEMS])
 {
 #pragma unroll
-    for (int k = 0; k < LM_MB_PF; k++) {
-        const unsigned pa = pA0 + (unsigned)k * 1024u + threadIdx.x, pb = pB0 + (unsigned)k * 1024u + threadIdx.x;
+    for (int k = 0; k < LM_MB_PFA; k++) {
+        const unsigned pa = pA0 + (unsigned)k * 1024u + threadIdx.x;
         ra[k] = (pa < pA1) ? mb.pairs[0][pa] : make_uint2(0u, 0xffffffffu);
+    }
+#pragma unroll
+    for (int k = 0; k < LM_MB_PFB; k++) {
+        const unsigned pb = pB0 + (unsigned)k * 1024u + threadIdx.x;
         rb[k] = (pb < pB1) ? mb.pairs[1][pb] : make_uint2(0u, 0xffffffffu);
     }
 #pragma unroll
@@ -495,6 +500,7 @@ __global__ void __launch_bounds__(1024) lm_k_mb_resolve(const LmCcRec* __restric
     __shared__ int s_c0[LM_MB_MAX_FRAMES + 1];
     __shared__ unsigned s_tA[LM_MB_MAX_FRAMES + 1], s_tB[LM_MB_MAX_FRAMES + 1];
     __shared__ int s_fail;
+    __shared__ unsigned s_wsum[16];
     __shared__ unsigned long long s_tempo;
     if (cnt->error) return;
     const int nt = mb.ftile[B];
@@ -517,7 +523,7 @@ __global__ void __launch_bounds__(1024) lm_k_mb_resolve(const LmCcRec* __restric
     for (int i = threadIdx.x; i < nA0 && i < LM_MB_LA; i += 1024) s_last[i] = active_last[i];
     for (int k = threadIdx.x; k < nS && k < LM_MB_LS; k += 1024) s_newpos[k] = -1;
     __syncthreads();
-    uint2 ra[LM_MB_PF], rb[LM_MB_PF];
+    uint2 ra[LM_MB_PFA], rb[LM_MB_PFB];
     int rs[LM_MB_ITEMS];
     lm_mb_prefetch(mb, s_tA[0], s_tA[1], s_tB[0], s_tB[1], C0 + s_c0[0], s_c0[1] - s_c0[0], ra, rb, rs);
 
@@ -543,15 +549,15 @@ __global__ void __launch_bounds__(1024) lm_k_mb_resolve(const LmCcRec* __restric
             // ---- pairs against uniques that existed before the batch / born inside it
             if (single) {
 #pragma unroll
-                for (int k = 0; k < LM_MB_PF; k++) {
+                for (int k = 0; k < LM_MB_PFA; k++)
                     if (ra[k].y != 0xffffffffu) lm_mb_pair_old(ra[k], f, max_gap, rel0, s_best, s_last, active_last, tempo);
+#pragma unroll
+                for (int k = 0; k < LM_MB_PFB; k++)
                     if (rb[k].y != 0xffffffffu) lm_mb_pair_new(rb[k], f, max_gap, rel0, s_best, s_last, s_newpos, active_last, mb.newpos, tempo);
-                }
             }
-            const unsigned skip = single ? (unsigned)LM_MB_PF * 1024u : 0u;
-            for (unsigned p = pA0 + skip + threadIdx.x; p < pA1; p += 1024)
+            for (unsigned p = pA0 + (single ? (unsigned)LM_MB_PFA * 1024u : 0u) + threadIdx.x; p < pA1; p += 1024)
                 lm_mb_pair_old(mb.pairs[0][p], f, max_gap, rel0, s_best, s_last, active_last, tempo);
-            for (unsigned p = pB0 + skip + threadIdx.x; p < pB1; p += 1024)
+            for (unsigned p = pB0 + (single ? (unsigned)LM_MB_PFB * 1024u : 0u) + threadIdx.x; p < pB1; p += 1024)
                 lm_mb_pair_new(mb.pairs[1][p], f, max_gap, rel0, s_best, s_last, s_newpos, active_last, mb.newpos, tempo);
             int cur_s[LM_MB_ITEMS];
 #pragma unroll
@@ -580,8 +586,19 @@ __global__ void __launch_bounds__(1024) lm_k_mb_resolve(const LmCcRec* __restric
                 }
                 mine += isnew[k];
             }
-            unsigned tot;
-            unsigned o = lds_only ? lm_block_excl_scan_lds<1024>(mine, &tot) : lm_block_excl_scan<1024>(mine, &tot);
+            // exclusive scan of the new-unique flags with ONE barrier: wave totals to LDS, every thread sums the waves before it
+            // (s_wsum is rewritten only after the barrier that ends this chunk)
+            const unsigned incl = lm_wave_incl_scan(mine);
+            if (lm_lane() == 63) s_wsum[threadIdx.x >> 6] = incl;
+            if (lds_only) lm_lds_barrier(); else __syncthreads();
+            unsigned tot = 0, before = 0;
+#pragma unroll
+            for (int w = 0; w < 16; w++) {
+                const unsigned t = s_wsum[w];
+                before += (w < (int)(threadIdx.x >> 6)) ? t : 0u;
+                tot += t;
+            }
+            unsigned o = before + incl - mine;
 #pragma unroll
             for (int k = 0; k < LM_MB_ITEMS; k++) {
                 if (!isnew[k]) continue;

@@ -37,6 +37,13 @@ def test_stream_match_paths_agree(hip_lib, oracle_built):
     lm_checks.check_stream_match_paths(hip_lib, n_frames=97, max_gap=1, seed=4)
 
 
+def test_stream_frames_with_thousands_of_ccs(hip_lib, oracle_built):
+    """~3.7k kept CCs per frame: more than one LDS pass of the replay kernel (2048 CCs) and several join chunks."""
+    frames = lm_checks.dot_grid_stream(n_frames=6, h=200, w=800, seed=8)
+    r = lm_checks.check_stream_oracle(hip_lib, frames, max_gap=2, max_batch=4, max_ccs=1 << 16, max_crop_words=1 << 20)
+    assert len(r["cc_idx_per_frame"][0]) > 3000
+
+
 def test_stream_vs_oracle_random_noise(hip_lib, oracle_built):
     rng = np.random.default_rng(11)
     base = (rng.random((120, 200)) < 0.5)
