@@ -167,6 +167,86 @@ lm_f32x16 hipemu_mfma_32x32x16f16(lm_h8 a, lm_h8 b, lm_f32x16 c);
 #define LM_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #endif
 
+// Staging is software-pipelined: the next group of weights and the next chunk's input patch are fetched into registers
+// while the MFMAs of the current group run (weights double-buffered in LDS, one LDS-only barrier per group -- a full
+// __syncthreads() would drain the prefetches).
+#define LM_CV_MAXP 8        // float4 patch items per thread (22 x 22 px x 4 / 256 for 7x7)
+#define LM_CV_MAXW 8        // 16-B weight items per thread and group: taps-per-group x NT <= 16
+
+LM_DEV void lm_cv_load_patch(const LmConvArgs& a, int ch, int ty0, int tx0, int pad, int PW, int items, int ctot, float4 (&pr)[LM_CV_MAXP])
+{
+#pragma unroll
+    for (int k = 0; k < LM_CV_MAXP; k++) {
+        const int i = (int)threadIdx.x + k * 256;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < items) {
+            const int px = i >> 2, q = i & 3;
+            const int py = px / PW, pxx = px - py * PW;
+            const int y = ty0 + py - pad, x = tx0 + pxx - pad;
+            const int cl = ch * 16 + q * 4;                     // logical (concatenated) channel
+            if (y >= 0 && y < a.H && x >= 0 && x < a.W && cl < ctot) {
+                const long long p = (long long)y * a.W + x;
+                v = (cl < a.c0) ? *(const float4*)(a.in0 + p * a.ps0 + cl) : *(const float4*)(a.in1 + p * a.ps1 + (cl - a.c0));
+            }
+        }
+        pr[k] = v;
+    }
+}
+
+// LDS patch layout: pixel stride 80 B (16 hi + 16 lo halfs + 16 B pad), row stride rounded up to 256 B.  ds_read_b128 is
+// serviced in 16-lane groups that mix lanes of two patch rows ({0-3,12-15,20-27}, ...): with the row stride a multiple of
+// the 256-B bank row the 16 lanes of a group fall on pixels 0..15 of one residue class, i.e. on 16 distinct 16-B slots
+// (5 slots per pixel, 5 coprime to 16).  Measured before the padding: 37-39 % of the LDS cycles were bank conflicts.
+LM_DEV int lm_cv_row_bytes(int PW) { return (PW * 80 + 255) & ~255; }
+
+LM_DEV void lm_cv_store_patch(char* s_patch, int PW, int items, const float4 (&pr)[LM_CV_MAXP])
+{
+    const int RB = lm_cv_row_bytes(PW);
+#pragma unroll
+    for (int k = 0; k < LM_CV_MAXP; k++) {
+        const int i = (int)threadIdx.x + k * 256;
+        if (i < items) {
+            const int px = i >> 2, q = i & 3;
+            const int py = px / PW, pxx = px - py * PW;
+            char* dst = s_patch + py * RB + pxx * 80;
+            const float4 v = pr[k];
+            lm_h4 hi, lo;
+            hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+            lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
+            lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
+            *(lm_h4*)(dst + q * 8) = hi;
+            *(lm_h4*)(dst + 32 + q * 8) = lo;
+        }
+    }
+}
+
+template <int NT>
+LM_DEV void lm_cv_load_w(const LmConvArgs& a, int ch, int t0, int ntg, int taps, int nb0, uint4 (&wr)[LM_CV_MAXW])
+{
+    const uint4* wsrc = (const uint4*)a.wpk + (long long)ch * taps * a.nblocks * 128;
+    const int n16 = ntg * NT * 128;
+#pragma unroll
+    for (int k = 0; k < LM_CV_MAXW; k++) {
+        const int i = (int)threadIdx.x + k * 256;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (i < n16) {
+            const int t = i / (NT * 128), rem = i - t * (NT * 128);
+            const int nb = rem >> 7, u = rem & 127;
+            if (nb0 + nb < a.nblocks) v = wsrc[(long long)((t0 + t) * a.nblocks + nb0 + nb) * 128 + u];
+        }
+        wr[k] = v;
+    }
+}
+
+LM_DEV void lm_cv_store_w(char* s_w, int n16, const uint4 (&wr)[LM_CV_MAXW])
+{
+#pragma unroll
+    for (int k = 0; k < LM_CV_MAXW; k++) {
+        const int i = (int)threadIdx.x + k * 256;
+        if (i < n16) *(uint4*)(s_w + (long long)i * 16) = wr[k];
+    }
+}
+
 template <int NT>
 __global__ void __launch_bounds__(256) lm_k_conv_mfma_h(const LmConvArgs a)
 {
@@ -174,14 +254,18 @@ __global__ void __launch_bounds__(256) lm_k_conv_mfma_h(const LmConvArgs a)
     constexpr int PB = 80;                  // bytes per pixel in LDS
     const int K = a.K, pad = (K - 1) >> 1, taps = K * K;
     const int PW = 16 + K - 1, PH = 16 + K - 1;
+    const int patch_items = PH * PW * 4;
     char* s_patch = smem;
-    char* s_w = s_patch + ((PH * PW * PB + 15) & ~15);          // [tap][NT][2][64] x 16 B
+    const int RB = lm_cv_row_bytes(PW);
+    char* s_wbuf = s_patch + PH * RB;                           // 2 x [tap in group][NT][2][64] x 16 B
+    const int wbuf_bytes = a.tg * NT * 2048;
     const int tiles_x = (a.W + 15) >> 4;
     const int ty0 = (blockIdx.x / tiles_x) << 4, tx0 = (blockIdx.x % tiles_x) << 4;
     const int nb0 = blockIdx.y * NT;
     const int lane = lm_lane(), wave = (int)(threadIdx.x >> 6), half = lane >> 5;
     const int ctot = a.c0 + a.c1;
     const int nchunks = (ctot + 15) >> 4;
+    const int ngroups = (taps + a.tg - 1) / a.tg;
 
     lm_f32x16 acc[2][NT];
 #pragma unroll
@@ -193,49 +277,34 @@ __global__ void __launch_bounds__(256) lm_k_conv_mfma_h(const LmConvArgs a)
     const int pi = lane & 31;
     const int prow = wave * 4 + (pi >> 4), pcol = pi & 15;
 
+    float4 pr[LM_CV_MAXP];
+    uint4 wr[LM_CV_MAXW];
+    lm_cv_load_patch(a, 0, ty0, tx0, pad, PW, patch_items, ctot, pr);
+    lm_cv_load_w<NT>(a, 0, 0, a.tg < taps ? a.tg : taps, taps, nb0, wr);
+    int buf = 0;
     for (int ch = 0; ch < nchunks; ch++) {
-        __syncthreads();
-        // ---- stage + split the input patch: 4 channels (one float4) per item, zero outside the image / channel range
-        for (int i = threadIdx.x; i < PH * PW * 4; i += blockDim.x) {
-            const int px = i >> 2, q = i & 3;
-            const int py = px / PW, pxx = px - py * PW;
-            const int y = ty0 + py - pad, x = tx0 + pxx - pad;
-            const int cl = ch * 16 + q * 4;                     // logical (concatenated) channel
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (y >= 0 && y < a.H && x >= 0 && x < a.W && cl < ctot) {
-                const long long p = (long long)y * a.W + x;
-                v = (cl < a.c0) ? *(const float4*)(a.in0 + p * a.ps0 + cl) : *(const float4*)(a.in1 + p * a.ps1 + (cl - a.c0));
+        lm_lds_barrier();                                       // everybody is done with the previous chunk's patch
+        lm_cv_store_patch(s_patch, PW, patch_items, pr);
+        if (ch + 1 < nchunks) lm_cv_load_patch(a, ch + 1, ty0, tx0, pad, PW, patch_items, ctot, pr);   // in flight for a whole chunk
+        for (int g = 0; g < ngroups; g++) {
+            const int t0 = g * a.tg;
+            const int ntg = (taps - t0 < a.tg) ? taps - t0 : a.tg;
+            char* s_w = s_wbuf + buf * wbuf_bytes;
+            lm_cv_store_w(s_w, ntg * NT * 128, wr);
+            lm_lds_barrier();       // group g (and, for g == 0, the patch) visible; buffer `buf` was last read two groups ago
+            if (g + 1 < ngroups) {
+                const int t1 = t0 + a.tg;
+                lm_cv_load_w<NT>(a, ch, t1, (taps - t1 < a.tg) ? taps - t1 : a.tg, taps, nb0, wr);
+            } else if (ch + 1 < nchunks) {
+                lm_cv_load_w<NT>(a, ch + 1, 0, a.tg < taps ? a.tg : taps, taps, nb0, wr);
             }
-            lm_h4 hi, lo;
-            hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
-            lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
-            lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
-            *(lm_h4*)(s_patch + px * PB + q * 8) = hi;
-            *(lm_h4*)(s_patch + px * PB + 32 + q * 8) = lo;
-        }
-        // ---- weights are staged a.tg taps at a time (one kernel row for 7x7): a small LDS footprint lets ~3 blocks share a
-        // CU and hide each other's staging -- with f16 MFMAs the arithmetic of a chunk is shorter than its loads
-        for (int t0 = 0; t0 < taps; t0 += a.tg) {
-            if (t0) __syncthreads();
-            {
-                const uint4* wsrc = (const uint4*)a.wpk + (long long)ch * taps * a.nblocks * 128;
-                const int n16 = a.tg * NT * 128;
-                for (int i = threadIdx.x; i < n16; i += blockDim.x) {
-                    const int t = i / (NT * 128), rem = i - t * (NT * 128);
-                    const int nb = rem >> 7, u = rem & 127;
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (nb0 + nb < a.nblocks) v = wsrc[(long long)((t0 + t) * a.nblocks + nb0 + nb) * 128 + u];
-                    *(uint4*)(s_w + (long long)i * 16) = v;
-                }
-            }
-            __syncthreads();
-            for (int tt = 0; tt < a.tg; tt++) {
+            for (int tt = 0; tt < ntg; tt++) {
                 const int t = t0 + tt;
                 const int kh = t / K, kw = t - kh * K;
                 lm_h8 ah[2], al[2], bh[NT], bl[NT];
 #pragma unroll
                 for (int m = 0; m < 2; m++) {
-                    const char* pp = s_patch + ((prow + m * 2 + kh) * PW + pcol + kw) * PB + half * 16;
+                    const char* pp = s_patch + (prow + m * 2 + kh) * RB + (pcol + kw) * PB + half * 16;
                     ah[m] = *(const lm_h8*)pp;
                     al[m] = *(const lm_h8*)(pp + 32);
                 }
@@ -245,15 +314,22 @@ __global__ void __launch_bounds__(256) lm_k_conv_mfma_h(const LmConvArgs a)
                     bh[n] = *(const lm_h8*)wp;
                     bl[n] = *(const lm_h8*)(wp + 64 * 16);
                 }
+                // the three products of one accumulator are a dependent chain: issue them term by term across the 2 * NT
+                // accumulators so that neighbouring MFMAs are independent
 #pragma unroll
                 for (int m = 0; m < 2; m++)
 #pragma unroll
-                    for (int n = 0; n < NT; n++) {
-                        acc[m][n] = LM_MFMA_F16(ah[m], bh[n], acc[m][n]);
-                        acc[m][n] = LM_MFMA_F16(ah[m], bl[n], acc[m][n]);
-                        acc[m][n] = LM_MFMA_F16(al[m], bh[n], acc[m][n]);
-                    }
+                    for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA_F16(ah[m], bh[n], acc[m][n]);
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA_F16(ah[m], bl[n], acc[m][n]);
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA_F16(al[m], bh[n], acc[m][n]);
             }
+            buf ^= 1;
         }
     }
     const int cj = lane & 31;
@@ -274,6 +350,83 @@ __global__ void __launch_bounds__(256) lm_k_conv_mfma_h(const LmConvArgs a)
                 a.out[opix * a.ops + a.ooff + co] = v;
             }
     }
+}
+
+// 2x2 stride-2 transposed convolution (fp16-split operands): the four (dy, dx) sub-convolutions are 1x1 GEMMs over the SAME
+// input pixels, so one workgroup stages a 16x16-px patch chunk once, reads its A fragments once and feeds four accumulator
+// sets (weights packed like a conv with 4 taps, tap = dy * 2 + dx).  One n-block (32 output channels) per workgroup.
+__global__ void __launch_bounds__(256) lm_k_convT_mfma_h(const LmConvArgs a)
+{
+    LM_DYN_SMEM(smem);
+    constexpr int PW = 16, TAPS = 4;
+    const int RB = lm_cv_row_bytes(PW);
+    char* s_patch = smem;
+    char* s_wbuf = s_patch + PW * RB;                           // 2 x [tap][2][64] x 16 B
+    const int tiles_x = (a.W + 15) >> 4;
+    const int ty0 = (blockIdx.x / tiles_x) << 4, tx0 = (blockIdx.x % tiles_x) << 4;
+    const int nb0 = blockIdx.y;
+    const int lane = lm_lane(), wave = (int)(threadIdx.x >> 6), half = lane >> 5;
+    const int ctot = a.c0 + a.c1;
+    const int nchunks = (ctot + 15) >> 4;
+    lm_f32x16 acc[TAPS][2];
+#pragma unroll
+    for (int t = 0; t < TAPS; t++)
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[t][m][r] = 0.0f;
+    const int pi = lane & 31;
+    const int prow = wave * 4 + (pi >> 4), pcol = pi & 15;
+    float4 pr[LM_CV_MAXP];
+    uint4 wr[LM_CV_MAXW];
+    lm_cv_load_patch(a, 0, ty0, tx0, 0, PW, PW * PW * 4, ctot, pr);
+    lm_cv_load_w<1>(a, 0, 0, TAPS, TAPS, nb0, wr);
+    int buf = 0;
+    for (int ch = 0; ch < nchunks; ch++) {
+        char* s_w = s_wbuf + buf * (TAPS * 2048);
+        lm_lds_barrier();                                       // the previous chunk's patch has been read by everybody
+        lm_cv_store_patch(s_patch, PW, PW * PW * 4, pr);
+        lm_cv_store_w(s_w, TAPS * 128, wr);
+        lm_lds_barrier();
+        if (ch + 1 < nchunks) {
+            lm_cv_load_patch(a, ch + 1, ty0, tx0, 0, PW, PW * PW * 4, ctot, pr);
+            lm_cv_load_w<1>(a, ch + 1, 0, TAPS, TAPS, nb0, wr);
+        }
+        lm_h8 ah[2], al[2];
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const char* pp = s_patch + (prow + m * 2) * RB + pcol * 80 + half * 16;
+            ah[m] = *(const lm_h8*)pp;
+            al[m] = *(const lm_h8*)(pp + 32);
+        }
+#pragma unroll
+        for (int t = 0; t < TAPS; t++) {
+            const char* wp = s_w + ((long long)t * 128 + lane) * 16;
+            const lm_h8 bh = *(const lm_h8*)wp, bl = *(const lm_h8*)(wp + 64 * 16);
+#pragma unroll
+            for (int m = 0; m < 2; m++) acc[t][m] = LM_MFMA_F16(ah[m], bh, acc[t][m]);
+#pragma unroll
+            for (int m = 0; m < 2; m++) acc[t][m] = LM_MFMA_F16(ah[m], bl, acc[t][m]);
+#pragma unroll
+            for (int m = 0; m < 2; m++) acc[t][m] = LM_MFMA_F16(al[m], bh, acc[t][m]);
+        }
+        buf ^= 1;
+    }
+    const int co = nb0 * 32 + (lane & 31);
+    if (co >= a.Cout) return;
+    const float b = a.bias[co];
+#pragma unroll
+    for (int t = 0; t < TAPS; t++)
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int y = ty0 + wave * 4 + m * 2 + (i >> 4), x = tx0 + (i & 15);
+                if (y >= a.H || x >= a.W) continue;
+                const long long opix = (long long)(2 * y + (t >> 1)) * a.OW + (2 * x + (t & 1));
+                a.out[opix * a.ops + a.ooff + co] = lm_act(acc[t][m][r] + b, a.act);
+            }
 }
 
 // rows / columns of a transposed-conv output that no input pixel reaches (output_size = 2*in + 1): act(bias)
@@ -549,10 +702,17 @@ template <int CK, int NT> static int lm_launch_conv_t(const LmConvArgs& a, hipSt
 
 static int lm_conv_tg(int K) { return (K >= 5) ? K : K * K; }     // weights staged per kernel row for 5x5 / 7x7
 
+// taps per weight group of the fp16-split kernel: a kernel row at most, and at most LM_CV_MAXW 16-B items per thread
+static int lm_conv_tg_h(int K, int NT)
+{
+    const int want = lm_conv_tg(K), cap = (LM_CV_MAXW * 2) / NT;
+    return want < cap ? want : cap;
+}
+
 static size_t lm_conv_smem_h(int K, int NT)
 {
     const int P = 16 + K - 1;
-    return (((size_t)P * P * 80 + 15) & ~(size_t)15) + (size_t)lm_conv_tg(K) * NT * 2048;
+    return (size_t)P * (((size_t)P * 80 + 255) & ~(size_t)255) + 2 * (size_t)lm_conv_tg_h(K, NT) * NT * 2048;   // rows padded to 256 B, weights double-buffered
 }
 
 template <int NT> static int lm_launch_conv_h(const LmConvArgs& a, hipStream_t st)
@@ -567,7 +727,7 @@ template <int NT> static int lm_launch_conv_h(const LmConvArgs& a, hipStream_t s
 #endif
     const int tiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
     LmConvArgs b = a;
-    b.tg = lm_conv_tg(a.K);
+    b.tg = lm_conv_tg_h(a.K, NT);
     hipLaunchKernelGGL((lm_k_conv_mfma_h<NT>), dim3(tiles, (a.nblocks + NT - 1) / NT), dim3(256), smem, st, b);
     LM_HIP(hipGetLastError());
     return LM_OK;
@@ -621,7 +781,17 @@ static int lm_convT_layer(LmFcn* f, int layer, const float* in, int cin, int H, 
     const int nblocks = (l.cout + 31) / 32;
     // floats per (dy, dx) weight set: fp32 packing [chunk][ks][nblock][64][4]; f16x3 packing [chunk][nblock][2][64] x 16 B
     const long long per_set = l.ck ? (long long)(cin / l.ck) * (l.ck / 8) * nblocks * 256 : (long long)((cin + 15) / 16) * nblocks * 512;
-    for (int d = 0; d < 4; d++) {
+    if (l.ck == 0) {        // fp16-split: one launch, the four (dy, dx) weight sets are the four taps of the packing
+        LmConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in0 = in; a.c0 = cin; a.ps0 = cin; a.H = H; a.W = W;
+        a.wpk = l.w; a.bias = l.bias; a.out = out; a.ops = l.cout; a.ooff = 0; a.Cout = l.cout; a.nblocks = nblocks;
+        a.K = 1; a.act = LM_ACT_GELU; a.tmode = 1; a.OH = OH; a.OW = OW;
+        const size_t smem = (size_t)16 * ((16 * 80 + 255) & ~255) + 2 * 4 * 2048;
+        hipLaunchKernelGGL(lm_k_convT_mfma_h, dim3(((W + 15) / 16) * ((H + 15) / 16), nblocks), dim3(256), smem, st, a);
+        LM_HIP(hipGetLastError());
+    }
+    for (int d = 0; d < 4 && l.ck != 0; d++) {
         LmConvArgs a;
         memset(&a, 0, sizeof(a));
         a.in0 = in; a.c0 = cin; a.ps0 = cin; a.H = H; a.W = W;

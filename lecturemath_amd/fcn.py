@@ -167,8 +167,11 @@ class FcnEngine:
             wt = _np(sd["transposed_conv_%d.weight" % lvl]).astype(np.float32)          # [Cin][Cout][2][2]
             bt = _np(sd["transposed_conv_%d.bias" % lvl]).astype(np.float32)
             wt, bt = fold_bn(wt, bt, sd, "upsample_block_%d.0" % lvl, 1)
-            sets = [mfma(np.ascontiguousarray(wt[:, :, dy, dx].T)[:, :, None, None], range(tin), tin) for dy in (0, 1) for dx in (0, 1)]
-            self._set(L_UPT + i, np.concatenate([p for p, _ in sets]), bias_pad(bt), tin, u, 1, sets[0][1])
+            if h:       # one launch: the four (dy, dx) sets are the four "taps" of the packing (lm_k_convT_mfma_h)
+                self._set(L_UPT + i, pack_mfma_h(np.ascontiguousarray(wt.transpose(1, 0, 2, 3)), range(tin), tin), bias_pad(bt), tin, u, 1, 0)
+            else:
+                sets = [mfma(np.ascontiguousarray(wt[:, :, dy, dx].T)[:, :, None, None], range(tin), tin) for dy in (0, 1) for dx in (0, 1)]
+                self._set(L_UPT + i, np.concatenate([p for p, _ in sets]), bias_pad(bt), tin, u, 1, sets[0][1])
             w, b = conv_bn("conv_up_block_%d" % lvl)                                      # input = cat(up, skip_pre)
             wpk, ck = mfma(w, range(u + skip), (u, skip))
             self._set(L_UPC + i, wpk, bias_pad(b), u + skip, c, self.kk, ck)
