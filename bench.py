@@ -174,7 +174,9 @@ def main():
         slots.append({"fs": fs, "binary": torch.empty((F, H, W), dtype=torch.uint8, device="cuda"),
                       "labels": None if a.no_labels else torch.empty((a.batch, H, W), dtype=torch.int32, device="cuda"),
                       "clean": torch.empty((a.batch, H, W), dtype=torch.uint8, device="cuda"),
-                      "s_front": torch.cuda.Stream(), "s_back": torch.cuda.Stream(), "done": torch.cuda.Event(),
+                      # steps 01-02 are the bandwidth-bound part: their stream gets the higher priority, step 03's small kernels fill in
+                      "s_front": torch.cuda.Stream(priority=0 if os.environ.get("LM_BENCH_NO_PRIO") else -1), "s_back": torch.cuda.Stream(),
+                      "done": torch.cuda.Event(),
                       "rdone": torch.cuda.Event(), "gr": None})
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, depth - 1))
 

@@ -277,6 +277,8 @@ __global__ void __launch_bounds__(512) lm_k_band(const uint8_t* __restrict__ img
     for (int i = threadIdx.x; i < n; i += blockDim.x) par_g[i] = band * slot + lm_find(s_par, i);
 }
 
+#define LM_SEAM_CAP 1024       // contacts of one seam row kept in LDS (a row of W px has at most W / 2)
+
 // K4b: seam rows between bands (device-scope atomics in L2), and -- for the rare bands whose forest did not fit the LDS
 // (very dense frames) -- all of the band's own contacts as well.  One block per (band, frame).
 __global__ void __launch_bounds__(256) lm_k_seam_union(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
@@ -289,9 +291,22 @@ __global__ void __launch_bounds__(256) lm_k_seam_union(const uint64_t* __restric
     const int y1 = (y0 + LM_BAND_ROWS < H) ? y0 + LM_BAND_ROWS : H;
     const long long row0 = (long long)b * H + y0;
     int32_t* par = parent + (long long)b * cap;
-    if (band > 0)       // contacts of the band's first row with the last row of the band above
+    // contacts of the band's first row with the last row of the band above: enumerated into LDS first (bit tricks only),
+    // then one union per thread -- the unions are chains of dependent L2 accesses, so they must run side by side
+    __shared__ int2 s_contact[LM_SEAM_CAP];
+    __shared__ int s_ncontact;
+    if (threadIdx.x == 0) s_ncontact = 0;
+    __syncthreads();
+    if (band > 0)
         for (int w = threadIdx.x; w < WW; w += blockDim.x)
-            lm_cell_contacts(bits, starts, prefix, rowoff, row0, w, WW, [&](int a, int c) { lm_union(par, a, c); });
+            lm_cell_contacts(bits, starts, prefix, rowoff, row0, w, WW, [&](int a, int c) {
+                const int slot = atomicAdd(&s_ncontact, 1);
+                if (slot < LM_SEAM_CAP) s_contact[slot] = make_int2(a, c);
+                else lm_union(par, a, c);
+            });
+    __syncthreads();
+    const int ncontact = s_ncontact < LM_SEAM_CAP ? s_ncontact : LM_SEAM_CAP;
+    for (int i = threadIdx.x; i < ncontact; i += blockDim.x) lm_union(par, s_contact[i].x, s_contact[i].y);
     if (band_fallback[b * gridDim.x + band])
         for (int cell = threadIdx.x; cell < (y1 - y0 - 1) * WW; cell += blockDim.x) {
             const int r = cell / WW, w = cell - r * WW;
@@ -309,8 +324,8 @@ __global__ void __launch_bounds__(256) lm_k_seam_union(const uint64_t* __restric
 // K5a: one block per (band, frame): flatten, root flags (one ballot per 64 runs), and -- since the block sees all of its
 // band's flags -- the exclusive popcount prefix of the band's 64-run words and the band's root count.
 __global__ void __launch_bounds__(256) lm_k_flatten_flag(int32_t* __restrict__ parent, const int32_t* __restrict__ band_runs,
-                                                         unsigned long long* __restrict__ rootbits, uint32_t* __restrict__ wordprefix,
-                                                         uint32_t* __restrict__ band_roots, int slot, int cap, int capw)
+                                                          unsigned long long* __restrict__ rootbits, uint32_t* __restrict__ wordprefix,
+                                                          uint32_t* __restrict__ band_roots, int slot, int cap, int capw)
 {
     const int b = blockIdx.y, band = blockIdx.x;
     const int n = band_runs[b * gridDim.x + band];
@@ -396,7 +411,7 @@ __global__ void __launch_bounds__(256) lm_k_apply_labels(const int32_t* __restri
 __global__ void __launch_bounds__(256) lm_k_write_labels(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
                                                          const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
                                                          const int32_t* __restrict__ final_label, int32_t* __restrict__ labels,
-                                                         int W, int H, int WW, int cap, unsigned long long magic_q)
+                                                         int W, int H, int WW, int cap, unsigned long long magic_q, int contiguous)
 {
     // The kernel is instruction-bound before it is memory-bound (the first version spent ~870 instructions and 54
     // exec-mask branches per trip): 32-bit index math, one lookup for the common "all ink of the quad is one run" case.
@@ -413,7 +428,13 @@ __global__ void __launch_bounds__(256) lm_k_write_labels(const uint64_t* __restr
     const uint32_t* frowoff = rowoff + (long long)b * H;
     const int32_t* fin = final_label + (long long)b * cap;
     int32_t* lab_frame = labels + (long long)b * H * W;
-    for (unsigned base = wave * (64 * LM_WL_Q); base < total; base += nwaves * (64 * LM_WL_Q)) {
+    // contiguous != 0: every workgroup owns one contiguous span of the frame's quads (its waves interleave inside the span)
+    const unsigned wpb = blockDim.x >> 6, chunk = 64 * LM_WL_Q;
+    const unsigned span = contiguous ? ((total + gridDim.x - 1) / gridDim.x + wpb * chunk - 1) / (wpb * chunk) * (wpb * chunk) : 0u;
+    const unsigned first = contiguous ? blockIdx.x * span + (threadIdx.x >> 6) * chunk : wave * chunk;
+    const unsigned stop = contiguous ? ((blockIdx.x + 1) * span < total ? (blockIdx.x + 1) * span : total) : total;
+    const unsigned step = contiguous ? wpb * chunk : nwaves * chunk;
+    for (unsigned base = first; base < stop; base += step) {
         unsigned y[LM_WL_Q], x[LM_WL_Q], rw[LM_WL_Q], nib[LM_WL_Q];
 #pragma unroll
         for (int k = 0; k < LM_WL_Q; k++) {
