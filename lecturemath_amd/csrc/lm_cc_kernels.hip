@@ -253,7 +253,8 @@ __global__ void __launch_bounds__(512) lm_k_band(const uint8_t* __restrict__ img
     __syncthreads();
     // ---- 4. unions between vertically adjacent runs, all from LDS (per cell: every distinct (run, upper run) contact).
     // Measured alternatives that were slower on MI355X (profiles/r01_label_experiments.md): run-centric parent stores +
-    // barrier-separated pointer jumping + atomics only for merges (112 vs 76 us per 32 frames).
+    // barrier-separated pointer jumping + atomics only for merges (112 vs 76 us per 32 frames); path halving in the finds
+    // (52.6 vs 50.9 us: the chains are short, the extra LDS stores cost more than they save).
     for (int cell = threadIdx.x; cell < (nrows - 1) * WW; cell += blockDim.x) {
         const int r = 1 + (int)lm_fastdiv((unsigned)cell, magic_ww), w = cell - (r - 1) * WW;
         const unsigned long long cur = s_bits[r * WW + w];
