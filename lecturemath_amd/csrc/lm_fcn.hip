@@ -170,13 +170,16 @@ lm_f32x16 hipemu_mfma_32x32x16f16(lm_h8 a, lm_h8 b, lm_f32x16 c);
 // Staging is software-pipelined: the next group of weights and the next chunk's input patch are fetched into registers
 // while the MFMAs of the current group run (weights double-buffered in LDS, one LDS-only barrier per group -- a full
 // __syncthreads() would drain the prefetches).
-#define LM_CV_MAXP 8        // float4 patch items per thread (22 x 22 px x 4 / 256 for 7x7)
-#define LM_CV_MAXW 8        // 16-B weight items per thread and group: taps-per-group x NT <= 16
+#define LM_CV_MAXP 8        // float4 patch items per thread, worst case (22 x 22 px x 4 / 256 for 7x7)
+#define LM_CV_MAXW 8        // 16-B weight items per thread and group, worst case: taps-per-group x NT <= 16
+// The prefetch arrays are sized per instantiation (kernel side and NT are template parameters): with worst-case arrays every
+// variant needed ~200 VGPRs and the NT = 2 / transposed variants fell to one wave per SIMD.
 
-LM_DEV void lm_cv_load_patch(const LmConvArgs& a, int ch, int ty0, int tx0, int pad, int PW, int items, int ctot, float4 (&pr)[LM_CV_MAXP])
+template <int MAXP>
+LM_DEV void lm_cv_load_patch(const LmConvArgs& a, int ch, int ty0, int tx0, int pad, int PW, int items, int ctot, float4 (&pr)[MAXP])
 {
 #pragma unroll
-    for (int k = 0; k < LM_CV_MAXP; k++) {
+    for (int k = 0; k < MAXP; k++) {
         const int i = (int)threadIdx.x + k * 256;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < items) {
@@ -199,11 +202,12 @@ LM_DEV void lm_cv_load_patch(const LmConvArgs& a, int ch, int ty0, int tx0, int 
 // (5 slots per pixel, 5 coprime to 16).  Measured before the padding: 37-39 % of the LDS cycles were bank conflicts.
 LM_DEV int lm_cv_row_bytes(int PW) { return (PW * 80 + 255) & ~255; }
 
-LM_DEV void lm_cv_store_patch(char* s_patch, int PW, int items, const float4 (&pr)[LM_CV_MAXP])
+template <int MAXP>
+LM_DEV void lm_cv_store_patch(char* s_patch, int PW, int items, const float4 (&pr)[MAXP])
 {
     const int RB = lm_cv_row_bytes(PW);
 #pragma unroll
-    for (int k = 0; k < LM_CV_MAXP; k++) {
+    for (int k = 0; k < MAXP; k++) {
         const int i = (int)threadIdx.x + k * 256;
         if (i < items) {
             const int px = i >> 2, q = i & 3;
@@ -220,13 +224,13 @@ LM_DEV void lm_cv_store_patch(char* s_patch, int PW, int items, const float4 (&p
     }
 }
 
-template <int NT>
-LM_DEV void lm_cv_load_w(const LmConvArgs& a, int ch, int t0, int ntg, int taps, int nb0, uint4 (&wr)[LM_CV_MAXW])
+template <int NT, int MAXW>
+LM_DEV void lm_cv_load_w(const LmConvArgs& a, int ch, int t0, int ntg, int taps, int nb0, uint4 (&wr)[MAXW])
 {
     const uint4* wsrc = (const uint4*)a.wpk + (long long)ch * taps * a.nblocks * 128;
     const int n16 = ntg * NT * 128;
 #pragma unroll
-    for (int k = 0; k < LM_CV_MAXW; k++) {
+    for (int k = 0; k < MAXW; k++) {
         const int i = (int)threadIdx.x + k * 256;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (i < n16) {
@@ -238,21 +242,37 @@ LM_DEV void lm_cv_load_w(const LmConvArgs& a, int ch, int t0, int ntg, int taps,
     }
 }
 
-LM_DEV void lm_cv_store_w(char* s_w, int n16, const uint4 (&wr)[LM_CV_MAXW])
+template <int MAXW>
+LM_DEV void lm_cv_store_w(char* s_w, int n16, const uint4 (&wr)[MAXW])
 {
 #pragma unroll
-    for (int k = 0; k < LM_CV_MAXW; k++) {
+    for (int k = 0; k < MAXW; k++) {
         const int i = (int)threadIdx.x + k * 256;
         if (i < n16) *(uint4*)(s_w + (long long)i * 16) = wr[k];
     }
 }
 
-template <int NT>
-__global__ void __launch_bounds__(256) lm_k_conv_mfma_h(const LmConvArgs a)
+// taps per weight group.  Chosen so that the block's LDS (patch + two weight buffers of tg * NT * 2 KB) lets at least two
+// workgroups share a CU (three for 3x3 / NT = 1) without adding barriers: 3x3 -> 5 + 4 taps, 7x7 -> a kernel row (NT = 1) or
+// 4 taps (NT = 2); never more than LM_CV_MAXW 16-B items per thread.
+constexpr int lm_cv_tg(int K, int NT)
+{
+    const int cap = (LM_CV_MAXW * 2) / NT;
+    int want = K * K;
+    if (K == 3) want = (NT <= 2) ? 5 : 3;
+    else if (K >= 5) want = (NT == 1) ? K : (NT == 2 ? 4 : 2);
+    return want < cap ? want : cap;
+}
+
+// KS: kernel side known at compile time (1, 3, 7), or 0 = taken from the arguments (worst-case prefetch arrays)
+template <int NT, int KS, int TG = 0>     // TG: taps per weight group, 0 = lm_cv_tg(KS, NT)
+__global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1) lm_k_conv_mfma_h(const LmConvArgs a)      // two waves per SIMD whenever the accumulators allow
 {
     LM_DYN_SMEM(smem);
     constexpr int PB = 80;                  // bytes per pixel in LDS
-    const int K = a.K, pad = (K - 1) >> 1, taps = K * K;
+    constexpr int MAXP = KS ? ((16 + KS - 1) * (16 + KS - 1) * 4 + 255) / 256 : LM_CV_MAXP;
+    constexpr int MAXW = KS ? ((TG ? TG : lm_cv_tg(KS, NT)) * NT + 1) / 2 : LM_CV_MAXW;
+    const int K = KS ? KS : a.K, pad = (K - 1) >> 1, taps = K * K;
     const int PW = 16 + K - 1, PH = 16 + K - 1;
     const int patch_items = PH * PW * 4;
     char* s_patch = smem;
@@ -277,26 +297,26 @@ __global__ void __launch_bounds__(256) lm_k_conv_mfma_h(const LmConvArgs a)
     const int pi = lane & 31;
     const int prow = wave * 4 + (pi >> 4), pcol = pi & 15;
 
-    float4 pr[LM_CV_MAXP];
-    uint4 wr[LM_CV_MAXW];
-    lm_cv_load_patch(a, 0, ty0, tx0, pad, PW, patch_items, ctot, pr);
-    lm_cv_load_w<NT>(a, 0, 0, a.tg < taps ? a.tg : taps, taps, nb0, wr);
+    float4 pr[MAXP];
+    uint4 wr[MAXW];
+    lm_cv_load_patch<MAXP>(a, 0, ty0, tx0, pad, PW, patch_items, ctot, pr);
+    lm_cv_load_w<NT, MAXW>(a, 0, 0, a.tg < taps ? a.tg : taps, taps, nb0, wr);
     int buf = 0;
     for (int ch = 0; ch < nchunks; ch++) {
         lm_lds_barrier();                                       // everybody is done with the previous chunk's patch
-        lm_cv_store_patch(s_patch, PW, patch_items, pr);
-        if (ch + 1 < nchunks) lm_cv_load_patch(a, ch + 1, ty0, tx0, pad, PW, patch_items, ctot, pr);   // in flight for a whole chunk
+        lm_cv_store_patch<MAXP>(s_patch, PW, patch_items, pr);
+        if (ch + 1 < nchunks) lm_cv_load_patch<MAXP>(a, ch + 1, ty0, tx0, pad, PW, patch_items, ctot, pr);   // in flight for a whole chunk
         for (int g = 0; g < ngroups; g++) {
             const int t0 = g * a.tg;
             const int ntg = (taps - t0 < a.tg) ? taps - t0 : a.tg;
             char* s_w = s_wbuf + buf * wbuf_bytes;
-            lm_cv_store_w(s_w, ntg * NT * 128, wr);
+            lm_cv_store_w<MAXW>(s_w, ntg * NT * 128, wr);
             lm_lds_barrier();       // group g (and, for g == 0, the patch) visible; buffer `buf` was last read two groups ago
             if (g + 1 < ngroups) {
                 const int t1 = t0 + a.tg;
-                lm_cv_load_w<NT>(a, ch, t1, (taps - t1 < a.tg) ? taps - t1 : a.tg, taps, nb0, wr);
+                lm_cv_load_w<NT, MAXW>(a, ch, t1, (taps - t1 < a.tg) ? taps - t1 : a.tg, taps, nb0, wr);
             } else if (ch + 1 < nchunks) {
-                lm_cv_load_w<NT>(a, ch + 1, 0, a.tg < taps ? a.tg : taps, taps, nb0, wr);
+                lm_cv_load_w<NT, MAXW>(a, ch + 1, 0, a.tg < taps ? a.tg : taps, taps, nb0, wr);
             }
             for (int tt = 0; tt < ntg; tt++) {
                 const int t = t0 + tt;
@@ -355,7 +375,7 @@ __global__ void __launch_bounds__(256) lm_k_conv_mfma_h(const LmConvArgs a)
 // 2x2 stride-2 transposed convolution (fp16-split operands): the four (dy, dx) sub-convolutions are 1x1 GEMMs over the SAME
 // input pixels, so one workgroup stages a 16x16-px patch chunk once, reads its A fragments once and feeds four accumulator
 // sets (weights packed like a conv with 4 taps, tap = dy * 2 + dx).  One n-block (32 output channels) per workgroup.
-__global__ void __launch_bounds__(256) lm_k_convT_mfma_h(const LmConvArgs a)
+__global__ void __launch_bounds__(256, 2) lm_k_convT_mfma_h(const LmConvArgs a)
 {
     LM_DYN_SMEM(smem);
     constexpr int PW = 16, TAPS = 4;
@@ -377,20 +397,20 @@ __global__ void __launch_bounds__(256) lm_k_convT_mfma_h(const LmConvArgs a)
             for (int r = 0; r < 16; r++) acc[t][m][r] = 0.0f;
     const int pi = lane & 31;
     const int prow = wave * 4 + (pi >> 4), pcol = pi & 15;
-    float4 pr[LM_CV_MAXP];
-    uint4 wr[LM_CV_MAXW];
-    lm_cv_load_patch(a, 0, ty0, tx0, 0, PW, PW * PW * 4, ctot, pr);
-    lm_cv_load_w<1>(a, 0, 0, TAPS, TAPS, nb0, wr);
+    float4 pr[4];           // 16 x 16 px x 4 items / 256 threads
+    uint4 wr[2];            // 4 taps x 128 items / 256 threads
+    lm_cv_load_patch<4>(a, 0, ty0, tx0, 0, PW, PW * PW * 4, ctot, pr);
+    lm_cv_load_w<1, 2>(a, 0, 0, TAPS, TAPS, nb0, wr);
     int buf = 0;
     for (int ch = 0; ch < nchunks; ch++) {
         char* s_w = s_wbuf + buf * (TAPS * 2048);
         lm_lds_barrier();                                       // the previous chunk's patch has been read by everybody
-        lm_cv_store_patch(s_patch, PW, PW * PW * 4, pr);
-        lm_cv_store_w(s_w, TAPS * 128, wr);
+        lm_cv_store_patch<4>(s_patch, PW, PW * PW * 4, pr);
+        lm_cv_store_w<2>(s_w, TAPS * 128, wr);
         lm_lds_barrier();
         if (ch + 1 < nchunks) {
-            lm_cv_load_patch(a, ch + 1, ty0, tx0, 0, PW, PW * PW * 4, ctot, pr);
-            lm_cv_load_w<1>(a, ch + 1, 0, TAPS, TAPS, nb0, wr);
+            lm_cv_load_patch<4>(a, ch + 1, ty0, tx0, 0, PW, PW * PW * 4, ctot, pr);
+            lm_cv_load_w<1, 2>(a, ch + 1, 0, TAPS, TAPS, nb0, wr);
         }
         lm_h8 ah[2], al[2];
 #pragma unroll
@@ -703,11 +723,7 @@ template <int CK, int NT> static int lm_launch_conv_t(const LmConvArgs& a, hipSt
 static int lm_conv_tg(int K) { return (K >= 5) ? K : K * K; }     // weights staged per kernel row for 5x5 / 7x7
 
 // taps per weight group of the fp16-split kernel: a kernel row at most, and at most LM_CV_MAXW 16-B items per thread
-static int lm_conv_tg_h(int K, int NT)
-{
-    const int want = lm_conv_tg(K), cap = (LM_CV_MAXW * 2) / NT;
-    return want < cap ? want : cap;
-}
+static int lm_conv_tg_h(int K, int NT) { return lm_cv_tg(K, NT); }
 
 static size_t lm_conv_smem_h(int K, int NT)
 {
@@ -715,33 +731,49 @@ static size_t lm_conv_smem_h(int K, int NT)
     return (size_t)P * (((size_t)P * 80 + 255) & ~(size_t)255) + 2 * (size_t)lm_conv_tg_h(K, NT) * NT * 2048;   // rows padded to 256 B, weights double-buffered
 }
 
-template <int NT> static int lm_launch_conv_h(const LmConvArgs& a, hipStream_t st)
+template <int NT, int KS, int TG = 0> static int lm_launch_conv_hk(const LmConvArgs& a, hipStream_t st)
 {
-    const size_t smem = lm_conv_smem_h(a.K, NT);
+    const int tg = TG ? TG : lm_conv_tg_h(a.K, NT);
+    const int P = 16 + a.K - 1;
+    const size_t smem = (size_t)P * (((size_t)P * 80 + 255) & ~(size_t)255) + 2 * (size_t)tg * NT * 2048;   // rows padded to 256 B, weights double-buffered
 #if !LM_HIP_EMULATED
     static size_t configured = 0;
     if (smem > configured) {
-        LM_HIP(hipFuncSetAttribute((const void*)lm_k_conv_mfma_h<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        LM_HIP(hipFuncSetAttribute((const void*)lm_k_conv_mfma_h<NT, KS, TG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         configured = smem;
     }
 #endif
     const int tiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
     LmConvArgs b = a;
-    b.tg = lm_conv_tg_h(a.K, NT);
-    hipLaunchKernelGGL((lm_k_conv_mfma_h<NT>), dim3(tiles, (a.nblocks + NT - 1) / NT), dim3(256), smem, st, b);
+    b.tg = tg;
+    hipLaunchKernelGGL((lm_k_conv_mfma_h<NT, KS, TG>), dim3(tiles, (a.nblocks + NT - 1) / NT), dim3(256), smem, st, b);
     LM_HIP(hipGetLastError());
     return LM_OK;
+}
+
+template <int NT> static int lm_launch_conv_h(const LmConvArgs& a, hipStream_t st)
+{
+    if (a.K > 7) { lm_set_error("lm_fcn: kernel side %d not supported by the fp16-split convolution (<= 7)", a.K); return LM_ERR_ARG; }
+    const int blocks = ((a.W + 15) / 16) * ((a.H + 15) / 16) * ((a.nblocks + NT - 1) / NT);
+    switch (a.K) {
+        case 1: return lm_launch_conv_hk<NT, 1>(a, st);
+        case 3:
+            // few workgroups (deep layers): LDS is not what limits residency, so stage all nine taps at once (one barrier less
+            // per chunk); many workgroups: 5 + 4 taps, three workgroups per CU
+            if (NT == 1 && blocks < 1000) return lm_launch_conv_hk<NT, 3, (NT == 1) ? 9 : 0>(a, st);
+            return lm_launch_conv_hk<NT, 3>(a, st);
+        case 7: return lm_launch_conv_hk<NT, 7>(a, st);
+        default: return lm_launch_conv_hk<NT, 0>(a, st);
+    }
 }
 
 static int lm_launch_conv(const LmConvArgs& a, int ck, hipStream_t st)
 {
     if (ck == 0) {          // fp16-split packing
+        // two n-blocks per wave when the channel blocks divide evenly and the grid still has >= 1.5 workgroups per CU (four
+        // would need 128 accumulator registers: one wave per SIMD, measured slower)
         const int tiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
-        int nt = 1;
-        for (int cand : {4, 2})
-            if (a.nblocks % cand == 0 && lm_conv_smem_h(a.K, cand) <= 150 * 1024 && tiles * (a.nblocks / cand) >= 512) { nt = cand; break; }
-        if (nt == 4) return lm_launch_conv_h<4>(a, st);
-        if (nt == 2) return lm_launch_conv_h<2>(a, st);
+        if (a.nblocks % 2 == 0 && tiles * (a.nblocks / 2) >= 384) return lm_launch_conv_h<2>(a, st);
         return lm_launch_conv_h<1>(a, st);
     }
     // n-blocks per wave: as many as fit 160 KiB of LDS and divide the channel blocks evenly -- but the deep layers have few
