@@ -558,7 +558,7 @@ static int lm_stream_push_impl(LmStream* s, const uint8_t* d_binary, int n_frame
                            s->min_pixels);
         hipLaunchKernelGGL(lm_k_batch_offsets, dim3(1), dim3(1024), 0, st, c->frame_kept, c->frame_cropwords, B, s->counters,
                            s->frame_cc_off, s->batch_cc_base, s->batch_word_base, s->cap_cc, s->cap_words, s->cap_frames);
-        hipLaunchKernelGGL(lm_k_emit, dim3(64, B), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff, c->final_label,
+        hipLaunchKernelGGL(lm_k_emit, dim3(LM_HIP_EMULATED ? 2 : 320, B), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff, c->final_label,
                            c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x, c->st_count, c->kept_label, c->kept_cropoff,
                            c->frame_kept, s->batch_cc_base, s->batch_word_base, s->cc, s->crop, s->frames_pushed, g.WW, g.H,
                            g.cap);
