@@ -142,11 +142,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
+    # LM_BENCH_REHEARSE=1: all ranks on cuda:0 with the gloo backend -- exercises the multi-process path on a one-GPU box
+    rehearse = bool(os.environ.get("LM_BENCH_REHEARSE"))
+    if rehearse:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)               # before the process group: RCCL binds to the current device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
-    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
-    torch.cuda.set_device(local_rank)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from lecturemath_amd import _lib, device, synth
     lib = _lib.load()
     assert lib.is_device_build
@@ -256,7 +263,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if rehearse else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
