@@ -572,6 +572,96 @@ __global__ void __launch_bounds__(256) lm_k_conv_small(const float* __restrict__
     }
 }
 
+// Cout == 1 heads (text mask 7x7, output logit 7x7), direct convolution on the VALU with a sliding window in registers:
+// 16 x 64 px tile, every thread computes FOUR adjacent pixels of a row, so one kernel row costs 10 patch reads + 7 weight
+// reads (16 B each) per 4 channels for 112 FMAs (the two-pixel version needed 2.4x the LDS traffic and was LDS-bound).
+// LDS layout per patch row: pixel x sits at position (x % 4) * Q + x / 4 (Q = ceil(PW / 4)), 12 floats per position, so for a
+// fixed window offset the 16 lanes of a row read consecutive positions (3 slots apart: conflict-free); row stride is a
+// multiple of 256 B because ds_read_b128 lane groups straddle two rows.  Weights [chunk of 8 channels][tap][8].
+#define LM_C1_TW 64
+
+LM_DEV int lm_c1_q(int K) { return (LM_C1_TW + K - 1 + 3) >> 2; }
+LM_DEV int lm_c1_row_floats(int K) { return (4 * lm_c1_q(K) * 12 + 63) & ~63; }
+
+__global__ void __launch_bounds__(256) lm_k_conv_c1(const float* __restrict__ in, int ips, int C, int H, int W,
+                                                    const float* __restrict__ wts, const float* __restrict__ bias, int K, int act,
+                                                    float* __restrict__ out, int ops)
+{
+    LM_DYN_SMEM(smem);
+    const int pad = (K - 1) >> 1, taps = K * K, PW = LM_C1_TW + K - 1, PH = 16 + K - 1;
+    const int Q = lm_c1_q(K), RF = lm_c1_row_floats(K);
+    float* s_patch = (float*)smem;                          // [PH][RF]
+    float* s_w = s_patch + PH * RF;                         // [tap][8]
+    const int tiles_x = (W + LM_C1_TW - 1) / LM_C1_TW;
+    const int ty0 = (blockIdx.x / tiles_x) << 4, tx0 = (blockIdx.x % tiles_x) * LM_C1_TW;
+    const int ly = (int)(threadIdx.x >> 4), lx = (int)(threadIdx.x & 15);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // the next chunk's patch is fetched into registers while the current chunk is being convolved
+    constexpr int MAXI = 13;                                // ceil(22 * 70 * 2 / 256) patch items per thread (7x7)
+    const int items = PH * PW * 2;
+    float4 pr[MAXI];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < MAXI; k++) {
+            const int i = (int)threadIdx.x + k * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < items) {
+                const int px = i >> 1, q = i & 1;
+                const int py = px / PW, pxx = px - py * PW;
+                const int y = ty0 + py - pad, x = tx0 + pxx - pad;
+                if (y >= 0 && y < H && x >= 0 && x < W) v = *(const float4*)(in + ((long long)y * W + x) * ips + c0 + q * 4);
+            }
+            pr[k] = v;
+        }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < C; c0 += 8) {
+        lm_lds_barrier();                                   // the previous chunk has been read by everybody
+#pragma unroll
+        for (int k = 0; k < MAXI; k++) {
+            const int i = (int)threadIdx.x + k * 256;
+            if (i < items) {
+                const int px = i >> 1, q = i & 1;
+                const int py = px / PW, pxx = px - py * PW;
+                *(float4*)(s_patch + py * RF + ((pxx & 3) * Q + (pxx >> 2)) * 12 + q * 4) = pr[k];
+            }
+        }
+        const float* wsrc = wts + (long long)(c0 >> 3) * taps * 8;
+        for (int i = threadIdx.x; i < taps * 2; i += blockDim.x) *(float4*)(s_w + i * 4) = *(const float4*)(wsrc + (long long)i * 4);
+        lm_lds_barrier();
+        if (c0 + 8 < C) fetch(c0 + 8);
+        for (int kh = 0; kh < K; kh++) {
+            const float* prow = s_patch + (ly + kh) * RF;
+#pragma unroll
+            for (int hq = 0; hq < 2; hq++) {                // channels 0-3, 4-7 of the chunk
+                float4 win[10];                             // window pixels 4*lx .. 4*lx + K + 2 (K <= 7)
+#pragma unroll
+                for (int s2 = 0; s2 < 10; s2++)
+                    win[s2] = (s2 < K + 3) ? *(const float4*)(prow + ((s2 & 3) * Q + lx + (s2 >> 2)) * 12 + hq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int kw = 0; kw < 7; kw++) {
+                    if (kw >= K) break;
+                    const float4 wv = *(const float4*)(s_w + (kh * K + kw) * 8 + hq * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float4 u = win[j + kw];
+                        acc[j] = fmaf(u.x, wv.x, acc[j]); acc[j] = fmaf(u.y, wv.y, acc[j]);
+                        acc[j] = fmaf(u.z, wv.z, acc[j]); acc[j] = fmaf(u.w, wv.w, acc[j]);
+                    }
+                }
+            }
+        }
+    }
+    const int y = ty0 + ly;
+    if (y >= H) return;
+    const float bb = bias[0];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int x = tx0 + 4 * lx + j;
+        if (x < W) out[((long long)y * W + x) * ops] = lm_act(acc[j] + bb, act);
+    }
+}
+
 // diff = (x0 - rec) * sigmoid(text)  (:379), written to channels 0..2 of three NHWC buffers
 __global__ void __launch_bounds__(256) lm_k_diff(const float* __restrict__ x0, const float* __restrict__ rec4,
                                                  const float* __restrict__ text, long long npx, float* __restrict__ o0, int s0,
@@ -862,6 +952,21 @@ static int lm_small_layer(LmFcn* f, int layer, const float* in, int ips, int C, 
 {
     const LmFcnLayer& l = f->layer[layer];
     if (!l.w) { lm_set_error("lm_fcn_forward: layer %d has no weights", layer); return LM_ERR_STATE; }
+    if (l.cout == 1 && l.k <= 7) {
+        const int PH = 16 + l.k - 1, Q = (LM_C1_TW + l.k - 1 + 3) >> 2, RF = (4 * Q * 12 + 63) & ~63;
+        const size_t smem = ((size_t)PH * RF + (size_t)l.k * l.k * 8) * sizeof(float);
+#if !LM_HIP_EMULATED
+        static size_t configured = 0;
+        if (smem > configured) {
+            LM_HIP(hipFuncSetAttribute((const void*)lm_k_conv_c1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            configured = smem;
+        }
+#endif
+        const int tiles = ((W + LM_C1_TW - 1) / LM_C1_TW) * ((H + 15) / 16);
+        hipLaunchKernelGGL(lm_k_conv_c1, dim3(tiles), dim3(256), smem, st, in, ips, C, H, W, l.w, l.bias, l.k, act, out, ops);
+        LM_HIP(hipGetLastError());
+        return LM_OK;
+    }
     return (l.cout == 1) ? lm_small_launch<1>(l, in, ips, C, H, W, out, ops, act, st) : lm_small_launch<4>(l, in, ips, C, H, W, out, ops, act, st);
 }
 
