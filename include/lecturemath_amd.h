@@ -155,6 +155,11 @@ void lm_group_destroy(LmGroups* g);
 /* frames_from_groups (:638-681, the encoded channel 0): frames [first, first + n) -> d_out [n][height][width] uint8 */
 int lm_group_render(LmGroups* g, int first, int n, uint8_t* d_out, void* stream);
 
+/* Step 04 helper: exact per-frame sums of n_frames uint8 frames resident on the device (d_sums[f] = sum of the frame's
+ * bytes).  Replaces the integer part of VideoSegmenter.compute_binary_sums (AccessMath/preprocessing/content/
+ * video_segmenter.py:22-28, `binary.sum() / 255`); the float64 division by 255 stays with the caller. */
+int lm_frame_sums(const uint8_t* d_frames, int n_frames, int64_t pixels_per_frame, uint64_t* d_sums, void* stream);
+
 /* Host arrays owned by g (valid until lm_group_destroy): *ptr, *count (elements).  Array ids and element types:
  *  0 UNIQ_CC i32[n_uniq]  first-seen CC record of every unique (after the split)
  *  1 ULIST_OFF i64[n_uniq+1], 2 ULIST_CC i32   CSR of unique_cc_frames (entries are global CC indices)

@@ -332,6 +332,41 @@ __global__ void __launch_bounds__(256) lm_k_render_frames(const long long* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// G5: per-frame pixel sums of uint8 frames (step 04, VideoSegmenter.compute_binary_sums,
+// AccessMath/preprocessing/content/video_segmenter.py:22-28: `binary.sum() / 255`; the division stays on the host in
+// float64).  Exact integer sums: 16-B loads, v_sad_u8 adds four bytes per instruction, one 64-bit atomic per workgroup.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) lm_k_frame_sums(const uint8_t* __restrict__ frames, long long px, unsigned long long* __restrict__ sums)
+{
+    const uint8_t* f = frames + (long long)blockIdx.y * px;
+    const bool vec = ((((uintptr_t)f) & 15) == 0);
+    unsigned long long acc = 0;
+    const long long n16 = vec ? (px >> 4) : 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) {
+        const uint4 v = *(const uint4*)(f + (i << 4));
+        unsigned s4 = 0;
+#if LM_HIP_EMULATED
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        for (int k = 0; k < 4; k++) s4 += (w[k] & 0xffu) + ((w[k] >> 8) & 0xffu) + ((w[k] >> 16) & 0xffu) + (w[k] >> 24);
+#else
+        s4 = __builtin_amdgcn_sad_u8(v.x, 0u, s4); s4 = __builtin_amdgcn_sad_u8(v.y, 0u, s4);
+        s4 = __builtin_amdgcn_sad_u8(v.z, 0u, s4); s4 = __builtin_amdgcn_sad_u8(v.w, 0u, s4);
+#endif
+        acc += s4;
+    }
+    for (long long i = (n16 << 4) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < px; i += (long long)gridDim.x * blockDim.x) acc += f[i];
+    __shared__ unsigned long long s_acc;
+    if (threadIdx.x == 0) s_acc = 0;
+    __syncthreads();
+    // wave reduction of the 64-bit partial sums (two 32-bit halves through the 32-bit wave sum)
+    const unsigned lo = lm_wave_sum((unsigned)(acc & 0xffffffu)), mid = lm_wave_sum((unsigned)((acc >> 24) & 0xffffffu));
+    const unsigned hi = lm_wave_sum((unsigned)(acc >> 48));
+    if (lm_lane() == 0) atomicAdd(&s_acc, (unsigned long long)lo + ((unsigned long long)mid << 24) + ((unsigned long long)hi << 48));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_acc) atomicAdd(&sums[blockIdx.y], s_acc);
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -901,6 +936,20 @@ extern "C" int lm_group_render(LmGroups* g, int first, int n, uint8_t* d_out, vo
 
 // Generic accessor: pointer to a host array owned by `g` (valid until lm_group_destroy) and its element count.
 // Element types: see the LM_G_* table in include/lecturemath_amd.h.
+extern "C" int lm_frame_sums(const uint8_t* d_frames, int n_frames, int64_t pixels_per_frame, uint64_t* d_sums, void* stream)
+{
+    if (!d_frames || !d_sums || n_frames <= 0 || pixels_per_frame <= 0) { lm_set_error("lm_frame_sums: bad arguments"); return LM_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    LM_HIP(hipMemsetAsync(d_sums, 0, (size_t)n_frames * sizeof(uint64_t), st));
+    long long bx = (pixels_per_frame / 16 + 255) / 256;
+    if (bx > 64) bx = 64;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(lm_k_frame_sums, dim3((unsigned)(LM_HIP_EMULATED ? 2 : bx), n_frames), dim3(256), 0, st, d_frames, (long long)pixels_per_frame,
+                       (unsigned long long*)d_sums);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
 extern "C" int lm_group_array(LmGroups* g, int which, const void** ptr, int64_t* count)
 {
     if (!g || !ptr || !count) { lm_set_error("lm_group_array: bad arguments"); return LM_ERR_ARG; }

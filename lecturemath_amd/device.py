@@ -102,6 +102,16 @@ class FrameLabeler:
         return out
 
 
+def frame_sums(frames, lib=None):
+    """Exact per-frame sums of a device uint8 tensor [n, H, W] (step 04, VideoSegmenter.compute_binary_sums): int64 numpy."""
+    lib = lib or _lib.load()
+    be = Backend(lib)
+    n = int(frames.shape[0])
+    out = be.empty((n,), np.int64)
+    lib.check(lib.lm_frame_sums(_lib.ptr(frames), n, int(frames.shape[1]) * int(frames.shape[2]), _lib.ptr(out), be.stream()))
+    return be.to_host(out)
+
+
 def decode_crop(words, min_x, max_x, min_y, max_y):
     """bit-row crop (absolute 32-px column alignment) -> uint8 0/255 (h, w) like ConnectedComponent.img."""
     wx0 = min_x >> 5

@@ -1,0 +1,76 @@
+"""Step 04 entry point (same name, argv, config keys, inputs and output as the reference's
+pre_ST3D_v3.0_04_vid_segmentation.py) for the shipped VIDEO_SEGMENTATION_METHOD = 3 (deletion events, :44-99):
+[(frame_times, frame_indices, compressed_frames), (group_ages, conflicts), SpaceTimeStruct] -> list of (first, last) frame
+intervals.  The reference's debug plots (matplotlib, :100-112, :175-218) and the decompression + sums that only feed them
+(:28-41) are not produced; pass the parameter `sums=1` to get the binary sums printed."""
+import sys
+import time
+
+import numpy as np
+
+
+def process_input(process, input_data):
+    from AccessMath.data.space_time_struct import SpaceTimeStruct
+    from AccessMath.preprocessing.content.video_segmenter import VideoSegmenter
+    segmentation_method = process.configuration.get_int("VIDEO_SEGMENTATION_METHOD", 3)
+    if segmentation_method != 3:
+        raise NotImplementedError("only VIDEO_SEGMENTATION_METHOD = 3 (deletion events, the shipped configuration) is built")
+    frame_times, frame_indices, compressed_frames = input_data[0]
+    if "sums" in process.params:
+        from AccessMath.preprocessing.content.helper import Helper
+        print("Computing sums...")
+        print(VideoSegmenter.compute_binary_sums(Helper.decompress_binary_images(compressed_frames)))
+    group_ages, conflicts = input_data[1]
+    st3D = input_data[2]
+    assert isinstance(st3D, SpaceTimeStruct)
+    add_threshold = process.configuration.get_float("VIDEO_SEGMENTATION_DEL_EVENT_ADD_THRESHOLD", 10)
+    min_segment_length = process.configuration.get_int("VIDEO_SEGMENTATION_DEL_EVENT_MIN_LENGTH", 15)
+    threshold = process.configuration.get_float("VIDEO_SEGMENTATION_DEL_EVENT_THRESHOLD", 0.25)
+    n = len(st3D.frame_indices)
+    add_values = np.zeros(n)
+    del_values = np.zeros(n)
+    for group_idx in group_ages:
+        first, last = group_ages[group_idx][0], group_ages[group_idx][-1]
+        g_min_x, g_max_x, g_min_y, g_max_y = st3D.cc_group_boundaries[group_idx]
+        area = (g_max_x - g_min_x + 1) * (g_max_y - g_min_y + 1)
+        area /= (st3D.width * st3D.height)          # normalised by the frame size (float64)
+        add_values[first] += area
+        del_values[last] += area
+    accumulated_delete = 0.0
+    cumulative_delete = np.zeros(n)
+    for idx in range(n):
+        if add_values[idx] > add_threshold:
+            accumulated_delete = 0.0
+        accumulated_delete += del_values[idx]
+        cumulative_delete[idx] = accumulated_delete
+    intervals = VideoSegmenter.split_video_from_group_deletes(cumulative_delete, 0, n - 1, min_segment_length, threshold)
+    print(intervals)
+    print([(st3D.frame_indices[start_f], st3D.frame_indices[end_f]) for start_f, end_f in intervals])
+    print("Total intervals: " + str(len(intervals)))
+    return intervals
+
+
+def main():
+    from AccessMath.preprocessing.user_interface.console_ui_process import ConsoleUIProcess
+    if not ConsoleUIProcess.usage_with_config_check(sys.argv):
+        return
+    process = ConsoleUIProcess.FromConfigPath(sys.argv[1], sys.argv[2:], None, "VIDEO_SEGMENTATION_OUTPUT")
+    segmentation_method = process.configuration.get_int("VIDEO_SEGMENTATION_METHOD", 2)
+    if segmentation_method == 3:
+        inputs = [process.configuration.get("CC_RECONSTRUCTED_OUTPUT"), process.configuration.get("CC_CONFLICTS_OUTPUT"),
+                  process.configuration.get("CC_ST3D_OUTPUT")]
+    elif segmentation_method == 2:
+        inputs = [process.configuration.get("CC_RECONSTRUCTED_OUTPUT"), process.configuration.get("CC_CONFLICTS_OUTPUT")]
+    else:
+        inputs = process.configuration.get("CC_RECONSTRUCTED_OUTPUT")
+    process.input_temp_prefix = inputs
+    if not process.initialize():
+        return
+    start = time.time()
+    process.start_input_processing(process_input)
+    print("Total time: %.1f s" % (time.time() - start))
+    print("Finished")
+
+
+if __name__ == "__main__":
+    main()

@@ -77,7 +77,44 @@ def check_steps_02_03(lib, name):
     assert (np.packbits(clean == 255, axis=2) == g["clean_packed"]).all()
     assert (clean[(clean != 0) & (clean != 255)] == g["clean_other_val"]).all()
     assert st3d.width == spec["w"] and st3d.height == spec["h"] and rec[0] == times
+    check_step_04(name, [rec, conf, st3d], clean)
     return blob
+
+
+def g7(name):
+    import json
+    g = np.load(os.path.join(lm_checks.GOLD, "g7_step04_%s.npz" % name))
+    return g, json.loads(bytes(g["params"]).decode())
+
+
+def check_step_04(name, step03_outputs, clean=None):
+    """pre_ST3D 04 (deletion-event segmentation) on step-03 outputs vs the reference's intervals (G7), three parameter sets;
+    binary sums of the reconstructed frames vs VideoSegmenter.compute_binary_sums of the reference."""
+    if DROPIN not in sys.path:
+        sys.path.insert(0, DROPIN)
+    from AccessMath.preprocessing.content.video_segmenter import VideoSegmenter
+    g, param_sets = g7(name)
+    s04 = load_script("pre_ST3D_v3.0_04_vid_segmentation.py")
+    for k, values in enumerate(param_sets):
+        proc = fake_process(dict({key: str(v) for key, v in values.items()}, VIDEO_SEGMENTATION_METHOD="3"))
+        intervals = s04.process_input(proc, step03_outputs)
+        assert [tuple(int(v) for v in iv) for iv in intervals] == [tuple(int(v) for v in iv) for iv in g["intervals_%d" % k]]
+    if clean is not None:
+        sums = VideoSegmenter.compute_binary_sums(list(clean))
+        assert [float(v) for v in sums] == [float(v) for v in g["sums"]]
+
+
+def check_step_04_from_golden(name):
+    """Host-only: the step-04 drop-in fed with the reference's own step-03 outputs (ages, boundaries) from the G7 fixture."""
+    if DROPIN not in sys.path:
+        sys.path.insert(0, DROPIN)
+    from AccessMath.data.space_time_struct import SpaceTimeStruct
+    g, _ = g7(name)
+    n = int(g["n_frames"])
+    ages = {k: [int(v) for v in g["ages"][g["ages_off"][k]:g["ages_off"][k + 1]]] for k in range(len(g["ages_off"]) - 1)}
+    bounds = {k: tuple(int(v) for v in g["bounds"][k]) for k in range(len(g["bounds"]))}
+    st3d = SpaceTimeStruct([float(i) for i in range(n)], list(range(n)), int(g["h"]), int(g["w"]), ages, {}, bounds)
+    check_step_04(name, [([float(i) for i in range(n)], list(range(n)), []), (ages, {}), st3d])
 
 
 def check_labeler(lib):

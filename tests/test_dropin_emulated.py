@@ -86,3 +86,17 @@ pickle.dump((t, i, e2), open("%s", "wb"), protocol=pickle.HIGHEST_PROTOCOL)
     assert [[(a,) for a in conf[0][k]] for k in range(ng)] == lm_checks.unrag(g["ages"], g["ages_off"])
     gi = np.concatenate([im.ravel() for k in range(ng) for im in st3d.cc_group_images[k]])
     assert (gi == g["gimg"]).all()
+
+
+@pytest.mark.parametrize("name", lm_checks.STREAMS)
+def test_step_04_on_reference_step03_outputs(name):
+    """Step 04 drop-in (host list logic) on the reference's own step-03 outputs: intervals of three parameter sets."""
+    dropin_checks.check_step_04_from_golden(name)
+
+
+def test_frame_sums_kernel(emu_lib):
+    from lecturemath_amd import device
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, (3, 37, 53), dtype=np.uint8)
+    frames[1] = 255
+    assert list(device.frame_sums(frames, emu_lib)) == [int(f.astype(np.int64).sum()) for f in frames]

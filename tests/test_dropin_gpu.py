@@ -23,3 +23,20 @@ def test_fcn_class_and_worker(hip_lib, name):
 
 def test_fcn_4k_resize_branch(hip_lib):
     dropin_checks.check_fcn_4k_resize_branch(hip_lib)
+
+
+def test_frame_sums_device(hip_lib):
+    """lm_frame_sums (step 04, compute_binary_sums) on 1080p frames incl. an unaligned view: exact integer sums."""
+    import torch
+    from lecturemath_amd import device
+    dropin_checks.use_library(hip_lib)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    frames = torch.randint(0, 256, (5, 1080, 1920), dtype=torch.uint8, device="cuda", generator=g)
+    frames[2] = 255
+    want = [int(v) for v in frames.to(torch.int64).sum(dim=(1, 2)).cpu()]
+    assert list(device.frame_sums(frames, hip_lib)) == want
+    odd = frames[:, :333, :1919].contiguous()       # frame bases and sizes that are not multiples of 16
+    assert list(device.frame_sums(odd, hip_lib)) == [int(v) for v in odd.to(torch.int64).sum(dim=(1, 2)).cpu()]
+    from AccessMath.preprocessing.content.video_segmenter import VideoSegmenter
+    assert VideoSegmenter.compute_binary_sums(frames) == [v / 255 for v in want]

@@ -90,3 +90,23 @@ def test_g6_threshold(oracle_built):
     assert diff <= 2, diff
     far = np.abs(g["logits"] - 0.01569) > 1e-4
     assert (out[far] == g["expected"][far]).all()
+
+
+@pytest.mark.parametrize("name", lm_checks.STREAMS)
+def test_g7_step04(name):
+    """oracle/segmentation.py (step 04, deletion events) vs the reference's intervals and binary sums (G7)."""
+    import json
+    from oracle import segmentation as seg
+    g = np.load(os.path.join(GOLD, "g7_step04_%s.npz" % name))
+    ages = {k: [int(v) for v in g["ages"][g["ages_off"][k]:g["ages_off"][k + 1]]] for k in range(len(g["ages_off"]) - 1)}
+    bounds = {k: tuple(int(v) for v in g["bounds"][k]) for k in range(len(g["bounds"]))}
+    for i, ps in enumerate(json.loads(bytes(g["params"]).decode())):
+        iv = seg.run_step04(int(g["n_frames"]), int(g["w"]), int(g["h"]), ages, bounds, ps["VIDEO_SEGMENTATION_DEL_EVENT_ADD_THRESHOLD"],
+                            ps["VIDEO_SEGMENTATION_DEL_EVENT_MIN_LENGTH"], ps["VIDEO_SEGMENTATION_DEL_EVENT_THRESHOLD"])
+        assert [tuple(int(v) for v in x) for x in iv] == [tuple(int(v) for v in x) for x in g["intervals_%d" % i]]
+    # binary sums: the G4 fixture holds the reference's reconstructed frames
+    g4, spec, _ = lm_checks.load_stream(name)
+    clean = np.unpackbits(g4["clean_packed"], axis=2)[:, :, :spec["w"]].astype(np.uint8) * 255
+    for (f, y, x), v in zip(g4["clean_other"], g4["clean_other_val"]):
+        clean[f, y, x] = v
+    assert [float(v) for v in seg.binary_sums(list(clean))] == [float(v) for v in g["sums"]]
