@@ -340,20 +340,30 @@ __global__ void __launch_bounds__(256) lm_k_flatten_flag(int32_t* __restrict__ p
     for (int base = 0; base < n; base += 256 * 64) {          // 256 words of 64 runs per pass, words dealt round-robin to the waves
         s_pc[threadIdx.x] = 0;
         __syncthreads();
-        for (int k = 0; k < 64; k++) {
-            const int word = k * 4 + wave;                     // word index inside this pass
-            const int i0 = base + word * 64;
-            if (i0 >= n) break;                                // wave-uniform
-            const int i = i0 + lane;
-            bool flag = false;
-            if (i < n) {
-                const int gid = band * slot + i;
-                const int r = lm_find(par, gid);
-                par[gid] = r;
-                flag = (r == gid);
+        for (int k = 0; k < 64; k += 4) {                      // four words per trip: their first parent loads fly together
+            if (base + (k * 4 + wave) * 64 >= n) break;        // wave-uniform
+            int gid[4], p[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = base + ((k + u) * 4 + wave) * 64 + lane;
+                gid[u] = (i < n) ? band * slot + i : -1;
+                p[u] = (gid[u] >= 0) ? par[gid[u]] : -1;
             }
-            const unsigned long long m = __ballot(flag);
-            if (lane == 0) { rb[i0 >> 6] = m; s_pc[word] = (unsigned)__popcll(m); }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int word = (k + u) * 4 + wave;           // word index inside this pass
+                const int i0 = base + word * 64;
+                if (i0 >= n) break;                            // wave-uniform
+                bool flag = false;
+                if (gid[u] >= 0) {
+                    int x = gid[u], q = p[u];
+                    while (q != x) { x = q; q = par[x]; }      // lm_find, continued from the prefetched parent
+                    par[gid[u]] = x;
+                    flag = (x == gid[u]);
+                }
+                const unsigned long long m = __ballot(flag);
+                if (lane == 0) { rb[i0 >> 6] = m; s_pc[word] = (unsigned)__popcll(m); }
+            }
         }
         __syncthreads();
         unsigned tot;
@@ -395,10 +405,23 @@ __global__ void __launch_bounds__(256) lm_k_apply_labels(const int32_t* __restri
     const unsigned long long* rb = rootbits + (long long)b * capw;
     const uint32_t* wp = wordprefix + (long long)b * capw;
     int32_t* fin = final_label + (long long)b * cap;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int gid = band * slot + i;
-        const int r = par[gid];
-        fin[gid] = (int32_t)(s_base[r / slot] + wp[r >> 6] + (unsigned)__popcll(rb[r >> 6] & lm_lowmask_excl(r & 63)) + 1u);
+    for (int i0 = threadIdx.x; i0 < n; i0 += blockDim.x * 4) {       // four runs per trip: independent lookup chains in flight
+        int r[4];
+        unsigned w[4];
+        unsigned long long bm[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * (int)blockDim.x;
+            r[u] = (i < n) ? par[band * slot + i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { w[u] = wp[r[u] >> 6]; bm[u] = rb[r[u] >> 6]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * (int)blockDim.x;
+            if (i < n)
+                fin[band * slot + i] = (int32_t)(s_base[r[u] / slot] + w[u] + (unsigned)__popcll(bm[u] & lm_lowmask_excl(r[u] & 63)) + 1u);
+        }
     }
 }
 
