@@ -160,6 +160,16 @@ int lm_group_render(LmGroups* g, int first, int n, uint8_t* d_out, void* stream)
  * video_segmenter.py:22-28, `binary.sum() / 255`); the float64 division by 255 stays with the caller. */
 int lm_frame_sums(const uint8_t* d_frames, int n_frames, int64_t pixels_per_frame, uint64_t* d_sums, void* stream);
 
+/* Step 05 helper: which pairs (i < j) of n images placed in the frame share an ink pixel?  Replaces the all-pairs
+ * ConnectedComponent.getOverlapFMeasure loop of CCStabilityEstimator.compute_overlapping_CC_groups
+ * (AccessMath/preprocessing/content/cc_stability_estimator.py:696-714) and the incompatibility tests of
+ * KeyframeExtractor.GenerateFromST3DForIntervals (keyframe_extractor.py:85-91); "recall > 0 or precision > 0" of
+ * connected_component.py:202-250 is "one common pixel".  Host pointers: h_boxes [n][4] = min_x, max_x, min_y, max_y
+ * (inclusive), h_img_off [n + 1] byte offsets into h_images (image k is h x w uint8, non-zero = ink).  Up to cap pairs,
+ * sorted by (i, j), are written to h_pairs [cap][2]; *n_pairs = pairs found (LM_ERR_CAPACITY when that exceeds cap). */
+int lm_image_pairs_overlap(const int32_t* h_boxes, const uint8_t* h_images, const int64_t* h_img_off, int n, int32_t* h_pairs,
+                           int64_t cap, int64_t* n_pairs, void* stream);
+
 /* Host arrays owned by g (valid until lm_group_destroy): *ptr, *count (elements).  Array ids and element types:
  *  0 UNIQ_CC i32[n_uniq]  first-seen CC record of every unique (after the split)
  *  1 ULIST_OFF i64[n_uniq+1], 2 ULIST_CC i32   CSR of unique_cc_frames (entries are global CC indices)

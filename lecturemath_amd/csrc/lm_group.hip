@@ -367,6 +367,70 @@ __global__ void __launch_bounds__(256) lm_k_frame_sums(const uint8_t* __restrict
     if (threadIdx.x == 0 && s_acc) atomicAdd(&sums[blockIdx.y], s_acc);
 }
 
+// ------------------------------------------------------------------------------------------------
+// G6 (step 05): which pairs of {0,255} images placed in the frame share an ink pixel?  Replaces the all-pairs
+// ConnectedComponent.getOverlapFMeasure loop of CCStabilityEstimator.compute_overlapping_CC_groups
+// (cc_stability_estimator.py:696-714; "recall > 0 or precision > 0" <=> one common pixel) and the incompatibility tests of
+// KeyframeExtractor.GenerateFromST3DForIntervals (keyframe_extractor.py:85-91): box self-join, then a bit test per pair.
+// Images are packed to bit rows relative to their own x0 (ceil(w / 32) words per row).
+// ------------------------------------------------------------------------------------------------
+struct LmBitImage { int32_t x0, y0, w, h; long long src_off, bits_off; };
+
+__global__ void __launch_bounds__(256) lm_k_img_pack(const LmBitImage* __restrict__ items, int n, const uint8_t* __restrict__ src,
+                                                     uint32_t* __restrict__ bits)
+{
+    for (int it = blockIdx.y; it < n; it += gridDim.y) {
+        const LmBitImage im = items[it];
+        const int bw = (im.w + 31) >> 5;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < im.h * bw; i += gridDim.x * blockDim.x) {
+            const int y = i / bw, k = i - y * bw;
+            const uint8_t* p = src + im.src_off + (long long)y * im.w + k * 32;
+            const int lim = (im.w - k * 32 < 32) ? im.w - k * 32 : 32;
+            unsigned word = 0;
+            for (int b = 0; b < lim; b++) word |= (unsigned)(p[b] != 0) << b;
+            bits[im.bits_off + i] = word;
+        }
+    }
+}
+
+// 32 bits of row `y` (image coordinates) starting at column `x` (may start anywhere; bits beyond the row are zero)
+LM_DEV unsigned lm_bitrow32(const uint32_t* __restrict__ bits, const LmBitImage& im, int bw, int y, int x)
+{
+    const uint32_t* row = bits + im.bits_off + (long long)y * bw;
+    const int k = x >> 5, off = x & 31;
+    unsigned lo = (k < bw) ? row[k] : 0u;
+    unsigned hi = (off && k + 1 < bw) ? row[k + 1] : 0u;
+    return off ? ((lo >> off) | (hi << (32 - off))) : lo;
+}
+
+__global__ void __launch_bounds__(256) lm_k_bitimg_pair_any(const LmBitImage* __restrict__ items, const uint32_t* __restrict__ bits,
+                                                            const int2* __restrict__ pairs, int np, int32_t* __restrict__ hit)
+{
+    const int sub = (int)(threadIdx.x & 15);
+    const int group = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4), ngroups = (int)((gridDim.x * blockDim.x) >> 4);
+    const int np_pad = (np + 3) & ~3;       // whole waves stay in the loop for the shuffles
+    for (int p = group; p < np_pad; p += ngroups) {
+        int any = 0;
+        if (p < np) {
+            const LmBitImage a = items[pairs[p].x], b = items[pairs[p].y];
+            const int x0 = a.x0 > b.x0 ? a.x0 : b.x0, x1 = (a.x0 + a.w < b.x0 + b.w) ? a.x0 + a.w : b.x0 + b.w;     // [x0, x1)
+            const int y0 = a.y0 > b.y0 ? a.y0 : b.y0, y1 = (a.y0 + a.h < b.y0 + b.h) ? a.y0 + a.h : b.y0 + b.h;
+            const int abw = (a.w + 31) >> 5, bbw = (b.w + 31) >> 5;
+            const int chunks = (x1 - x0 + 31) >> 5, total = chunks * (y1 - y0);
+            for (int i = sub; i < total && !any; i += 16) {
+                const int r = i / chunks, c = i - r * chunks;
+                const int x = x0 + c * 32, y = y0 + r;
+                unsigned m = lm_bitrow32(bits, a, abw, y - a.y0, x - a.x0) & lm_bitrow32(bits, b, bbw, y - b.y0, x - b.x0);
+                if (x1 - x < 32) m &= (1u << (x1 - x)) - 1u;
+                any |= (m != 0u);
+            }
+        }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) any |= __shfl_xor(any, d, 16);
+        if (p < np && sub == 0) hit[p] = any;
+    }
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -948,6 +1012,93 @@ extern "C" int lm_frame_sums(const uint8_t* d_frames, int n_frames, int64_t pixe
                        (unsigned long long*)d_sums);
     LM_HIP(hipGetLastError());
     return LM_OK;
+}
+
+// Pairs (i < j) of images that share an ink pixel (see G6).  h_boxes [n][4] = min_x, max_x, min_y, max_y (inclusive), h_img_off
+// [n + 1] byte offsets into h_images (image k is (max_y - min_y + 1) x (max_x - min_x + 1) uint8, non-zero = ink).  Writes at
+// most cap pairs, sorted by (i, j), to h_pairs [cap][2]; *n_pairs receives the number found (LM_ERR_CAPACITY when > cap).
+extern "C" int lm_image_pairs_overlap(const int32_t* h_boxes, const uint8_t* h_images, const int64_t* h_img_off, int n, int32_t* h_pairs,
+                                      int64_t cap, int64_t* n_pairs, void* stream)
+{
+    if (!n_pairs || n < 0 || (n > 0 && (!h_boxes || !h_images || !h_img_off)) || cap < 0 || (cap > 0 && !h_pairs)) {
+        lm_set_error("lm_image_pairs_overlap: bad arguments");
+        return LM_ERR_ARG;
+    }
+    *n_pairs = 0;
+    if (n < 2) return LM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<LmBitImage> items((size_t)n);
+    std::vector<unsigned long long> hbox((size_t)n);
+    long long words = 0;
+    for (int k = 0; k < n; k++) {
+        const int32_t* bx = h_boxes + (size_t)k * 4;
+        LmBitImage& im = items[(size_t)k];
+        im.x0 = bx[0]; im.y0 = bx[2]; im.w = bx[1] - bx[0] + 1; im.h = bx[3] - bx[2] + 1;
+        if (im.w <= 0 || im.h <= 0 || bx[0] < 0 || bx[2] < 0 || bx[1] > 32767 || bx[3] > 32767 ||
+            h_img_off[k + 1] - h_img_off[k] != (int64_t)im.w * im.h) {
+            lm_set_error("lm_image_pairs_overlap: image %d: box / size mismatch", k);
+            return LM_ERR_ARG;
+        }
+        im.src_off = h_img_off[k];
+        im.bits_off = words;
+        words += (long long)im.h * ((im.w + 31) >> 5);
+        hbox[(size_t)k] = (unsigned long long)(unsigned short)bx[0] | ((unsigned long long)(unsigned short)bx[1] << 16) |
+                          ((unsigned long long)(unsigned short)bx[2] << 32) | ((unsigned long long)(unsigned short)bx[3] << 48);
+    }
+    const size_t img_bytes = (size_t)h_img_off[n];
+    LmBitImage* d_items = nullptr; unsigned long long* d_box = nullptr; uint8_t* d_src = nullptr; uint32_t* d_bits = nullptr;
+    int* d_np = nullptr; int2* d_pairs = nullptr; int32_t* d_hit = nullptr;
+    int rc = LM_OK;
+    auto done = [&](int code) {
+        void* ptrs[] = {d_items, d_box, d_src, d_bits, d_np, d_pairs, d_hit};
+        for (void* q : ptrs)
+            if (q) (void)hipFree(q);
+        return code;
+    };
+#define LM_PO(x) do { if ((x) != hipSuccess) { lm_set_error("lm_image_pairs_overlap: HIP error at %s", #x); return done(LM_ERR_HIP); } } while (0)
+    LM_PO(hipMalloc((void**)&d_items, items.size() * sizeof(LmBitImage)));
+    LM_PO(hipMalloc((void**)&d_box, hbox.size() * sizeof(unsigned long long)));
+    LM_PO(hipMalloc((void**)&d_src, std::max<size_t>(img_bytes, 1)));
+    LM_PO(hipMalloc((void**)&d_bits, (size_t)std::max<long long>(words, 1) * sizeof(uint32_t)));
+    LM_PO(hipMalloc((void**)&d_np, sizeof(int)));
+    LM_PO(hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(LmBitImage), hipMemcpyHostToDevice, st));
+    LM_PO(hipMemcpyAsync(d_box, hbox.data(), hbox.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+    LM_PO(hipMemcpyAsync(d_src, h_images, img_bytes, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(lm_k_img_pack, dim3(LM_HIP_EMULATED ? 1 : 4, (unsigned)std::min(n, LM_HIP_EMULATED ? 2 : 4096)), dim3(256), 0, st, d_items, n,
+                       d_src, d_bits);
+    int cap_pairs = 1 << 16, np = 0;
+    for (;;) {
+        LM_PO(hipMalloc((void**)&d_pairs, (size_t)cap_pairs * sizeof(int2)));
+        LM_PO(hipMemsetAsync(d_np, 0, sizeof(int), st));
+        const int gx = std::min((n + 255) / 256, LM_HIP_EMULATED ? 2 : 64), gy = std::min((n + LM_SJ_TILE - 1) / LM_SJ_TILE, LM_HIP_EMULATED ? 2 : 64);
+        hipLaunchKernelGGL(lm_k_selfjoin, dim3(gx, gy), dim3(256), 0, st, d_box, n, d_np, d_pairs, cap_pairs);
+        LM_PO(hipMemcpyAsync(&np, d_np, sizeof(int), hipMemcpyDeviceToHost, st));
+        LM_PO(hipStreamSynchronize(st));
+        if (np <= cap_pairs) break;
+        (void)hipFree(d_pairs); d_pairs = nullptr;
+        cap_pairs = np + (np >> 3);
+    }
+    std::vector<std::pair<int32_t, int32_t>> found;
+    if (np > 0) {
+        LM_PO(hipMalloc((void**)&d_hit, (size_t)np * sizeof(int32_t)));
+        hipLaunchKernelGGL(lm_k_bitimg_pair_any, dim3(LM_HIP_EMULATED ? 2 : 1024), dim3(256), 0, st, d_items, d_bits, d_pairs, np, d_hit);
+        std::vector<int2> hp((size_t)np);
+        std::vector<int32_t> hh((size_t)np);
+        LM_PO(hipMemcpyAsync(hp.data(), d_pairs, (size_t)np * sizeof(int2), hipMemcpyDeviceToHost, st));
+        LM_PO(hipMemcpyAsync(hh.data(), d_hit, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        LM_PO(hipStreamSynchronize(st));
+        for (int i = 0; i < np; i++)
+            if (hh[(size_t)i]) found.push_back({hp[(size_t)i].x, hp[(size_t)i].y});
+        std::sort(found.begin(), found.end());
+    }
+#undef LM_PO
+    *n_pairs = (int64_t)found.size();
+    if ((int64_t)found.size() > cap) {
+        lm_set_error("lm_image_pairs_overlap: %zu pairs, room for %lld", found.size(), (long long)cap);
+        return done(LM_ERR_CAPACITY);
+    }
+    for (size_t i = 0; i < found.size(); i++) { h_pairs[i * 2] = found[i].first; h_pairs[i * 2 + 1] = found[i].second; }
+    return done(rc);
 }
 
 extern "C" int lm_group_array(LmGroups* g, int which, const void** ptr, int64_t* count)

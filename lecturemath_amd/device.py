@@ -112,6 +112,30 @@ def frame_sums(frames, lib=None):
     return be.to_host(out)
 
 
+def image_pairs_overlap(boxes, images, lib=None):
+    """Pairs (i < j), sorted, of {0,255} images placed at their boxes (min_x, max_x, min_y, max_y inclusive) that share an ink
+    pixel (step 05: compute_overlapping_CC_groups / keyframe conflicts).  Box join + bit tests on the device."""
+    lib = lib or _lib.load()
+    n = len(images)
+    if n < 2:
+        return []
+    hb = np.ascontiguousarray(np.asarray(boxes, np.int32).reshape(n, 4))
+    off = np.zeros(n + 1, np.int64)
+    off[1:] = np.cumsum([im.size for im in images])
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(im, np.uint8).ravel() for im in images]))
+    be = Backend(lib)
+    cap = max(1024, 8 * n)
+    while True:
+        pairs = np.zeros((cap, 2), np.int32)
+        found = np.zeros(1, np.int64)
+        rc = lib.lm_image_pairs_overlap(hb.ctypes.data, flat.ctypes.data, off.ctypes.data, n, pairs.ctypes.data, cap, found.ctypes.data, be.stream())
+        if rc == _lib.LM_ERR_CAPACITY and int(found[0]) > cap:
+            cap = int(found[0])
+            continue
+        lib.check(rc)
+        return [(int(a), int(b)) for a, b in pairs[:int(found[0])]]
+
+
 def decode_crop(words, min_x, max_x, min_y, max_y):
     """bit-row crop (absolute 32-px column alignment) -> uint8 0/255 (h, w) like ConnectedComponent.img."""
     wx0 = min_x >> 5

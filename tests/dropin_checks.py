@@ -104,6 +104,66 @@ def check_step_04(name, step03_outputs, clean=None):
         assert [float(v) for v in sums] == [float(v) for v in g["sums"]]
 
 
+def check_step_05(lib, name):
+    """Step 05 core (KeyframeExtractor.GenerateFromST3DForIntervals) on the reference's own step-03 outputs (G4 fixture) vs
+    the reference's keyframes and CC times (G8), three segmentations; plus the entry point's interval arithmetic."""
+    import json
+    use_library(lib)
+    from AccessMath.data.space_time_struct import SpaceTimeStruct
+    from AccessMath.preprocessing.content.keyframe_extractor import KeyframeExtractor
+    g4, spec, _ = lm_checks.load_stream(name)
+    ng = len(g4["gimg_count"])
+    ages = {k: [int(v[0]) for v in lm_checks.unrag(g4["ages"], g4["ages_off"])[k]] for k in range(ng)}
+    bounds = {k: tuple(int(v) for v in g4["bounds"][k]) for k in range(ng)}
+    images, off = {}, 0
+    for k in range(ng):
+        w, h = bounds[k][1] - bounds[k][0] + 1, bounds[k][3] - bounds[k][2] + 1
+        images[k] = []
+        for _ in range(int(g4["gimg_count"][k])):
+            images[k].append(g4["gimg"][off:off + w * h].reshape(h, w).copy())
+            off += w * h
+    g = np.load(os.path.join(lm_checks.GOLD, "g8_step05_%s.npz" % name))
+    n = int(g["n_frames"])
+    times = [1000.0 * i for i in range(n)]
+    st3d = SpaceTimeStruct(times, list(range(n)), spec["h"], spec["w"], ages, images, bounds)
+    for k, segs in enumerate(json.loads(bytes(g["segments"]).decode())):
+        segs = [tuple(sg) for sg in segs]
+        keyframes, cc_times = KeyframeExtractor.GenerateFromST3DForIntervals(st3d, segs, False)
+        kf = np.stack(keyframes)
+        assert kf.dtype == np.uint8 and (kf[..., 0] == kf[..., 1]).all() and (kf[..., 0] == kf[..., 2]).all()
+        assert (np.packbits(kf[..., 0] == 255, axis=2) == g["keyframes_%d" % k]).all()
+        flat = [(sidx, *t) for sidx, lst in enumerate(cc_times) for t in lst]
+        assert (np.asarray(flat, np.float64).reshape(-1, 6) == g["times_%d" % k]).all()
+    s05 = load_script("pre_ST3D_v3.0_05_generate_summary.py")
+    (indices, stimes, kfs), = s05.process_input(types.SimpleNamespace(database=None), [st3d, segs])
+    assert indices == [sg[1] for sg in segs] and stimes == [times[sg[1]] for sg in segs] and len(kfs) == len(segs)
+
+
+def check_image_pairs(lib, seed=3, n=60, side=96):
+    """device.image_pairs_overlap vs a numpy all-pairs test: boxes at arbitrary (unaligned) positions, widths around the
+    32-bit word boundaries, disjoint ink inside overlapping boxes."""
+    from lecturemath_amd import device
+    rng = np.random.default_rng(seed)
+    boxes, images = [], []
+    for k in range(n):
+        w, h = int(rng.choice([1, 5, 31, 32, 33, 40, 64, 65])), int(rng.integers(1, 20))
+        x0, y0 = int(rng.integers(0, side - 1)), int(rng.integers(0, side - 1))
+        img = (rng.random((h, w)) < (0.15 if k % 3 else 0.6)).astype(np.uint8) * 255
+        boxes.append((x0, x0 + w - 1, y0, y0 + h - 1))
+        images.append(img)
+    want = []
+    canvas = []
+    for (x0, x1, y0, y1), img in zip(boxes, images):
+        c = np.zeros((side + 80, side + 80), bool)
+        c[y0:y1 + 1, x0:x1 + 1] = img > 0
+        canvas.append(c)
+    for i in range(n):
+        for j in range(i + 1, n):
+            if (canvas[i] & canvas[j]).any():
+                want.append((i, j))
+    assert device.image_pairs_overlap(boxes, images, lib) == want and len(want) > 10
+
+
 def check_step_04_from_golden(name):
     """Host-only: the step-04 drop-in fed with the reference's own step-03 outputs (ages, boundaries) from the G7 fixture."""
     if DROPIN not in sys.path:

@@ -100,3 +100,11 @@ def test_frame_sums_kernel(emu_lib):
     frames = rng.integers(0, 256, (3, 37, 53), dtype=np.uint8)
     frames[1] = 255
     assert list(device.frame_sums(frames, emu_lib)) == [int(f.astype(np.int64).sum()) for f in frames]
+
+
+def test_image_pairs_overlap(emu_lib):
+    dropin_checks.check_image_pairs(emu_lib)
+
+
+def test_step_05_short_gap(emu_lib):
+    dropin_checks.check_step_05(emu_lib, "short_gap_jitter")

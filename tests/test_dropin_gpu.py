@@ -40,3 +40,14 @@ def test_frame_sums_device(hip_lib):
     assert list(device.frame_sums(odd, hip_lib)) == [int(v) for v in odd.to(torch.int64).sum(dim=(1, 2)).cpu()]
     from AccessMath.preprocessing.content.video_segmenter import VideoSegmenter
     assert VideoSegmenter.compute_binary_sums(frames) == [v / 255 for v in want]
+
+
+def test_image_pairs_overlap(hip_lib):
+    dropin_checks.check_image_pairs(hip_lib)
+    dropin_checks.check_image_pairs(hip_lib, seed=9, n=400, side=300)
+
+
+@pytest.mark.parametrize("name", lm_checks.STREAMS)
+def test_step_05(hip_lib, name):
+    """Step 05 core: keyframes per video segment and their CC time lists vs the reference (G8)."""
+    dropin_checks.check_step_05(hip_lib, name)

@@ -110,3 +110,36 @@ def test_g7_step04(name):
     for (f, y, x), v in zip(g4["clean_other"], g4["clean_other_val"]):
         clean[f, y, x] = v
     assert [float(v) for v in seg.binary_sums(list(clean))] == [float(v) for v in g["sums"]]
+
+
+def g4_space_time(name):
+    """group ages / boundaries / images of the reference's step 03 (G4 fixture) as the dicts step 04 / 05 consume."""
+    g, spec, _ = lm_checks.load_stream(name)
+    ng = len(g["gimg_count"])
+    ages = {k: [int(v[0]) for v in lm_checks.unrag(g["ages"], g["ages_off"])[k]] for k in range(ng)}
+    bounds = {k: tuple(int(v) for v in g["bounds"][k]) for k in range(ng)}
+    images, off = {}, 0
+    for k in range(ng):
+        w, h = bounds[k][1] - bounds[k][0] + 1, bounds[k][3] - bounds[k][2] + 1
+        images[k] = []
+        for _ in range(int(g["gimg_count"][k])):
+            images[k].append(g["gimg"][off:off + w * h].reshape(h, w).copy())
+            off += w * h
+    return spec, ages, bounds, images
+
+
+@pytest.mark.parametrize("name", lm_checks.STREAMS)
+def test_g8_step05(name):
+    """oracle/keyframes.py (step 05 core) vs the reference's keyframes and CC times (G8)."""
+    from oracle import keyframes as okf
+    spec, ages, bounds, images = g4_space_time(name)
+    g = np.load(os.path.join(GOLD, "g8_step05_%s.npz" % name))
+    n = int(g["n_frames"])
+    times = [1000.0 * i for i in range(n)]
+    for k, segs in enumerate(json.loads(bytes(g["segments"]).decode())):
+        frames, cc_times = okf.keyframes(n, spec["w"], spec["h"], times, ages, bounds, images, [tuple(s) for s in segs])
+        kf = np.stack(frames)
+        assert (kf[..., 0] == kf[..., 1]).all() and (kf[..., 0] == kf[..., 2]).all()
+        assert (np.packbits(kf[..., 0] == 255, axis=2) == g["keyframes_%d" % k]).all()
+        flat = [(s, *t) for s, lst in enumerate(cc_times) for t in lst]
+        assert (np.asarray(flat, np.float64).reshape(-1, 6) == g["times_%d" % k]).all()
