@@ -170,6 +170,20 @@ int lm_frame_sums(const uint8_t* d_frames, int n_frames, int64_t pixels_per_fram
 int lm_image_pairs_overlap(const int32_t* h_boxes, const uint8_t* h_images, const int64_t* h_img_off, int n, int32_t* h_pairs,
                            int64_t cap, int64_t* n_pairs, void* stream);
 
+/* ---- the remaining exports of the reference's accessmath_lib.c (classical, pre-FCN binarizers) --------
+ * Same symbols and C signatures as the reference, host pointers (ctypes), results bit-identical to the C library:
+ *   accessmath_lib.c:7-111    speaker_detection_handle_frame (bound by AccessMath/preprocessing/video_worker/ speaker detection)
+ *   accessmath_lib.c:113-173  regionCumulativeDistribution   (adaptive_equalizer.py:274-291)
+ *   accessmath_lib.c:175-329  adapthisteq                    (adaptive_equalizer.py, binarizer.py:139-246)
+ *   accessmath_lib.c:331-355  combine_results                (binarizer.py:382-402) */
+int speaker_detection_handle_frame(unsigned char* frame, unsigned char* last_frame, int width, int height, int channels, int threshold,
+                                   int jump_cells, double* change_boundaries, double* change_avg, double* change_deviation);
+void regionCumulativeDistribution(unsigned char* grayscale, int width, int height, int min_x, int max_x, int min_y, int max_y,
+                                  double slope_max, double* output);
+int adapthisteq(unsigned char* grayscale, int width, int height, double slope, int grid_x, int grid_y, unsigned char* output);
+int combine_results(unsigned char* only_board, unsigned char* equalized, int width, int height, unsigned char threshold,
+                    unsigned char* final_content);
+
 /* Host arrays owned by g (valid until lm_group_destroy): *ptr, *count (elements).  Array ids and element types:
  *  0 UNIQ_CC i32[n_uniq]  first-seen CC record of every unique (after the split)
  *  1 ULIST_OFF i64[n_uniq+1], 2 ULIST_CC i32   CSR of unique_cc_frames (entries are global CC indices)

@@ -55,6 +55,10 @@ SIGNATURES = {
     "lm_stream_match": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
     "lm_stream_match_stats": (ctypes.c_int, [_vp, _vp, _vp]),
     "lm_frame_sums": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _vp, _vp]),
+    "speaker_detection_handle_frame": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
+    "regionCumulativeDistribution": (None, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, _vp]),
+    "adapthisteq": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, _vp]),
+    "combine_results": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_ubyte, _vp]),
     "lm_image_pairs_overlap": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, ctypes.c_int64, _vp, _vp]),
     "lm_stream_counters": (ctypes.c_int, [_vp, _vp, _vp]),
     "lm_stream_import": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, _i64, _i64, ctypes.c_int, _i64, _vp, _vp, _vp,

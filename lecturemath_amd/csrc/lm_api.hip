@@ -783,3 +783,5 @@ extern "C" int lm_stream_read(LmStream* s, int32_t* h_rec, int64_t* h_frame_off,
     LM_HIP(hipStreamSynchronize(st));
     return LM_OK;
 }
+
+#include "lm_legacy.hip"

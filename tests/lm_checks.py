@@ -8,6 +8,7 @@ import numpy as np
 
 from lecturemath_amd import device, synth
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 STREAMS = ["accumulate_erase", "occluder_return", "short_gap_jitter"]
 
@@ -231,6 +232,74 @@ def dot_grid_stream(n_frames=6, h=72, w=520, seed=3):
                     img[y:y + 4, x:x + 5] = 255
         frames.append(img)
     return frames
+
+
+def reference_c_library():
+    """oracle/_ref/accessmath_lib.so: the reference's own C file compiled by oracle/Makefile (travels to the GPU box)."""
+    import ctypes
+    path = os.path.join(ROOT, "oracle", "_ref", "accessmath_lib.so")
+    if not os.path.exists(path):
+        import pytest
+        pytest.skip("oracle/_ref/accessmath_lib.so not built (reference sources absent)")
+    return ctypes.CDLL(path)
+
+
+def check_legacy_exports(lib, big=False):
+    """The classical-binarizer exports of accessmath_lib.c (speaker_detection_handle_frame, regionCumulativeDistribution,
+    adapthisteq, combine_results) vs the reference C library itself, bit for bit (float64 outputs compared as bit patterns)."""
+    import ctypes
+    ref, mine = reference_c_library(), lib.cdll
+    rng = np.random.default_rng(17)
+    vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    for L in (ref, mine):
+        L.regionCumulativeDistribution.restype = None
+        L.regionCumulativeDistribution.argtypes = [vp, ci, ci, ci, ci, ci, ci, cd, vp]
+        L.adapthisteq.argtypes = [vp, ci, ci, cd, ci, ci, vp]
+        L.combine_results.argtypes = [vp, vp, ci, ci, ctypes.c_ubyte, vp]
+        L.speaker_detection_handle_frame.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp]
+        L.speaker_detection_handle_frame.restype = ci
+    sizes = [(97, 131), (64, 64)] + ([(1080, 1920)] if big else [])
+    for h, w in sizes:
+        # smooth image + noise so that histograms are neither flat nor degenerate
+        yy, xx = np.mgrid[0:h, 0:w]
+        gray = np.clip(120 + 60 * np.sin(xx / 17.0) * np.cos(yy / 23.0) + rng.normal(0, 25, (h, w)), 0, 255).astype(np.uint8)
+        gray = np.ascontiguousarray(gray)
+        # -- regionCumulativeDistribution
+        for (x0, x1, y0, y1), slope in (((0, w - 1, 0, h - 1), 0.0), ((3, w // 2, 5, h - 2), 0.01), ((w // 3, w // 3, 0, 0), 0.02)):
+            outs = []
+            for L in (ref, mine):
+                o = np.zeros(256, np.float64)
+                L.regionCumulativeDistribution(gray.ctypes.data, w, h, x0, x1, y0, y1, slope, o.ctypes.data)
+                outs.append(o)
+            assert (outs[0].view(np.int64) == outs[1].view(np.int64)).all()
+        # -- adapthisteq
+        for gx, gy, slope in ((8, 8, 0.01), (3, 5, 0.0), (1, 1, 0.02), (2, 1, 0.005)):
+            outs = []
+            for L in (ref, mine):
+                o = np.zeros((h, w), np.uint8)
+                L.adapthisteq(gray.ctypes.data, w, h, slope, gx, gy, o.ctypes.data)
+                outs.append(o)
+            assert (outs[0] == outs[1]).all(), (h, w, gx, gy, slope, int((outs[0] != outs[1]).sum()))
+        # -- combine_results
+        board = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        for thr in (0, 97, 255):
+            outs = []
+            for L in (ref, mine):
+                o = np.zeros((h, w), np.uint8)
+                L.combine_results(board.ctypes.data, gray.ctypes.data, w, h, thr, o.ctypes.data)
+                outs.append(o)
+            assert (outs[0] == outs[1]).all()
+        # -- speaker_detection_handle_frame
+        f0 = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        f1 = f0.copy()
+        f1[h // 4:h // 2, w // 3:w // 3 + 20] = rng.integers(0, 256, (h // 2 - h // 4, 20, 3), dtype=np.uint8)
+        for a, b, thr, jump in ((f1, f0, 20, 1), (f1, f0, 20, 4), (f0, f0, 20, 2), (f1, f0, 300, 1)):
+            outs = []
+            for L in (ref, mine):
+                bd, av, dv = np.zeros(4), np.zeros(2), np.zeros(2)
+                n = L.speaker_detection_handle_frame(a.ctypes.data, b.ctypes.data, w, h, 3, thr, jump, bd.ctypes.data, av.ctypes.data, dv.ctypes.data)
+                outs.append((n, bd.view(np.int64).tolist(), av.view(np.int64).tolist(), dv.view(np.int64).tolist()))
+            assert outs[0] == outs[1], (h, w, thr, jump, outs)
 
 
 def check_fcn_golden(lib, name, tol=1e-3, precision="f16x3"):

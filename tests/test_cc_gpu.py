@@ -44,6 +44,12 @@ def test_stream_frames_with_thousands_of_ccs(hip_lib, oracle_built):
     assert len(r["cc_idx_per_frame"][0]) > 3000
 
 
+def test_legacy_exports_vs_reference_c(hip_lib, oracle_built):
+    """speaker_detection_handle_frame / regionCumulativeDistribution / adapthisteq / combine_results of accessmath_lib.c on
+    the device vs the reference C library (oracle/_ref), bit for bit, up to 1080p."""
+    lm_checks.check_legacy_exports(hip_lib, big=True)
+
+
 def test_stream_vs_oracle_random_noise(hip_lib, oracle_built):
     rng = np.random.default_rng(11)
     base = (rng.random((120, 200)) < 0.5)
