@@ -217,6 +217,26 @@ def check_grouping_oracle(lib, frames, gap2=85, gap3=85, max_batch=8):
     return r
 
 
+def churn_stream(n_frames=40, h=160, w=640, seed=21, empty_every=7):
+    """Every frame re-draws its 5x4 dots at fresh random grid cells (almost everything is a new unique every frame: tens of
+    thousands of in-batch sources, active positions far beyond the replay kernel's LDS tables), with completely empty
+    frames in between (also as the very first frame)."""
+    rng = np.random.default_rng(seed)
+    ys, xs = np.arange(2, h - 5, 6), np.arange(2, w - 6, 7)
+    frames = []
+    for f in range(n_frames):
+        img = np.zeros((h, w), np.uint8)
+        if f % empty_every != 0:
+            on = rng.random((len(ys), len(xs))) < 0.45
+            for i, y in enumerate(ys):
+                for j, x in enumerate(xs):
+                    if on[i, j]:
+                        dy, dx = rng.integers(0, 2, 2)
+                        img[y + dy:y + dy + 4, x + dx:x + dx + 5] = 255
+        frames.append(img)
+    return frames
+
+
 def dot_grid_stream(n_frames=6, h=72, w=520, seed=3):
     """Hundreds of 5x4-pixel dots per 64x256 tile (more stable groups in one render tile than its cooperative hit list
     holds), a few of them blinking."""

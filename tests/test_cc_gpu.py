@@ -44,6 +44,17 @@ def test_stream_frames_with_thousands_of_ccs(hip_lib, oracle_built):
     assert len(r["cc_idx_per_frame"][0]) > 3000
 
 
+def test_stream_churn_and_empty_frames(hip_lib, oracle_built):
+    """A stream where nearly every CC is a new unique (>16k in-batch sources and >16k active positions in ONE 40-frame
+    matching batch: the replay kernel's global-memory fallbacks) and every seventh frame is empty; both matching paths."""
+    frames = lm_checks.churn_stream()
+    # max_gap = 1: a unique retires as soon as it misses a frame, so almost every CC of the 40-frame batch is a new unique
+    r = lm_checks.check_stream_oracle(hip_lib, frames, max_gap=1, max_batch=8, records_then_match=True, max_ccs=1 << 17,
+                                      max_crop_words=1 << 21)
+    assert len(r["unique_recs"]) > 20000
+    lm_checks.check_stream_oracle(hip_lib, frames, max_gap=50, max_batch=8, max_ccs=1 << 17, max_crop_words=1 << 21)
+
+
 def test_legacy_exports_vs_reference_c(hip_lib, oracle_built):
     """speaker_detection_handle_frame / regionCumulativeDistribution / adapthisteq / combine_results of accessmath_lib.c on
     the device vs the reference C library (oracle/_ref), bit for bit, up to 1080p."""
