@@ -32,7 +32,8 @@ ALGO_BYTES_PER_PX = 5           # 1 B uint8 in + 4 B int32 label
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--steps", type=int, default=40,
+                   help="timed steps; a step is one 256-frame stream, so the default run covers the 10k frames of BASELINE configs[2]")
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--frames", type=int, default=256, help="frames per stream (= per step)")
     p.add_argument("--height", type=int, default=1080)

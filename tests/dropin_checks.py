@@ -139,6 +139,35 @@ def check_step_05(lib, name):
     assert indices == [sg[1] for sg in segs] and stimes == [times[sg[1]] for sg in segs] and len(kfs) == len(segs)
 
 
+def check_pipeline(lib, name):
+    """lecturemath_amd.pipeline.LecturePipeline (steps 02-05 in one process, device-resident hand-off) on a golden stream:
+    intervals == the reference's step 04 (G7, parameter set 2) and keyframes == the reference's step 05 on those intervals (G8)."""
+    import json
+    use_library(lib)
+    from lecturemath_amd.pipeline import LecturePipeline
+    g3, spec, frames = lm_checks.load_stream(name)
+    g7_, params = g7(name)
+    g8 = np.load(os.path.join(lm_checks.GOLD, "g8_step05_%s.npz" % name))
+    conf = dict(params[2], CC_STABILITY_MAX_GAP=spec["gap2"])
+    pipe = LecturePipeline(spec["w"], spec["h"], conf=conf, lib=lib)
+    n = len(frames)
+    half = n // 2
+    pipe.add_binary_frames(np.stack(frames[:half]), [1000.0 * i for i in range(half)], list(range(half)))
+    pipe.add_binary_frames(np.stack(frames[half:]), [1000.0 * i for i in range(half, n)], list(range(half, n)))
+    # the fixtures ran step 02 and step 03 with different CC_STABILITY_MAX_GAP values: switch the key between the two
+    pipe.configuration.data["CC_STABILITY_MAX_GAP"] = str(spec["gap3"])
+    out = pipe.finish(reconstructed_png=True)
+    assert [tuple(int(v) for v in iv) for iv in out["intervals"]] == [tuple(int(v) for v in iv) for iv in g7_["intervals_2"]]
+    assert json.loads(bytes(g8["segments"]).decode())[0] == [list(iv) for iv in out["intervals"]]
+    kf = np.stack(out["keyframes"])
+    assert (np.packbits(kf[..., 0] == 255, axis=2) == g8["keyframes_0"]).all()
+    from lecturemath_amd import png
+    clean = np.stack([png.decode_gray8(c) for c in out["reconstructed_png"]])
+    assert (np.packbits(clean == 255, axis=2) == g3["clean_packed"]).all()
+    dev = lib and out["reconstructed_device"](0, min(4, n))
+    assert (pipe.be.to_host(dev) == clean[:min(4, n)]).all()
+
+
 def check_image_pairs(lib, seed=3, n=60, side=96):
     """device.image_pairs_overlap vs a numpy all-pairs test: boxes at arbitrary (unaligned) positions, widths around the
     32-bit word boundaries, disjoint ink inside overlapping boxes."""

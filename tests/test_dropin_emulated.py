@@ -108,3 +108,7 @@ def test_image_pairs_overlap(emu_lib):
 
 def test_step_05_short_gap(emu_lib):
     dropin_checks.check_step_05(emu_lib, "short_gap_jitter")
+
+
+def test_pipeline_short_gap(emu_lib):
+    dropin_checks.check_pipeline(emu_lib, "short_gap_jitter")
