@@ -304,7 +304,7 @@ def main():
 
     # ---- CPU baseline: the oracle (C port, 1 thread) on a prefix of the same stream
     cpu = None
-    if a.cpu_frames > 0:
+    if a.cpu_frames > 0 and world == 1:     # reported at N = 1 only
         from oracle import cc as occ
         n = min(a.cpu_frames, F)
         lg = logits[:n].cpu().numpy()
