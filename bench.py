@@ -118,7 +118,7 @@ def main_fcn(a):
         err = float((out.cpu() - o[0, 0]).abs().max())
         cpu = {"value": round(1.0 / cdt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                "sample": "one 1080p frame, oracle/fcn.py (torch fp32 CPU functional restatement); max |logit diff| vs HIP = %.2e" % err}
-    print(json.dumps({
+    out = {
         "metric": "frames/sec FCN-LectureNet binarizer inference @1080p", "value": round(a.steps / dt, 3), "unit": "frames/s", "n_gpus": 1,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if a.fcn_precision == "fp32" else "f16x3 (fp16-split operands, fp32 accumulate)", "data": "synthetic",
@@ -131,7 +131,14 @@ def main_fcn(a):
                       "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(3 * tflops / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
                       "launch_ms": round(gpu_ms, 3), "algorithmic_tflops": round(tflops, 2),
                       "note": "achieved counts the executed f16 MFMA flops (3 per algorithmic flop: hi.hi + hi.lo + lo.hi)"}),
-        "cpu_baseline": cpu}))
+        "cpu_baseline": cpu}
+    # MFMA-pipe utilisation from the PMC pass committed under profiles/ (not collectable live): busy cycles of the matrix pipe
+    # over the conv-stack dispatches, as opposed to `frac` above, which prices useful flops against the dense peak
+    ppath = os.path.join(ROOT, "profiles", "r01_fcn_mfma_pmc_%s.json" % a.fcn_precision)
+    if os.path.exists(ppath) and (W, H) == (1920, 1080):
+        out["roofline"]["mfma_util_pmc"] = json.load(open(ppath))["conv_stack_mfma_util"]
+        out["roofline"]["mfma_util_pmc_source"] = "profiles/" + os.path.basename(ppath) + " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)"
+    print(json.dumps(out))
 
 
 def main():
