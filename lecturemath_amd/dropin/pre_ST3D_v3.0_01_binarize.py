@@ -28,15 +28,8 @@ def get_results(worker):
 
 
 def main():
-    from AccessMath.preprocessing.user_interface.console_ui_process import ConsoleUIProcess
-    if not ConsoleUIProcess.usage_with_config_check(sys.argv):
-        return
-    process = ConsoleUIProcess.FromConfigPath(sys.argv[1], sys.argv[2:], None, "BINARIZATION_OUTPUT")
-    if not process.initialize():
-        return
-    fps = process.configuration.get_float("SAMPLING_FPS", 1.0)
-    process.start_video_processing(fps, get_worker, get_results, 0, True, True)
-    print("finished")
+    import lm_entry
+    lm_entry.run_on_videos(sys.argv, "BINARIZATION_OUTPUT", get_worker, get_results)
 
 
 if __name__ == "__main__":

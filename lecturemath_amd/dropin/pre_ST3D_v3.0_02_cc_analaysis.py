@@ -6,29 +6,23 @@ import sys
 def process_input(process, input_data):
     from AccessMath.preprocessing.content.helper import Helper
     from AccessMath.preprocessing.content.cc_stability_estimator import CCStabilityEstimator
-    frame_times, frame_indices, compressed_frames = input_data
-    print("Decompressing input...")
-    binary_frames = Helper.decompress_binary_images(compressed_frames)
-    height, width = binary_frames[0].shape
+    times, indices, png_frames = input_data
     cfg = process.configuration
-    estimator = CCStabilityEstimator(width, height, cfg.get_float("CC_STABILITY_MIN_RECALL", 0.925),
-                                     cfg.get_float("CC_STABILITY_MIN_PRECISION", 0.925), cfg.get_int("CC_STABILITY_MAX_GAP", 85), True)
+    thresholds = [cfg.get_float("CC_STABILITY_MIN_" + which, 0.925) for which in ("RECALL", "PRECISION")]
+    print("Decompressing input...")
+    frames = Helper.decompress_binary_images(png_frames)
+    estimator = CCStabilityEstimator(frames[0].shape[1], frames[0].shape[0], thresholds[0], thresholds[1],
+                                     cfg.get_int("CC_STABILITY_MAX_GAP", 85), True)
     print("Processing frames...")
-    for frame in binary_frames:
-        estimator.add_frame(frame, True)
+    for binary in frames:                       # buffered; pushed to the device a batch at a time
+        estimator.add_frame(binary, True)
     estimator.finish_processing()
-    return frame_times, frame_indices, estimator
+    return times, indices, estimator
 
 
 def main():
-    from AccessMath.preprocessing.user_interface.console_ui_process import ConsoleUIProcess
-    if not ConsoleUIProcess.usage_with_config_check(sys.argv):
-        return
-    process = ConsoleUIProcess.FromConfigPath(sys.argv[1], sys.argv[2:], "BINARIZATION_OUTPUT", "CC_STABILITY_OUTPUT")
-    if not process.initialize():
-        return
-    process.start_input_processing(process_input)
-    print("Finished!")
+    import lm_entry
+    lm_entry.run_on_inputs(sys.argv, "BINARIZATION_OUTPUT", "CC_STABILITY_OUTPUT", process_input)
 
 
 if __name__ == "__main__":

@@ -37,17 +37,8 @@ def process_input(process, input_data):
 
 
 def main():
-    from AccessMath.preprocessing.user_interface.console_ui_process import ConsoleUIProcess
-    if not ConsoleUIProcess.usage_with_config_check(sys.argv):
-        return
-    process = ConsoleUIProcess.FromConfigPath(sys.argv[1], sys.argv[2:], "CC_STABILITY_OUTPUT",
-                                              ["CC_RECONSTRUCTED_OUTPUT", "CC_CONFLICTS_OUTPUT", "CC_ST3D_OUTPUT"])
-    if not process.initialize():
-        return
-    start = time.time()
-    process.start_input_processing(process_input)
-    print("Total time: %.1f s" % (time.time() - start))
-    print("Finished")
+    import lm_entry
+    lm_entry.run_on_inputs(sys.argv, "CC_STABILITY_OUTPUT", ["CC_RECONSTRUCTED_OUTPUT", "CC_CONFLICTS_OUTPUT", "CC_ST3D_OUTPUT"], process_input)
 
 
 if __name__ == "__main__":

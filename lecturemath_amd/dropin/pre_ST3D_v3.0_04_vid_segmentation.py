@@ -50,26 +50,16 @@ def process_input(process, input_data):
     return intervals
 
 
+def _inputs_for_method(configuration):
+    method = configuration.get_int("VIDEO_SEGMENTATION_METHOD", 2)
+    keys = {3: ["CC_RECONSTRUCTED_OUTPUT", "CC_CONFLICTS_OUTPUT", "CC_ST3D_OUTPUT"], 2: ["CC_RECONSTRUCTED_OUTPUT", "CC_CONFLICTS_OUTPUT"]}
+    chosen = keys.get(method)
+    return [configuration.get(k) for k in chosen] if chosen else configuration.get("CC_RECONSTRUCTED_OUTPUT")
+
+
 def main():
-    from AccessMath.preprocessing.user_interface.console_ui_process import ConsoleUIProcess
-    if not ConsoleUIProcess.usage_with_config_check(sys.argv):
-        return
-    process = ConsoleUIProcess.FromConfigPath(sys.argv[1], sys.argv[2:], None, "VIDEO_SEGMENTATION_OUTPUT")
-    segmentation_method = process.configuration.get_int("VIDEO_SEGMENTATION_METHOD", 2)
-    if segmentation_method == 3:
-        inputs = [process.configuration.get("CC_RECONSTRUCTED_OUTPUT"), process.configuration.get("CC_CONFLICTS_OUTPUT"),
-                  process.configuration.get("CC_ST3D_OUTPUT")]
-    elif segmentation_method == 2:
-        inputs = [process.configuration.get("CC_RECONSTRUCTED_OUTPUT"), process.configuration.get("CC_CONFLICTS_OUTPUT")]
-    else:
-        inputs = process.configuration.get("CC_RECONSTRUCTED_OUTPUT")
-    process.input_temp_prefix = inputs
-    if not process.initialize():
-        return
-    start = time.time()
-    process.start_input_processing(process_input)
-    print("Total time: %.1f s" % (time.time() - start))
-    print("Finished")
+    import lm_entry
+    lm_entry.run_on_inputs(sys.argv, None, "VIDEO_SEGMENTATION_OUTPUT", process_input, choose_inputs=_inputs_for_method)
 
 
 if __name__ == "__main__":

@@ -4,32 +4,27 @@ reference's own KeyframeExporter (XML + PNG files; not part of this build, impor
 import sys
 
 
+def tiling_intervals(st3D, video_segments):
+    """(idx_intervals, time_intervals, summary_indices, summary_times) of pre_ST3D_v3.0_05_generate_summary.py:38-66."""
+    # Every segment is summarised at its last frame (:63-66); the exported intervals tile the video: each boundary sits in the
+    # middle of the gap between one segment's last frame and the next segment's first frame (:46-57), the first interval
+    # starts at 0 and the last ends with the last segment.
+    summary_indices = [st3D.frame_indices[last] for _, last in video_segments]
+    summary_times = [st3D.frame_times[last] for _, last in video_segments]
+    following = [(st3D.frame_indices[first], st3D.frame_times[first]) for first, _ in video_segments[1:]]
+    cut_idx = [int((end + nxt[0]) / 2) for end, nxt in zip(summary_indices, following)] + summary_indices[-1:]
+    cut_time = [(end + nxt[1]) / 2.0 for end, nxt in zip(summary_times, following)] + summary_times[-1:]
+    idx_intervals = list(zip([0] + cut_idx[:-1], cut_idx))
+    time_intervals = list(zip([0] + cut_time[:-1], cut_time))
+    return idx_intervals, time_intervals, summary_indices, summary_times
+
+
 def process_input(process, input_data):
     from AccessMath.preprocessing.content.keyframe_extractor import KeyframeExtractor
     st3D = input_data[0]
     video_segments = input_data[1]
     keyframes, cc_times = KeyframeExtractor.GenerateFromST3DForIntervals(st3D, video_segments)
-    idx_intervals, time_intervals, summary_times, summary_indices = [], [], [], []
-    # logical frame indices of the intervals -> absolute frame indices; boundaries moved to the middle of the gaps (:38-66)
-    last_start = 0
-    last_time_start = 0
-    for idx, (segment_start, segment_end) in enumerate(video_segments):
-        frame_end = st3D.frame_indices[segment_end]
-        time_end = st3D.frame_times[segment_end]
-        if idx + 1 < len(video_segments):
-            next_frame_start = st3D.frame_indices[video_segments[idx + 1][0]]
-            next_time_start = st3D.frame_times[video_segments[idx + 1][0]]
-            interval_end = int((frame_end + next_frame_start) / 2)
-            time_interval_end = (time_end + next_time_start) / 2.0
-        else:
-            interval_end = frame_end
-            time_interval_end = time_end
-        idx_intervals.append((last_start, interval_end))
-        time_intervals.append((last_time_start, time_interval_end))
-        last_start = interval_end
-        last_time_start = time_interval_end
-        summary_indices.append(frame_end)
-        summary_times.append(st3D.frame_times[segment_end])
+    idx_intervals, time_intervals, summary_indices, summary_times = tiling_intervals(st3D, video_segments)
     if getattr(process, "database", None) is not None:
         from AccessMath.preprocessing.content.keyframe_exporter import KeyframeExporter
         database, lecture = process.database, process.current_lecture
@@ -41,15 +36,8 @@ def process_input(process, input_data):
 
 
 def main():
-    from AccessMath.preprocessing.user_interface.console_ui_process import ConsoleUIProcess
-    if not ConsoleUIProcess.usage_with_config_check(sys.argv):
-        return
-    process = ConsoleUIProcess.FromConfigPath(sys.argv[1], sys.argv[2:], ["CC_ST3D_OUTPUT", "VIDEO_SEGMENTATION_OUTPUT"],
-                                              "SUMMARY_KEYFRAMES_OUTPUT")
-    if not process.initialize():
-        return
-    process.start_input_processing(process_input)
-    print("Finished")
+    import lm_entry
+    lm_entry.run_on_inputs(sys.argv, ["CC_ST3D_OUTPUT", "VIDEO_SEGMENTATION_OUTPUT"], "SUMMARY_KEYFRAMES_OUTPUT", process_input)
 
 
 if __name__ == "__main__":

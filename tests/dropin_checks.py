@@ -137,6 +137,19 @@ def check_step_05(lib, name):
     s05 = load_script("pre_ST3D_v3.0_05_generate_summary.py")
     (indices, stimes, kfs), = s05.process_input(types.SimpleNamespace(database=None), [st3d, segs])
     assert indices == [sg[1] for sg in segs] and stimes == [times[sg[1]] for sg in segs] and len(kfs) == len(segs)
+    # the exported intervals: boundaries in the middle of the gaps (written out the long way here)
+    idx_iv, time_iv, _, _ = s05.tiling_intervals(st3d, segs)
+    want_idx, want_time, prev_i, prev_t = [], [], 0, 0
+    for k, (_, last) in enumerate(segs):
+        if k + 1 < len(segs):
+            nxt = segs[k + 1][0]
+            end_i, end_t = int((st3d.frame_indices[last] + st3d.frame_indices[nxt]) / 2), (st3d.frame_times[last] + st3d.frame_times[nxt]) / 2.0
+        else:
+            end_i, end_t = st3d.frame_indices[last], st3d.frame_times[last]
+        want_idx.append((prev_i, end_i))
+        want_time.append((prev_t, end_t))
+        prev_i, prev_t = end_i, end_t
+    assert idx_iv == want_idx and time_iv == want_time
 
 
 def check_pipeline(lib, name):
