@@ -385,7 +385,7 @@ extern "C" void lm_stream_destroy(LmStream* s)
         if (p) (void)hipFree(p);
     if (s->mb) {
         LmMatchBatch* m = s->mb;
-        void* mp[] = {m->ftile, m->s_prefix, m->tcount[0], m->tcount[1], m->toff[0], m->toff[1], m->pairs[0], m->pairs[1], m->pair_u[0],
+        void* mp[] = {m->tcur[0], m->tcur[1], m->ftile_all, m->nt_foff, m->nt_list, m->cls, m->troot, m->rootpos, m->ftile, m->s_prefix, m->tcount[0], m->tcount[1], m->toff[0], m->toff[1], m->pairs[0], m->pairs[1], m->pair_u[0],
                       m->pair_u[1], m->sidx, m->s_list, m->s_box, m->newpos, m->n_src, m->ttab, m->tkey, m->twin};
         for (void* p : mp)
             if (p) (void)hipFree(p);
@@ -456,9 +456,16 @@ extern "C" LmStream* lm_stream_create(LmCtx* ctx, int max_frames, int64_t max_cc
         m->cap_pairs = (uint32_t)cp;
         rc |= lm_alloc(&m->ftile, (size_t)max_frames + 2);
         rc |= lm_alloc(&m->s_prefix, (size_t)max_frames + 2);
+        rc |= lm_alloc(&m->ftile_all, (size_t)max_frames + 2);
+        rc |= lm_alloc(&m->nt_foff, (size_t)max_frames + 2);
+        rc |= lm_alloc(&m->nt_list, (size_t)max_ccs);
+        rc |= lm_alloc(&m->cls, (size_t)max_ccs);
+        rc |= lm_alloc(&m->troot, (size_t)max_ccs);
+        rc |= lm_alloc(&m->rootpos, (size_t)max_ccs);
         for (int k = 0; k < 2; k++) {
             rc |= lm_alloc(&m->tcount[k], (size_t)m->cap_tiles + 1);
             rc |= lm_alloc(&m->toff[k], (size_t)m->cap_tiles + 1);
+            rc |= lm_alloc(&m->tcur[k], (size_t)m->cap_tiles + 1);
             rc |= lm_alloc(&m->pairs[k], (size_t)m->cap_pairs);
             rc |= lm_alloc(&m->pair_u[k], (size_t)m->cap_pairs);
         }
@@ -505,18 +512,18 @@ static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st)
         return;
     }
     const LmMatchBatch mb = *s->mb;
-    const dim3 gj(LM_HIP_EMULATED ? 2 : 1024), ge(LM_HIP_EMULATED ? 2 : 2048);
+    const dim3 gj(LM_HIP_EMULATED ? 2 : 128, LM_HIP_EMULATED ? 2 : 8), gt(LM_HIP_EMULATED ? 2 : 1024), ge(LM_HIP_EMULATED ? 2 : 2048);
     for (int done = 0; done < n;) {
         const int B = (n - done < LM_MB_MAX_FRAMES) ? n - done : LM_MB_MAX_FRAMES;
         const int f = f0 + done;
         s->last_match_frames = B;
-        hipLaunchKernelGGL(lm_k_mb_prologue, dim3(1), dim3(1024), 0, st, s->frame_cc_off, f, B, s->active, s->active_cc, s->active_box,
-                           s->active_last, s->counters, mb, s->max_gap);
-        if (s->min_recall <= 1.0 && s->min_precision <= 1.0) {     // the twin rule needs "identical crops are accepted"
+        if (s->min_recall <= 1.0 && s->min_precision <= 1.0) {     // the twin rule needs "identical crops are accepted"; otherwise twin[] stays 0
             (void)hipMemsetAsync(mb.ttab, 0xff, (size_t)LM_MB_TTAB * sizeof(unsigned long long), st);
             hipLaunchKernelGGL(lm_k_mb_twin_insert, ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->counters, mb);
             hipLaunchKernelGGL(lm_k_mb_twin_find, ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->counters, mb, s->max_gap);
         }
+        hipLaunchKernelGGL(lm_k_mb_nt, dim3(1), dim3(1024), 0, st, s->frame_cc_off, f, B, s->active, s->active_cc, s->active_box, s->active_last,
+                           s->counters, mb, s->max_gap);
         hipLaunchKernelGGL((lm_k_mb_join<0, 0>), gj, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->counters, mb);
         hipLaunchKernelGGL((lm_k_mb_join<0, 1>), gj, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->counters, mb);
         hipLaunchKernelGGL((lm_k_mb_eval<0>), ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->active_last, s->counters, mb,
@@ -526,8 +533,10 @@ static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st)
         hipLaunchKernelGGL((lm_k_mb_join<1, 1>), gj, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->counters, mb);
         hipLaunchKernelGGL((lm_k_mb_eval<1>), ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->active_last, s->counters, mb,
                            s->min_recall, s->min_precision, s->max_gap);
-        hipLaunchKernelGGL(lm_k_mb_resolve, dim3(1), dim3(1024), LM_MB_RESOLVE_SMEM, st, s->cc, s->frame_cc_off, f, B, s->active, s->active_cc,
+        hipLaunchKernelGGL(lm_k_mb_resolve, dim3(1), dim3(LM_MB_RT), LM_MB_RESOLVE_SMEM, st, s->cc, s->frame_cc_off, f, B, s->active, s->active_cc,
                            s->active_box, s->active_last, s->counters, s->assign, mb, s->max_gap, s->cap_uniq);
+        hipLaunchKernelGGL(lm_k_mb_tempo, gt, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->active_last,
+                           s->counters, mb, s->max_gap);
         done += B;
     }
 }

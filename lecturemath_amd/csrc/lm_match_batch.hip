@@ -19,13 +19,19 @@
 //                         the twin itself -- with recall = precision = 1 (thresholds <= 1), and that unique is still
 //                         alive.  Twins are found with a hash table (min CC index per key) and verified word by word;
 //                         a missed twin only costs time.  Static video: almost every CC is a twin
+//                         A twin is moreover ASSIGNED the unique its root was assigned: every smaller-index candidate it accepts
+//                         was dead or rejected at the root's frame already, and the root's unique was matched there.  So only
+//                         the non-twin CCs (NT, compacted by lm_k_mb_nt) go through joins, evaluation and pair replay.
 //   S  lm_k_mb_sources    the other CCs of the batch are the only ones that CAN become new uniques: compact them (S)
 //   B  lm_k_mb_join<1,*> + lm_k_mb_eval<1>: the same join against S, restricted to sources of EARLIER frames
 //   C  lm_k_mb_resolve    frames in order: a pair counts if its unique exists and is alive; smallest accepted active
 //                         position per CC (ascending unique index == the reference's first match) or a new unique,
 //                         numbered in CC order; `last` and the active list are updated as the reference does.
 // In-batch uniques get active positions behind all earlier ones in creation order, so "smallest position" is still
-// "smallest unique index".  tempo_count (:85) counts the same (cur, alive unique) box pairs as the per-frame kernels.
+// "smallest unique index".  tempo_count (:85), the number of (cur, alive unique) box pairs, does not need the replay: a unique
+// is a candidate at frame f iff it was born before f and alive(f, its last match at the END of the batch) -- one that is
+// matched later was alive all along, a dead one is never matched again -- so lm_k_mb_tempo is one streaming box join of all
+// CCs against the final active list.
 #include "lm_stream.h"
 
 #define LM_MB_TILE 64
@@ -33,27 +39,35 @@
 #define LM_MB_CHUNK 4096        // source boxes filtered per round (LDS survivors list)
 #define LM_MB_MAX_FRAMES 64     // frames per batch (per-frame tables of the replay kernel live in LDS)
 #define LM_MB_CH 2048           // CCs of one frame resolved per LDS pass
-#define LM_MB_LA 16384          // active positions whose last-matched frame is cached in LDS by the replay kernel
-#define LM_MB_LS 16384          // sources whose active position is cached in LDS by the replay kernel
-#define LM_MB_PFA 6             // pairs per thread prefetched one frame ahead: against earlier uniques ...
-#define LM_MB_PFB 2             // ... and against in-batch sources
-#define LM_MB_RESOLVE_SMEM ((size_t)LM_MB_CH * 4 + (size_t)LM_MB_LA * 4 + (size_t)LM_MB_LS * 4)
+#define LM_MB_LA 12288          // active positions whose last-matched frame is cached in LDS by the replay kernel
+#define LM_MB_LS 12288          // sources whose active position is cached in LDS by the replay kernel
+#define LM_MB_RP 8192           // non-twin CCs whose decided active position is cached in LDS (twins look their root up)
+#define LM_MB_PFA 2             // pairs per thread prefetched one frame ahead: against earlier uniques ...
+#define LM_MB_PFB 1             // ... and against in-batch sources
+#define LM_MB_RESOLVE_SMEM ((size_t)LM_MB_CH * 8 + (size_t)LM_MB_LA * 4 + (size_t)LM_MB_LS * 4 + (size_t)LM_MB_RP * 4)
 
 struct LmMatchBatch {
-    int32_t* ftile;             // [cap_frames + 2] first tile of every frame of the batch; ftile[B] = number of tiles
+    int32_t* ftile;             // [cap_frames + 2] first tile (64 NON-TWIN CCs) of every frame of the batch; ftile[B] = number of tiles
+    int32_t* ftile_all;         // [cap_frames + 2] the same over ALL CCs (lm_k_mb_tempo)
+    int32_t* nt_foff;           // [cap_frames + 2] index in nt_list of the first non-twin CC of every frame; nt_foff[B] = count
+    int32_t* nt_list;           // [cap_cc] global cc index of non-twin k (ascending)
+    int32_t* cls;               // [cap_cc] per global cc: k >= 0 own index in nt_list; -1 - k: twin whose root is non-twin k
+    int32_t* troot;             // [cap_cc] per global cc: global cc index of the twin's root (valid where twin[] is set)
+    int32_t* rootpos;           // [cap_cc] active position decided for non-twin k (global copy of the replay's LDS table)
     int32_t* s_prefix;          // [cap_frames + 2] number of sources that belong to frames before frame b of the batch
     uint32_t* tcount[2];        // [cap_tiles + 1]  pairs per tile (A: vs actives, B: vs in-batch sources)
     uint32_t* toff[2];          // [cap_tiles + 1]  exclusive prefix, toff[nt] = total
+    uint32_t* tcur[2];          // [cap_tiles + 1]  fill cursors (one reservation per workgroup)
     uint2* pairs[2];            // x = (cc - C0) | accepted << 31, y = active position (A) / source index (B)
     int32_t* pair_u[2];         // cc index of the unique's first-seen CC (what the pair is evaluated against)
     int32_t* sidx;              // [cap_cc] per global cc: -2 undecided, -1 surely matched; after lm_k_mb_sources: k >= 0 index into
-                                // the source list, or -1 - (number of sources before this CC)
+                                // the source list for the sources, still negative for everybody else
     int32_t* s_list;            // [cap_cc] cc index of source k (ascending)
     unsigned long long* s_box;  // packed box of source k
     int32_t* newpos;            // active position source k was given when it became a unique, else -1
     int32_t* n_src;             // [1]
     unsigned long long* ttab;   // [LM_MB_TTAB] twin table: key32 << 32 | smallest batch-relative cc index with that key
-    uint32_t* tkey;             // [cap_cc] per global cc: key32 of (box, size, crop)
+    uint32_t* tkey;             // [cap_cc] per global cc: key32 of (box, size, crop); later: non-twins before this CC (lm_k_mb_nt)
     uint8_t* twin;              // [cap_cc] per global cc: 1 = exact twin of an earlier CC of the batch
     uint32_t cap_pairs;
     int cap_tiles;
@@ -62,9 +76,9 @@ struct LmMatchBatch {
 LM_DEV bool lm_mb_alive(int f, int last, int max_gap) { return f <= 1 || (f - 1) - last < max_gap; }
 
 // ------------------------------------------------------------------------------------------------
-// P: one block.
+// P: first part of lm_k_mb_nt (one block).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) lm_k_mb_prologue(const long long* __restrict__ frame_cc_off, int f0, int B,
+LM_DEV void lm_mb_prologue(const long long* __restrict__ frame_cc_off, int f0, int B,
                                                          int32_t* __restrict__ active, int32_t* __restrict__ active_cc,
                                                          unsigned long long* __restrict__ active_box, int32_t* __restrict__ active_last,
                                                          LmCounters* __restrict__ cnt, LmMatchBatch mb, int max_gap)
@@ -98,23 +112,90 @@ __global__ void __launch_bounds__(1024) lm_k_mb_prologue(const long long* __rest
         }
         nA = (int)kept;
     }
-    // ---- tile table
-    const int b = threadIdx.x;
-    unsigned nt_b = 0;
-    if (b < B) nt_b = (unsigned)((frame_cc_off[f0 + b + 1] - frame_cc_off[f0 + b] + LM_MB_TILE - 1) / LM_MB_TILE);
-    unsigned nt;
-    unsigned ex = lm_block_excl_scan<1024>(nt_b, &nt);
-    if (b < B) mb.ftile[b] = (int32_t)ex;
-    if (b == 0) {
-        mb.ftile[B] = (int32_t)nt;
+    if (threadIdx.x == 0) {
         *mb.n_src = 0;
         cnt->n_active = nA;
-        if ((int)nt > mb.cap_tiles) cnt->error = LM_ERR_CAPACITY;
     }
-    if ((int)nt > mb.cap_tiles) return;
-    for (unsigned t = threadIdx.x; t <= nt; t += 1024) { mb.tcount[0][t] = 0; mb.tcount[1][t] = 0; }
     const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
     for (long long i = C0 + threadIdx.x; i < C1; i += 1024) mb.sidx[i] = -2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// N: compact the non-twin CCs (the only ones that go through joins, evaluation and pair replay), give every twin its
+// root's index, and build the tile tables.  One block; ballots per 1024-CC row like lm_k_mb_sources.
+// ------------------------------------------------------------------------------------------------
+#define LM_MB_NT_R 32
+
+__global__ void __launch_bounds__(1024) lm_k_mb_nt(const long long* __restrict__ frame_cc_off, int f0, int B, int32_t* __restrict__ active,
+                                                   int32_t* __restrict__ active_cc, unsigned long long* __restrict__ active_box,
+                                                   int32_t* __restrict__ active_last, LmCounters* __restrict__ cnt, LmMatchBatch mb, int max_gap)
+{
+    __shared__ unsigned s_tab[LM_MB_NT_R * 16];
+    __shared__ unsigned s_tot;
+    if (cnt->error) return;
+    lm_mb_prologue(frame_cc_off, f0, B, active, active_cc, active_box, active_last, cnt, mb, max_gap);
+    const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
+    const int lane = lm_lane(), wid = (int)(threadIdx.x >> 6);
+    unsigned carry = 0;
+    for (long long base = C0; base < C1; base += 1024 * LM_MB_NT_R) {
+        unsigned fm = 0;
+#pragma unroll
+        for (int k = 0; k < LM_MB_NT_R; k++) {
+            const long long i = base + (long long)k * 1024 + threadIdx.x;
+            const int flag = (i < C1) ? (mb.twin[i] == 0) : 0;
+            fm |= (unsigned)flag << k;
+            const unsigned long long bal = __ballot(flag);
+            if (lane == 0) s_tab[k * 16 + wid] = (unsigned)__popcll(bal);
+        }
+        __syncthreads();
+        if (wid == 0) {     // exclusive scan of the 512 (row, wave) counts: 8 per lane
+            unsigned loc[8], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { loc[j] = s_tab[lane * 8 + j]; sum += loc[j]; }
+            const unsigned incl = lm_wave_incl_scan(sum);
+            unsigned run = incl - sum;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { s_tab[lane * 8 + j] = run; run += loc[j]; }
+            if (lane == 63) s_tot = incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LM_MB_NT_R; k++) {
+            const int flag = (int)((fm >> k) & 1u);
+            const unsigned long long bal = __ballot(flag);
+            const long long i = base + (long long)k * 1024 + threadIdx.x;
+            if (i < C1) {
+                const unsigned o = carry + s_tab[k * 16 + wid] + (unsigned)__popcll(bal & lm_lowmask_excl(lane));
+                mb.tkey[i] = o;                                 // non-twins before this CC (the hash keys are not needed any more)
+                if (flag) { mb.nt_list[o] = (int32_t)i; mb.cls[i] = (int32_t)o; }
+            }
+        }
+        carry += s_tot;
+        __syncthreads();
+    }
+    // per frame: first non-twin, tiles of non-twins, tiles of all CCs
+    const int b = threadIdx.x;
+    unsigned tiles_nt = 0, tiles_all = 0;
+    if (b <= B) {
+        const long long i = frame_cc_off[f0 + b];
+        mb.nt_foff[b] = (i < C1) ? (int32_t)mb.tkey[i] : (int32_t)carry;
+    }
+    __syncthreads();
+    if (b < B) {
+        tiles_nt = (unsigned)((mb.nt_foff[b + 1] - mb.nt_foff[b] + LM_MB_TILE - 1) / LM_MB_TILE);
+        tiles_all = (unsigned)((frame_cc_off[f0 + b + 1] - frame_cc_off[f0 + b] + LM_MB_TILE - 1) / LM_MB_TILE);
+    }
+    unsigned nt, nta;
+    const unsigned ex = lm_block_excl_scan<1024>(tiles_nt, &nt);
+    const unsigned exa = lm_block_excl_scan<1024>(tiles_all, &nta);
+    if (b < B) { mb.ftile[b] = (int32_t)ex; mb.ftile_all[b] = (int32_t)exa; }
+    if (b == 0) {
+        mb.ftile[B] = (int32_t)nt;
+        mb.ftile_all[B] = (int32_t)nta;
+        if ((int)nt > mb.cap_tiles || (int)nta > mb.cap_tiles) cnt->error = LM_ERR_CAPACITY;
+    }
+    if ((int)nt > mb.cap_tiles) return;
+    for (unsigned t = threadIdx.x; t <= nt; t += 1024) { mb.tcount[0][t] = 0; mb.tcount[1][t] = 0; mb.tcur[0][t] = 0; mb.tcur[1][t] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -142,7 +223,7 @@ __global__ void __launch_bounds__(256) lm_k_mb_join(const LmCcRec* __restrict__ 
     __shared__ int s_spos[LM_MB_CHUNK];
     __shared__ int s_ub[4];
     __shared__ int s_nsurv;
-    __shared__ unsigned s_count;
+    __shared__ unsigned s_count, s_base;
     if (cnt->error) return;
     const int nt = mb.ftile[B];
     const unsigned long long* src_box = SRC == 0 ? active_box : mb.s_box;
@@ -151,15 +232,17 @@ __global__ void __launch_bounds__(256) lm_k_mb_join(const LmCcRec* __restrict__ 
     const int ccl = (int)(threadIdx.x & 63), q = (int)(threadIdx.x >> 6);
     for (int t = blockIdx.x; t < nt; t += gridDim.x) {
         const int b = lm_mb_tile_frame(mb.ftile, B, t);
-        const int n_src = SRC == 0 ? cnt->n_active : mb.s_prefix[b];
-        const long long cf0 = frame_cc_off[f0 + b], cf1 = frame_cc_off[f0 + b + 1];
-        const long long c_first = cf0 + (long long)(t - mb.ftile[b]) * LM_MB_TILE;
-        const int ncc = (cf1 - c_first < LM_MB_TILE) ? (int)(cf1 - c_first) : LM_MB_TILE;
+        const int n_all = SRC == 0 ? cnt->n_active : mb.s_prefix[b];
+        // this workgroup's share of the sources: tiles of non-twins are few and scattered over the frame, so the work of one
+        // tile is spread over gridDim.y workgroups (one counter update / one slot reservation per workgroup)
+        const int s_lo = (int)((long long)n_all * blockIdx.y / gridDim.y), s_hi = (int)((long long)n_all * (blockIdx.y + 1) / gridDim.y);
+        const int k_first = mb.nt_foff[b] + (t - mb.ftile[b]) * LM_MB_TILE;          // first entry of nt_list in this tile
+        const int ncc = (mb.nt_foff[b + 1] - k_first < LM_MB_TILE) ? mb.nt_foff[b + 1] - k_first : LM_MB_TILE;
         __syncthreads();        // previous tile done with the shared scalars
         if (threadIdx.x == 0) { s_ub[0] = 0x7fff; s_ub[1] = -1; s_ub[2] = 0x7fff; s_ub[3] = -1; s_count = 0; }
         unsigned off = 0;
         if (FILL) {
-            // exclusive prefix of the tile counts, recomputed by the owner (a few hundred tiles per batch)
+            // exclusive prefix of the tile counts, recomputed by every owner (a few hundred tiles per batch at most)
             unsigned part = 0;
             for (int i = threadIdx.x; i < t; i += 256) part += mb.tcount[SRC][i];
             unsigned tot;
@@ -169,8 +252,9 @@ __global__ void __launch_bounds__(256) lm_k_mb_join(const LmCcRec* __restrict__ 
         __syncthreads();
         unsigned long long mybox = 0;
         const bool have = ccl < ncc;
+        const long long my_cc = have ? (long long)mb.nt_list[k_first + ccl] : 0;
         if (have) {
-            const LmCcRec r = cc[c_first + ccl];
+            const LmCcRec r = cc[my_cc];
             mybox = lm_pack_box(r);
             if (q == 0) {
                 atomicMin(&s_ub[0], (int)r.min_x); atomicMax(&s_ub[1], (int)r.max_x);
@@ -181,56 +265,63 @@ __global__ void __launch_bounds__(256) lm_k_mb_join(const LmCcRec* __restrict__ 
         const unsigned long long ubox = (unsigned long long)(unsigned short)s_ub[0] | ((unsigned long long)(unsigned short)s_ub[1] << 16) |
                                         ((unsigned long long)(unsigned short)s_ub[2] << 32) | ((unsigned long long)(unsigned short)s_ub[3] << 48);
         const unsigned tc = FILL ? mb.tcount[SRC][t] : 0u;
-        if (FILL && threadIdx.x == 0) {
+        if (FILL && threadIdx.x == 0 && blockIdx.y == 0) {
             if ((unsigned long long)off + tc > mb.cap_pairs) cnt->error = LM_ERR_CAPACITY;
             mb.toff[SRC][t] = off;
             if (t == nt - 1) mb.toff[SRC][nt] = off + tc;
         }
         const bool room = !FILL || (unsigned long long)off + tc <= mb.cap_pairs;
-        unsigned mycount = 0;
-        for (int base = 0; base < n_src; base += LM_MB_CHUNK) {
-            __syncthreads();
-            if (threadIdx.x == 0) s_nsurv = 0;
-            __syncthreads();
+        // FILL runs the hit loop twice: pass 0 counts this workgroup's hits (to reserve its slots with one atomic), pass 1 writes
+        for (int pass = FILL ? 0 : 1; pass < 2; pass++) {
+            unsigned mycount = 0;
+            for (int base = s_lo; base < s_hi; base += LM_MB_CHUNK) {
+                __syncthreads();
+                if (threadIdx.x == 0) s_nsurv = 0;
+                __syncthreads();
 #pragma unroll 4
-            for (int k = 0; k < LM_MB_CHUNK / 256; k++) {
-                const int i = base + k * 256 + (int)threadIdx.x;
-                if (i < n_src) {
-                    const unsigned long long sb = src_box[i];
-                    if (lm_box_hit_packed(ubox, sb)) {
-                        const int slot = atomicAdd(&s_nsurv, 1);
-                        s_sbox[slot] = sb;
-                        s_spos[slot] = i;
-                    }
-                }
-            }
-            __syncthreads();
-            const int ns = s_nsurv;
-            // the wave's trip count is uniform (q and ns are), so the hits of one trip can share one LDS slot allocation
-            for (int j = q; j < ns; j += 4) {
-                const bool hit = have && lm_box_hit_packed(mybox, s_sbox[j]);
-                if (FILL) {
-                    const unsigned long long bal = __ballot(hit);
-                    if (bal) {
-                        unsigned basep = 0;
-                        if (lm_lane() == 0) basep = atomicAdd(&s_count, (unsigned)__popcll(bal));
-                        basep = (unsigned)__shfl((int)basep, 0);
-                        if (hit && room) {
-                            const unsigned slot = off + basep + (unsigned)__popcll(bal & lm_lowmask_excl(lm_lane()));
-                            const int pos = s_spos[j];
-                            mb.pairs[SRC][slot] = make_uint2((unsigned)(c_first + ccl - C0), (unsigned)pos);
-                            mb.pair_u[SRC][slot] = src_cc[pos];
+                for (int k = 0; k < LM_MB_CHUNK / 256; k++) {
+                    const int i = base + k * 256 + (int)threadIdx.x;
+                    if (i < s_hi) {
+                        const unsigned long long sb = src_box[i];
+                        if (lm_box_hit_packed(ubox, sb)) {
+                            const int slot = atomicAdd(&s_nsurv, 1);
+                            s_sbox[slot] = sb;
+                            s_spos[slot] = i;
                         }
                     }
-                } else {
-                    mycount += hit ? 1u : 0u;
+                }
+                __syncthreads();
+                const int ns = s_nsurv;
+                // the wave's trip count is uniform (q and ns are), so the hits of one trip can share one LDS slot allocation
+                for (int j = q; j < ns; j += 4) {
+                    const bool hit = have && lm_box_hit_packed(mybox, s_sbox[j]);
+                    if (FILL && pass == 1) {
+                        const unsigned long long bal = __ballot(hit);
+                        if (bal) {
+                            unsigned basep = 0;
+                            if (lm_lane() == 0) basep = atomicAdd(&s_count, (unsigned)__popcll(bal));
+                            basep = (unsigned)__shfl((int)basep, 0);
+                            if (hit && room) {
+                                const unsigned slot = off + s_base + basep + (unsigned)__popcll(bal & lm_lowmask_excl(lm_lane()));
+                                const int pos = s_spos[j];
+                                mb.pairs[SRC][slot] = make_uint2((unsigned)(my_cc - C0), (unsigned)pos);
+                                mb.pair_u[SRC][slot] = src_cc[pos];
+                            }
+                        }
+                    } else {
+                        mycount += hit ? 1u : 0u;
+                    }
                 }
             }
-        }
-        if (!FILL) {
-            if (mycount) atomicAdd(&s_count, mycount);
-            __syncthreads();
-            if (threadIdx.x == 0) mb.tcount[SRC][t] = s_count;
+            if (!(FILL && pass == 1)) {
+                if (mycount) atomicAdd(&s_count, mycount);
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    if (!FILL) { if (s_count) atomicAdd(&mb.tcount[SRC][t], s_count); }
+                    else { s_base = s_count ? atomicAdd(&mb.tcur[SRC][t], s_count) : 0u; s_count = 0; }
+                }
+                __syncthreads();
+            }
         }
     }
 }
@@ -248,6 +339,13 @@ __global__ void __launch_bounds__(256) lm_k_mb_eval(const LmCcRec* __restrict__ 
     const int nt = mb.ftile[B];
     const unsigned total = nt > 0 ? mb.toff[SRC][nt] : 0u;
     const long long C0 = frame_cc_off[f0];
+    if (SRC == 0) {
+        // side job of the first evaluation pass (a wide launch that does not read cls): twins refer to their root's index in
+        // nt_list (roots are non-twins, their cls was written by lm_k_mb_nt)
+        const long long C1 = frame_cc_off[f0 + B];
+        for (long long i = C0 + (long long)blockIdx.x * 256 + threadIdx.x; i < C1; i += (long long)gridDim.x * 256)
+            if (mb.twin[i]) mb.cls[i] = -1 - mb.cls[mb.troot[i]];
+    }
     const int sub = (int)(threadIdx.x & 7);
     const unsigned grp = (blockIdx.x * 256u + threadIdx.x) >> 3, ngrp = (gridDim.x * 256u) >> 3;
     const unsigned rounds = (total + ngrp - 1) / ngrp;      // whole waves stay in the loop for the shuffles
@@ -341,6 +439,7 @@ __global__ void __launch_bounds__(256) lm_k_mb_twin_find(const LmCcRec* __restri
         const long long i = it * ngrp + grp;
         const bool live = i < n;
         int diff = 1;       // 0 after a complete, equal comparison
+        long long root_keep = -1;
         if (live && enabled) {
             const unsigned key = mb.tkey[C0 + i];
             long long root = -1;
@@ -349,6 +448,7 @@ __global__ void __launch_bounds__(256) lm_k_mb_twin_find(const LmCcRec* __restri
                 if (e == ~0ull) break;
                 if ((unsigned)(e >> 32) == key) { root = (long long)(unsigned)e; break; }
             }
+            root_keep = root;
             if (root >= 0 && root < i) {
                 const LmCcRec r = cc[C0 + i], q = cc[C0 + root];
                 if (r.size == q.size && r.min_x == q.min_x && r.max_x == q.max_x && r.min_y == q.min_y && r.max_y == q.max_y &&
@@ -361,15 +461,15 @@ __global__ void __launch_bounds__(256) lm_k_mb_twin_find(const LmCcRec* __restri
         }
 #pragma unroll
         for (int d = 4; d >= 1; d >>= 1) diff |= __shfl_xor(diff, d, 8);
-        if (live && sub == 0) mb.twin[C0 + i] = diff ? 0 : 1;
+        if (live && sub == 0) { mb.twin[C0 + i] = diff ? 0 : 1; mb.troot[C0 + i] = diff ? -1 : (int32_t)(C0 + root_keep); }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// S: compact the CCs that are not surely matched.  One block; 32 CCs per thread and pass, all loads of a pass in flight
-// together, positions from per-wave ballots.
+// S: compact the non-twin CCs that are not surely matched.  One block over nt_list; LM_MB_SRC_R entries per thread and pass,
+// all loads of a pass in flight together, positions from per-wave ballots.
 // ------------------------------------------------------------------------------------------------
-#define LM_MB_SRC_R 32
+#define LM_MB_SRC_R 8
 
 __global__ void __launch_bounds__(1024) lm_k_mb_sources(const LmCcRec* __restrict__ cc, const long long* __restrict__ frame_cc_off,
                                                         int f0, int B, LmCounters* __restrict__ cnt, LmMatchBatch mb)
@@ -377,16 +477,18 @@ __global__ void __launch_bounds__(1024) lm_k_mb_sources(const LmCcRec* __restric
     __shared__ unsigned s_tab[LM_MB_SRC_R * 16];
     __shared__ unsigned s_tot;
     if (cnt->error) return;
-    const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
+    const int nNT = mb.nt_foff[B];
     const int lane = lm_lane(), wid = (int)(threadIdx.x >> 6);
     unsigned carry = 0;
-    for (long long base = C0; base < C1; base += 1024 * LM_MB_SRC_R) {
-        int v[LM_MB_SRC_R];
+    for (int base = 0; base < nNT; base += 1024 * LM_MB_SRC_R) {
+        int ci[LM_MB_SRC_R], v[LM_MB_SRC_R];
 #pragma unroll
         for (int k = 0; k < LM_MB_SRC_R; k++) {
-            const long long i = base + (long long)k * 1024 + threadIdx.x;
-            v[k] = (i < C1 && !mb.twin[i]) ? mb.sidx[i] : 0;
+            const int e = base + k * 1024 + (int)threadIdx.x;
+            ci[k] = (e < nNT) ? mb.nt_list[e] : -1;
         }
+#pragma unroll
+        for (int k = 0; k < LM_MB_SRC_R; k++) v[k] = (ci[k] >= 0) ? mb.sidx[ci[k]] : 0;
         unsigned fm = 0;
 #pragma unroll
         for (int k = 0; k < LM_MB_SRC_R; k++) {
@@ -396,14 +498,15 @@ __global__ void __launch_bounds__(1024) lm_k_mb_sources(const LmCcRec* __restric
             if (lane == 0) s_tab[k * 16 + wid] = (unsigned)__popcll(bal);
         }
         __syncthreads();
-        if (wid == 0) {     // exclusive scan of the 512 (pass-row, wave) counts: 8 per lane
-            unsigned loc[8], sum = 0;
+        if (wid == 0) {     // exclusive scan of the (row, wave) counts: LM_MB_SRC_R * 16 / 64 per lane
+            constexpr int PER = LM_MB_SRC_R * 16 / 64;
+            unsigned loc[PER], sum = 0;
 #pragma unroll
-            for (int j = 0; j < 8; j++) { loc[j] = s_tab[lane * 8 + j]; sum += loc[j]; }
+            for (int j = 0; j < PER; j++) { loc[j] = s_tab[lane * PER + j]; sum += loc[j]; }
             const unsigned incl = lm_wave_incl_scan(sum);
             unsigned run = incl - sum;
 #pragma unroll
-            for (int j = 0; j < 8; j++) { s_tab[lane * 8 + j] = run; run += loc[j]; }
+            for (int j = 0; j < PER; j++) { s_tab[lane * PER + j] = run; run += loc[j]; }
             if (lane == 63) s_tot = incl;
         }
         __syncthreads();
@@ -411,16 +514,15 @@ __global__ void __launch_bounds__(1024) lm_k_mb_sources(const LmCcRec* __restric
         for (int k = 0; k < LM_MB_SRC_R; k++) {
             const int flag = (int)((fm >> k) & 1u);
             const unsigned long long bal = __ballot(flag);
-            const long long i = base + (long long)k * 1024 + threadIdx.x;
-            if (i < C1) {
+            const int e = base + k * 1024 + (int)threadIdx.x;
+            if (e < nNT) {
                 const unsigned o = carry + s_tab[k * 16 + wid] + (unsigned)__popcll(bal & lm_lowmask_excl(lane));
+                mb.rootpos[e] = (int32_t)o;         // sources before non-twin e (rootpos is free until the replay)
                 if (flag) {
-                    mb.sidx[i] = (int32_t)o;
-                    mb.s_list[o] = (int32_t)i;
-                    mb.s_box[o] = lm_pack_box(cc[i]);
+                    mb.sidx[ci[k]] = (int32_t)o;
+                    mb.s_list[o] = ci[k];
+                    mb.s_box[o] = lm_pack_box(cc[ci[k]]);
                     mb.newpos[o] = -1;
-                } else {
-                    mb.sidx[i] = -1 - (int32_t)o;
                 }
             }
         }
@@ -428,12 +530,10 @@ __global__ void __launch_bounds__(1024) lm_k_mb_sources(const LmCcRec* __restric
         __syncthreads();
     }
     if (threadIdx.x == 0) *mb.n_src = (int)carry;
-    // sources that belong to frames before frame b: the count in front of the frame's first CC
+    // sources that belong to frames before frame b: the count in front of the frame's first non-twin
     if ((int)threadIdx.x <= B) {
-        const long long i = frame_cc_off[f0 + threadIdx.x];
-        int pfx = (int)carry;
-        if (i < C1) { const int sv = mb.sidx[i]; pfx = sv >= 0 ? sv : -1 - sv; }
-        mb.s_prefix[threadIdx.x] = pfx;
+        const int e = mb.nt_foff[threadIdx.x];
+        mb.s_prefix[threadIdx.x] = (e < nNT) ? mb.rootpos[e] : (int)carry;
     }
 }
 
@@ -443,143 +543,154 @@ __global__ void __launch_bounds__(1024) lm_k_mb_sources(const LmCcRec* __restric
 // indices of its CCs) are fetched into registers while the previous frame is being decided.  Global state is written
 // through as the replay goes (positions / sources beyond the LDS tables fall back to it).
 // ------------------------------------------------------------------------------------------------
-#define LM_MB_ITEMS (LM_MB_CH / 1024)
+#define LM_MB_RT 1024           // threads of the replay workgroup (512 was measured slower: 144 vs 113 us per batch)
+#define LM_MB_ITEMS (LM_MB_CH / LM_MB_RT)
 
 LM_DEV void lm_mb_prefetch(const LmMatchBatch& mb, unsigned pA0, unsigned pA1, unsigned pB0, unsigned pB1, long long c_abs0, int n,
-                           uint2 (&ra)[LM_MB_PFA], uint2 (&rb)[LM_MB_PFB], int (&rs)[LM_MB_ITEMS])
+                           uint2 (&ra)[LM_MB_PFA], uint2 (&rb)[LM_MB_PFB], int (&rs)[LM_MB_ITEMS], int (&rc)[LM_MB_ITEMS])
 {
 #pragma unroll
     for (int k = 0; k < LM_MB_PFA; k++) {
-        const unsigned pa = pA0 + (unsigned)k * 1024u + threadIdx.x;
+        const unsigned pa = pA0 + (unsigned)k * (unsigned)LM_MB_RT + threadIdx.x;
         ra[k] = (pa < pA1) ? mb.pairs[0][pa] : make_uint2(0u, 0xffffffffu);
     }
 #pragma unroll
     for (int k = 0; k < LM_MB_PFB; k++) {
-        const unsigned pb = pB0 + (unsigned)k * 1024u + threadIdx.x;
+        const unsigned pb = pB0 + (unsigned)k * (unsigned)LM_MB_RT + threadIdx.x;
         rb[k] = (pb < pB1) ? mb.pairs[1][pb] : make_uint2(0u, 0xffffffffu);
     }
 #pragma unroll
     for (int k = 0; k < LM_MB_ITEMS; k++) {
         const int i = (int)threadIdx.x * LM_MB_ITEMS + k;
-        rs[k] = (i < n && n <= LM_MB_CH) ? mb.sidx[c_abs0 + i] : -1;
+        const bool on = i < n && n <= LM_MB_CH;
+        rs[k] = on ? mb.sidx[c_abs0 + i] : -1;
+        rc[k] = on ? mb.cls[c_abs0 + i] : 0;
     }
 }
 
-LM_DEV void lm_mb_pair_old(uint2 pr, int f, int max_gap, unsigned rel0, unsigned* s_best, const int* s_last,
-                           const int32_t* __restrict__ active_last, unsigned& tempo)
+// Only accepted pairs matter to the replay (tempo_count is computed by lm_k_mb_tempo).  idx >= nch: a CC of another LDS pass
+// of this frame (frames with more than LM_MB_CH CCs scan their pair lists once per pass).
+LM_DEV void lm_mb_pair_old(uint2 pr, int f, int max_gap, unsigned rel0, unsigned nch, unsigned* s_best, const int* s_last,
+                           const int32_t* __restrict__ active_last)
 {
+    if (!(pr.x >> 31)) return;
+    const unsigned idx = (pr.x & 0x7fffffffu) - rel0;
+    if (idx >= nch) return;
     const int last = pr.y < LM_MB_LA ? s_last[pr.y] : active_last[pr.y];
-    if (lm_mb_alive(f, last, max_gap)) {
-        tempo++;
-        if (pr.x >> 31) atomicMin(&s_best[(pr.x & 0x7fffffffu) - rel0], pr.y);
-    }
+    if (lm_mb_alive(f, last, max_gap)) atomicMin(&s_best[idx], pr.y);
 }
 
-LM_DEV void lm_mb_pair_new(uint2 pr, int f, int max_gap, unsigned rel0, unsigned* s_best, const int* s_last, const int* s_newpos,
-                           const int32_t* __restrict__ active_last, const int32_t* __restrict__ newpos, unsigned& tempo)
+LM_DEV void lm_mb_pair_new(uint2 pr, int f, int max_gap, unsigned rel0, unsigned nch, unsigned* s_best, const int* s_last, const int* s_newpos,
+                           const int32_t* __restrict__ active_last, const int32_t* __restrict__ newpos)
 {
+    if (!(pr.x >> 31)) return;
+    const unsigned idx = (pr.x & 0x7fffffffu) - rel0;
+    if (idx >= nch) return;
     const int pos = pr.y < LM_MB_LS ? s_newpos[pr.y] : newpos[pr.y];
     if (pos < 0) return;        // that source never became a unique
     const int last = pos < LM_MB_LA ? s_last[pos] : active_last[pos];
-    if (lm_mb_alive(f, last, max_gap)) {
-        tempo++;
-        if (pr.x >> 31) atomicMin(&s_best[(pr.x & 0x7fffffffu) - rel0], (unsigned)pos);
-    }
+    if (lm_mb_alive(f, last, max_gap)) atomicMin(&s_best[idx], (unsigned)pos);
 }
 
-__global__ void __launch_bounds__(1024) lm_k_mb_resolve(const LmCcRec* __restrict__ cc, const long long* __restrict__ frame_cc_off,
+__global__ void __launch_bounds__(LM_MB_RT) lm_k_mb_resolve(const LmCcRec* __restrict__ cc, const long long* __restrict__ frame_cc_off,
                                                         int f0, int B, int32_t* __restrict__ active, int32_t* __restrict__ active_cc,
                                                         unsigned long long* __restrict__ active_box, int32_t* __restrict__ active_last,
                                                         LmCounters* __restrict__ cnt, int32_t* __restrict__ assign, LmMatchBatch mb,
                                                         int max_gap, int cap_uniq)
 {
     LM_DYN_SMEM(smem);
-    unsigned* s_best = (unsigned*)smem;                 // [LM_MB_CH]
-    int* s_last = (int*)(smem + (size_t)LM_MB_CH * 4);  // [LM_MB_LA]
+    unsigned* s_best2 = (unsigned*)smem;                // [2][LM_MB_CH], double-buffered: the next step's buffer is reset while this one is decided
+    int* s_last = (int*)(smem + (size_t)LM_MB_CH * 8);  // [LM_MB_LA]
     int* s_newpos = s_last + LM_MB_LA;                  // [LM_MB_LS]
+    int* s_rootpos = s_newpos + LM_MB_LS;               // [LM_MB_RP] active position decided for non-twin k
     __shared__ int s_c0[LM_MB_MAX_FRAMES + 1];
     __shared__ unsigned s_tA[LM_MB_MAX_FRAMES + 1], s_tB[LM_MB_MAX_FRAMES + 1];
     __shared__ int s_fail;
-    __shared__ unsigned s_wsum[16];
-    __shared__ unsigned long long s_tempo;
+    __shared__ unsigned s_wsum[LM_MB_RT / 64];
     if (cnt->error) return;
     const int nt = mb.ftile[B];
     const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
     const int nA0 = cnt->n_active;
     const int nS = *mb.n_src;
+    const int nNT = mb.nt_foff[B];
     int nA = nA0;
     int nU = cnt->n_uniq;
-    unsigned tempo = 0;
-    // every position / source the replay can touch is covered by the LDS tables: the loop then never re-reads global memory
-    // it wrote, and its barriers only need to order LDS (prefetch loads and write-through stores stay in flight)
-    const bool lds_only = (long long)nA0 + nS <= LM_MB_LA && nS <= LM_MB_LS;
-    if (threadIdx.x == 0) { s_fail = 0; s_tempo = 0; }
+    // every position / source / non-twin the replay can touch is covered by the LDS tables: the loop then never re-reads global
+    // memory it wrote, and its barriers only need to order LDS (prefetch loads and write-through stores stay in flight)
+    const bool lds_only = (long long)nA0 + nS <= LM_MB_LA && nS <= LM_MB_LS && nNT <= LM_MB_RP;
+    if (threadIdx.x == 0) s_fail = 0;
     if ((int)threadIdx.x <= B) {
         s_c0[threadIdx.x] = (int)(frame_cc_off[f0 + threadIdx.x] - C0);
         const int t = mb.ftile[threadIdx.x];
         s_tA[threadIdx.x] = nt > 0 ? mb.toff[0][t] : 0u;
         s_tB[threadIdx.x] = nt > 0 ? mb.toff[1][t] : 0u;
     }
-    for (int i = threadIdx.x; i < nA0 && i < LM_MB_LA; i += 1024) s_last[i] = active_last[i];
-    for (int k = threadIdx.x; k < nS && k < LM_MB_LS; k += 1024) s_newpos[k] = -1;
+    for (int i = threadIdx.x; i < nA0 && i < LM_MB_LA; i += LM_MB_RT) s_last[i] = active_last[i];
+    for (int k = threadIdx.x; k < nS && k < LM_MB_LS; k += LM_MB_RT) s_newpos[k] = -1;
+    for (int i = threadIdx.x; i < 2 * LM_MB_CH; i += LM_MB_RT) s_best2[i] = 0xffffffffu;
+    int bb = 0;
     __syncthreads();
     uint2 ra[LM_MB_PFA], rb[LM_MB_PFB];
-    int rs[LM_MB_ITEMS];
-    lm_mb_prefetch(mb, s_tA[0], s_tA[1], s_tB[0], s_tB[1], C0 + s_c0[0], s_c0[1] - s_c0[0], ra, rb, rs);
+    int rs[LM_MB_ITEMS], rc[LM_MB_ITEMS];
+    lm_mb_prefetch(mb, s_tA[0], s_tA[1], s_tB[0], s_tB[1], C0 + s_c0[0], s_c0[1] - s_c0[0], ra, rb, rs, rc);
 
     for (int b = 0; b < B; b++) {
         const int f = f0 + b;
         const int n = s_c0[b + 1] - s_c0[b];
         const long long c0 = C0 + s_c0[b];
-        const int t0 = mb.ftile[b];
         const bool single = n <= LM_MB_CH;
+        const unsigned pA0 = s_tA[b], pA1 = s_tA[b + 1], pB0 = s_tB[b], pB1 = s_tB[b + 1];     // the frame's pair lists
         for (int cb = 0; cb < n || cb == 0; cb += LM_MB_CH) {
             const int nch = (n - cb < LM_MB_CH) ? n - cb : LM_MB_CH;
             const unsigned rel0 = (unsigned)s_c0[b] + (unsigned)cb;
-            unsigned pA0, pA1, pB0, pB1;
-            if (single) {
-                pA0 = s_tA[b]; pA1 = s_tA[b + 1]; pB0 = s_tB[b]; pB1 = s_tB[b + 1];
-            } else {        // a frame with more CCs than one LDS pass: tile-aligned sub-ranges, everything from global
-                const int ta = t0 + cb / LM_MB_TILE;
-                const int tb = (t0 + (cb + LM_MB_CH) / LM_MB_TILE < mb.ftile[b + 1]) ? t0 + (cb + LM_MB_CH) / LM_MB_TILE : mb.ftile[b + 1];
-                pA0 = mb.toff[0][ta]; pA1 = mb.toff[0][tb]; pB0 = mb.toff[1][ta]; pB1 = mb.toff[1][tb];
-            }
-            for (int i = threadIdx.x; i < nch; i += 1024) s_best[i] = 0xffffffffu;
-            if (lds_only) lm_lds_barrier(); else __syncthreads();
-            // ---- pairs against uniques that existed before the batch / born inside it
+            unsigned* s_best = s_best2 + bb * LM_MB_CH;
+            // ---- accepted pairs against uniques that existed before the batch / were born inside it
             if (single) {
 #pragma unroll
                 for (int k = 0; k < LM_MB_PFA; k++)
-                    if (ra[k].y != 0xffffffffu) lm_mb_pair_old(ra[k], f, max_gap, rel0, s_best, s_last, active_last, tempo);
+                    if (ra[k].y != 0xffffffffu) lm_mb_pair_old(ra[k], f, max_gap, rel0, (unsigned)nch, s_best, s_last, active_last);
 #pragma unroll
                 for (int k = 0; k < LM_MB_PFB; k++)
-                    if (rb[k].y != 0xffffffffu) lm_mb_pair_new(rb[k], f, max_gap, rel0, s_best, s_last, s_newpos, active_last, mb.newpos, tempo);
+                    if (rb[k].y != 0xffffffffu) lm_mb_pair_new(rb[k], f, max_gap, rel0, (unsigned)nch, s_best, s_last, s_newpos, active_last, mb.newpos);
             }
-            for (unsigned p = pA0 + (single ? (unsigned)LM_MB_PFA * 1024u : 0u) + threadIdx.x; p < pA1; p += 1024)
-                lm_mb_pair_old(mb.pairs[0][p], f, max_gap, rel0, s_best, s_last, active_last, tempo);
-            for (unsigned p = pB0 + (single ? (unsigned)LM_MB_PFB * 1024u : 0u) + threadIdx.x; p < pB1; p += 1024)
-                lm_mb_pair_new(mb.pairs[1][p], f, max_gap, rel0, s_best, s_last, s_newpos, active_last, mb.newpos, tempo);
-            int cur_s[LM_MB_ITEMS];
+            for (unsigned p = pA0 + (single ? (unsigned)LM_MB_PFA * (unsigned)LM_MB_RT : 0u) + threadIdx.x; p < pA1; p += LM_MB_RT)
+                lm_mb_pair_old(mb.pairs[0][p], f, max_gap, rel0, (unsigned)nch, s_best, s_last, active_last);
+            for (unsigned p = pB0 + (single ? (unsigned)LM_MB_PFB * (unsigned)LM_MB_RT : 0u) + threadIdx.x; p < pB1; p += LM_MB_RT)
+                lm_mb_pair_new(mb.pairs[1][p], f, max_gap, rel0, (unsigned)nch, s_best, s_last, s_newpos, active_last, mb.newpos);
+            int cur_s[LM_MB_ITEMS], cur_c[LM_MB_ITEMS];
 #pragma unroll
             for (int k = 0; k < LM_MB_ITEMS; k++) {
                 const int i = (int)threadIdx.x * LM_MB_ITEMS + k;
                 cur_s[k] = single ? rs[k] : (i < nch ? mb.sidx[c0 + cb + i] : -1);
+                cur_c[k] = single ? rc[k] : (i < nch ? mb.cls[c0 + cb + i] : 0);
             }
             if (cb + LM_MB_CH >= n && b + 1 < B)        // next frame's lists: in flight while this one is decided
-                lm_mb_prefetch(mb, s_tA[b + 1], s_tA[b + 2], s_tB[b + 1], s_tB[b + 2], C0 + s_c0[b + 1], s_c0[b + 2] - s_c0[b + 1], ra, rb, rs);
+                lm_mb_prefetch(mb, s_tA[b + 1], s_tA[b + 2], s_tB[b + 1], s_tB[b + 2], C0 + s_c0[b + 1], s_c0[b + 2] - s_c0[b + 1], ra, rb, rs, rc);
             if (lds_only) lm_lds_barrier(); else __syncthreads();
-            // ---- decisions; matched CCs keep the active POSITION for now (-2 - pos), translated after the replay
+            for (int i = threadIdx.x; i < LM_MB_CH; i += LM_MB_RT) s_best2[(bb ^ 1) * LM_MB_CH + i] = 0xffffffffu;     // for the next step
+            // ---- decisions; matched CCs keep the active POSITION for now (-2 - pos), translated after the replay.
+            // A twin takes its root's position (decided in an earlier frame) and refreshes that unique's last match.
             unsigned isnew[LM_MB_ITEMS], mine = 0;
 #pragma unroll
             for (int k = 0; k < LM_MB_ITEMS; k++) {
                 const int i = (int)threadIdx.x * LM_MB_ITEMS + k;
                 isnew[k] = 0;
                 if (i < nch) {
-                    const unsigned best = s_best[i];
+                    unsigned best;
+                    if (cur_c[k] < 0) {
+                        const int rk = -1 - cur_c[k];
+                        best = (unsigned)(rk < LM_MB_RP ? s_rootpos[rk] : mb.rootpos[rk]);
+                    } else {
+                        best = s_best[i];
+                    }
                     if (best != 0xffffffffu) {
                         assign[c0 + cb + i] = -2 - (int32_t)best;
                         if (best < LM_MB_LA) s_last[best] = f;      // several CCs may hit the same unique: same value
                         active_last[best] = f;
+                        if (cur_c[k] >= 0) {
+                            if (cur_c[k] < LM_MB_RP) s_rootpos[cur_c[k]] = (int)best;
+                            mb.rootpos[cur_c[k]] = (int32_t)best;
+                        }
                     } else {
                         isnew[k] = 1;
                     }
@@ -593,7 +704,7 @@ __global__ void __launch_bounds__(1024) lm_k_mb_resolve(const LmCcRec* __restric
             if (lds_only) lm_lds_barrier(); else __syncthreads();
             unsigned tot = 0, before = 0;
 #pragma unroll
-            for (int w = 0; w < 16; w++) {
+            for (int w = 0; w < LM_MB_RT / 64; w++) {
                 const unsigned t = s_wsum[w];
                 before += (w < (int)(threadIdx.x >> 6)) ? t : 0u;
                 tot += t;
@@ -605,7 +716,7 @@ __global__ void __launch_bounds__(1024) lm_k_mb_resolve(const LmCcRec* __restric
                 const long long ci = c0 + cb + (long long)threadIdx.x * LM_MB_ITEMS + k;
                 const long long idx = (long long)nU + o;
                 const int src = cur_s[k];
-                if (idx < cap_uniq && src >= 0) {
+                if (idx < cap_uniq && src >= 0 && cur_c[k] >= 0) {
                     const int pos = nA + (int)o;
                     assign[ci] = (int32_t)idx;
                     active[pos] = (int32_t)idx;
@@ -614,37 +725,40 @@ __global__ void __launch_bounds__(1024) lm_k_mb_resolve(const LmCcRec* __restric
                     if (pos < LM_MB_LA) s_last[pos] = f;
                     mb.newpos[src] = pos;
                     if (src < LM_MB_LS) s_newpos[src] = pos;
+                    if (cur_c[k] < LM_MB_RP) s_rootpos[cur_c[k]] = pos;
+                    mb.rootpos[cur_c[k]] = pos;
                 } else {
-                    s_fail = idx < cap_uniq ? LM_ERR_STATE : LM_ERR_CAPACITY;   // STATE: a surely matched CC found no match (bug)
+                    // STATE: a surely matched CC or a twin found no match (a bug, not an input condition)
+                    s_fail = idx < cap_uniq ? LM_ERR_STATE : LM_ERR_CAPACITY;
                 }
                 o++;
             }
             nA += (int)tot;
             nU += (int)tot;
+            bb ^= 1;
             if (lds_only) lm_lds_barrier(); else __syncthreads();
         }
     }
     __syncthreads();        // everything the replay wrote is visible to the whole block
     // ---- after the replay: positions -> unique indices, boxes of the new actives
     if (!s_fail) {
-        for (long long base = C0; base < C1; base += 1024 * 12) {     // 12 independent lookups in flight per thread
+        for (long long base = C0; base < C1; base += LM_MB_RT * 12) {     // 12 independent lookups in flight per thread
             int v[12], u[12];
 #pragma unroll
             for (int k = 0; k < 12; k++) {
-                const long long i = base + (long long)k * 1024 + threadIdx.x;
+                const long long i = base + (long long)k * LM_MB_RT + threadIdx.x;
                 v[k] = (i < C1) ? assign[i] : 0;
             }
 #pragma unroll
             for (int k = 0; k < 12; k++) u[k] = (v[k] <= -2) ? active[-2 - v[k]] : 0;
 #pragma unroll
             for (int k = 0; k < 12; k++) {
-                const long long i = base + (long long)k * 1024 + threadIdx.x;
+                const long long i = base + (long long)k * LM_MB_RT + threadIdx.x;
                 if (v[k] <= -2) assign[i] = u[k];
             }
         }
-        for (int pos = nA0 + (int)threadIdx.x; pos < nA; pos += 1024) active_box[pos] = lm_pack_box(cc[active_cc[pos]]);
+        for (int pos = nA0 + (int)threadIdx.x; pos < nA; pos += LM_MB_RT) active_box[pos] = lm_pack_box(cc[active_cc[pos]]);
     }
-    if (tempo) atomicAdd(&s_tempo, (unsigned long long)tempo);
     __syncthreads();
     if (threadIdx.x == 0) {
         if (s_fail) {
@@ -653,7 +767,82 @@ __global__ void __launch_bounds__(1024) lm_k_mb_resolve(const LmCcRec* __restric
             cnt->n_uniq = nU;
             cnt->n_active = nA;
             cnt->n_matched = f0 + B;
-            cnt->tempo_count += s_tempo;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Q: tempo_count (:85) of the batch, after the replay.  (cur CC of frame f, unique u) counts iff their boxes intersect, u
+// was born before f, and alive(f, last_u now): box join of ALL CCs (tiles of 64) against the active list as the replay
+// left it -- entries that died inside the batch are still there, entries that were dead before it were dropped by the
+// prologue.  One 64-bit atomic per workgroup.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) lm_k_mb_tempo(const LmCcRec* __restrict__ cc, const long long* __restrict__ frame_cc_off, int f0, int B,
+                                                     const unsigned long long* __restrict__ active_box, const int32_t* __restrict__ active_cc,
+                                                     const int32_t* __restrict__ active_last, LmCounters* __restrict__ cnt, LmMatchBatch mb,
+                                                     int max_gap)
+{
+    __shared__ unsigned long long s_sbox[LM_MB_CHUNK];
+    __shared__ int2 s_sinfo[LM_MB_CHUNK];               // (birth frame, last match)
+    __shared__ int s_ub[4];
+    __shared__ int s_nsurv;
+    __shared__ unsigned long long s_sum;
+    if (cnt->error) return;
+    const int nt = mb.ftile_all[B];
+    const int nA = cnt->n_active;
+    const int ccl = (int)(threadIdx.x & 63), q = (int)(threadIdx.x >> 6);
+    unsigned long long mine = 0;
+    for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+        const int b = lm_mb_tile_frame(mb.ftile_all, B, t);
+        const int f = f0 + b;
+        const long long cf1 = frame_cc_off[f + 1];
+        const long long c_first = frame_cc_off[f] + (long long)(t - mb.ftile_all[b]) * LM_MB_TILE;
+        const int ncc = (cf1 - c_first < LM_MB_TILE) ? (int)(cf1 - c_first) : LM_MB_TILE;
+        __syncthreads();
+        if (threadIdx.x == 0) { s_ub[0] = 0x7fff; s_ub[1] = -1; s_ub[2] = 0x7fff; s_ub[3] = -1; }
+        __syncthreads();
+        unsigned long long mybox = 0;
+        const bool have = ccl < ncc;
+        if (have) {
+            const LmCcRec r = cc[c_first + ccl];
+            mybox = lm_pack_box(r);
+            if (q == 0) {
+                atomicMin(&s_ub[0], (int)r.min_x); atomicMax(&s_ub[1], (int)r.max_x);
+                atomicMin(&s_ub[2], (int)r.min_y); atomicMax(&s_ub[3], (int)r.max_y);
+            }
+        }
+        __syncthreads();
+        const unsigned long long ubox = (unsigned long long)(unsigned short)s_ub[0] | ((unsigned long long)(unsigned short)s_ub[1] << 16) |
+                                        ((unsigned long long)(unsigned short)s_ub[2] << 32) | ((unsigned long long)(unsigned short)s_ub[3] << 48);
+        for (int base = 0; base < nA; base += LM_MB_CHUNK) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_nsurv = 0;
+            __syncthreads();
+#pragma unroll 4
+            for (int k = 0; k < LM_MB_CHUNK / 256; k++) {
+                const int i = base + k * 256 + (int)threadIdx.x;
+                if (i < nA) {
+                    const unsigned long long sb = active_box[i];
+                    if (lm_box_hit_packed(ubox, sb)) {
+                        const int last = active_last[i];
+                        const int born = cc[active_cc[i]].frame;
+                        if (born < f && lm_mb_alive(f, last, max_gap)) {        // the same for every CC of the tile (one frame)
+                            const int slot = atomicAdd(&s_nsurv, 1);
+                            s_sbox[slot] = sb;
+                            s_sinfo[slot] = make_int2(born, last);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const int ns = s_nsurv;
+            if (have)
+                for (int j = q; j < ns; j += 4) mine += lm_box_hit_packed(mybox, s_sbox[j]) ? 1ull : 0ull;
+        }
+    }
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+    if (mine) atomicAdd(&s_sum, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_sum) atomicAdd(&cnt->tempo_count, s_sum);
 }
