@@ -6,32 +6,31 @@
 //     function of the two bit crops alone (the unique keeps its FIRST-seen CC, :110-123) -- no stream state involved;
 //   * the state only decides WHICH uniques are candidates at frame f: those that exist (created in an earlier frame) and
 //     have not been retired (:126-145), and the first accepted one in ascending unique index wins (:84-108).
-// So the expensive part (box join + AND/popcount on the crops) runs for all B frames in wide launches, and only a cheap
-// replay of the decisions -- list lookups, no pixels -- is sequential over the frames, inside ONE workgroup:
-//   P  lm_k_mb_prologue   compact the active list (entries retired before f0), tile table (64 CCs per tile, tiles never
-//                         straddle a frame), reset per-batch tables
-//   A  lm_k_mb_join<0,*>  (tile of 64 CCs) x (uniques active at f0): count pass, then fill pass (exact offsets, no
-//                         atomics between workgroups: one workgroup owns a tile)
+//   * a CC that is a bit-identical TWIN (box, size, crop) of an earlier CC of the batch (its root), at most max_gap frames
+//     before it, is assigned the unique its root was assigned: every smaller-index candidate it accepts was dead or rejected
+//     at the root's frame already (a dead unique never comes back), and the root's unique was matched there, so it is alive
+//     (identical crops are accepted: recall = precision = 1, thresholds <= 1).  Static video: almost every CC is a twin;
+//   * tempo_count (:85), the number of (cur, candidate unique) box pairs, does not depend on the order of events: u is a
+//     candidate at frame f iff it was born before f and alive(f, last_u at the END of the batch) -- a unique that is matched
+//     later was alive all along, a dead one is never matched again.
+// So the expensive part (box join + AND/popcount on the crops) runs in wide launches over the NON-TWIN CCs of all B frames,
+// and only a cheap replay of the decisions -- list lookups, no pixels -- is sequential over the frames, in ONE workgroup:
+//   T  lm_k_mb_twin_*     hash table (key -> smallest CC index of the batch), candidates verified word by word; a missed twin
+//                         only costs time
+//   N  lm_k_mb_nt         drop the actives retired before f0 (order kept), compact the non-twin CCs (NT), tile tables (64 NT
+//                         CCs per tile, tiles never straddle a frame), reset per-batch tables
+//   A  lm_k_mb_join<0,*>  (NT tile) x (uniques active at f0): count pass, then fill pass at exact offsets; the sources of a
+//                         tile are shared by gridDim.y workgroups, one counter update / slot reservation per workgroup
 //   E  lm_k_mb_eval<0>    every pair, 8 lanes each: overlap + float64 thresholds -> accepted bit; a CC with an accepted
 //                         candidate that stays alive whatever happens in the batch is "surely matched"
-//   T  lm_k_mb_twin_*     a CC that is a bit-identical twin (box, size, crop) of an EARLIER CC of the batch, at most max_gap
-//                         frames before it, can never become a new unique: it accepts whatever its twin matched -- or
-//                         the twin itself -- with recall = precision = 1 (thresholds <= 1), and that unique is still
-//                         alive.  Twins are found with a hash table (min CC index per key) and verified word by word;
-//                         a missed twin only costs time.  Static video: almost every CC is a twin
-//                         A twin is moreover ASSIGNED the unique its root was assigned: every smaller-index candidate it accepts
-//                         was dead or rejected at the root's frame already, and the root's unique was matched there.  So only
-//                         the non-twin CCs (NT, compacted by lm_k_mb_nt) go through joins, evaluation and pair replay.
-//   S  lm_k_mb_sources    the other CCs of the batch are the only ones that CAN become new uniques: compact them (S)
+//   S  lm_k_mb_sources    the other NT CCs are the only ones that CAN become new uniques: compact them (S)
 //   B  lm_k_mb_join<1,*> + lm_k_mb_eval<1>: the same join against S, restricted to sources of EARLIER frames
-//   C  lm_k_mb_resolve    frames in order: a pair counts if its unique exists and is alive; smallest accepted active
-//                         position per CC (ascending unique index == the reference's first match) or a new unique,
-//                         numbered in CC order; `last` and the active list are updated as the reference does.
-// In-batch uniques get active positions behind all earlier ones in creation order, so "smallest position" is still
-// "smallest unique index".  tempo_count (:85), the number of (cur, alive unique) box pairs, does not need the replay: a unique
-// is a candidate at frame f iff it was born before f and alive(f, its last match at the END of the batch) -- one that is
-// matched later was alive all along, a dead one is never matched again -- so lm_k_mb_tempo is one streaming box join of all
-// CCs against the final active list.
+//   C  lm_k_mb_resolve    frames in order: smallest accepted active position per NT CC among the uniques that exist and are
+//                         alive (ascending unique index == the reference's first match) or a new unique, numbered in CC
+//                         order; a twin copies its root's position; `last` and the active list are updated as the
+//                         reference does.  In-batch uniques get positions behind all earlier ones in creation order, so
+//                         "smallest position" is still "smallest unique index"
+//   Q  lm_k_mb_tempo      streaming box join of ALL CCs against the final active list with the tempo_count rule above
 #include "lm_stream.h"
 
 #define LM_MB_TILE 64
