@@ -385,7 +385,7 @@ extern "C" void lm_stream_destroy(LmStream* s)
         if (p) (void)hipFree(p);
     if (s->mb) {
         LmMatchBatch* m = s->mb;
-        void* mp[] = {m->tcur[0], m->tcur[1], m->ftile_all, m->nt_foff, m->nt_list, m->cls, m->troot, m->rootpos, m->ftile, m->s_prefix, m->tcount[0], m->tcount[1], m->toff[0], m->toff[1], m->pairs[0], m->pairs[1], m->pair_u[0],
+        void* mp[] = {m->nt_src, m->tlast, m->tcur[0], m->tcur[1], m->ftile_all, m->nt_foff, m->nt_list, m->cls, m->troot, m->rootpos, m->ftile, m->s_prefix, m->tcount[0], m->tcount[1], m->toff[0], m->toff[1], m->pairs[0], m->pairs[1], m->pair_u[0],
                       m->pair_u[1], m->sidx, m->s_list, m->s_box, m->newpos, m->n_src, m->ttab, m->tkey, m->twin};
         for (void* p : mp)
             if (p) (void)hipFree(p);
@@ -462,6 +462,8 @@ extern "C" LmStream* lm_stream_create(LmCtx* ctx, int max_frames, int64_t max_cc
         rc |= lm_alloc(&m->cls, (size_t)max_ccs);
         rc |= lm_alloc(&m->troot, (size_t)max_ccs);
         rc |= lm_alloc(&m->rootpos, (size_t)max_ccs);
+        rc |= lm_alloc(&m->nt_src, (size_t)max_ccs);
+        rc |= lm_alloc(&m->tlast, (size_t)max_ccs);
         for (int k = 0; k < 2; k++) {
             rc |= lm_alloc(&m->tcount[k], (size_t)m->cap_tiles + 1);
             rc |= lm_alloc(&m->toff[k], (size_t)m->cap_tiles + 1);
@@ -535,6 +537,7 @@ static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st)
                            s->min_recall, s->min_precision, s->max_gap);
         hipLaunchKernelGGL(lm_k_mb_resolve, dim3(1), dim3(LM_MB_RT), LM_MB_RESOLVE_SMEM, st, s->cc, s->frame_cc_off, f, B, s->active, s->active_cc,
                            s->active_box, s->active_last, s->counters, s->assign, mb, s->max_gap, s->cap_uniq);
+        hipLaunchKernelGGL(lm_k_mb_finish, dim3(160), dim3(256), 0, st, s->frame_cc_off, f, B, s->active, s->counters, s->assign, mb);
         hipLaunchKernelGGL(lm_k_mb_tempo, gt, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->active_last,
                            s->counters, mb, s->max_gap);
         done += B;

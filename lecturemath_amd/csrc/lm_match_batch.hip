@@ -37,13 +37,18 @@
 #define LM_MB_TTAB (1 << 18)     // twin table slots; batches with more than LM_MB_TTAB / 2 CCs skip twin detection
 #define LM_MB_CHUNK 4096        // source boxes filtered per round (LDS survivors list)
 #define LM_MB_MAX_FRAMES 64     // frames per batch (per-frame tables of the replay kernel live in LDS)
-#define LM_MB_CH 2048           // CCs of one frame resolved per LDS pass
-#define LM_MB_LA 12288          // active positions whose last-matched frame is cached in LDS by the replay kernel
-#define LM_MB_LS 12288          // sources whose active position is cached in LDS by the replay kernel
-#define LM_MB_RP 8192           // non-twin CCs whose decided active position is cached in LDS (twins look their root up)
+#ifndef LM_MB_CH
+#define LM_MB_CH 2048           // non-twin CCs of one frame resolved per LDS pass
+#endif
+#define LM_MB_LA 16384          // active positions whose last-matched frame is cached in LDS by the replay kernel
+#define LM_MB_LS 16384          // sources whose active position is cached in LDS by the replay kernel
+#ifndef LM_MB_PFA
 #define LM_MB_PFA 2             // pairs per thread prefetched one frame ahead: against earlier uniques ...
+#endif
+#ifndef LM_MB_PFB
 #define LM_MB_PFB 1             // ... and against in-batch sources
-#define LM_MB_RESOLVE_SMEM ((size_t)LM_MB_CH * 8 + (size_t)LM_MB_LA * 4 + (size_t)LM_MB_LS * 4 + (size_t)LM_MB_RP * 4)
+#endif
+#define LM_MB_RESOLVE_SMEM ((size_t)LM_MB_CH * 8 + (size_t)LM_MB_LA * 4 + (size_t)LM_MB_LS * 4)
 
 struct LmMatchBatch {
     int32_t* ftile;             // [cap_frames + 2] first tile (64 NON-TWIN CCs) of every frame of the batch; ftile[B] = number of tiles
@@ -52,7 +57,9 @@ struct LmMatchBatch {
     int32_t* nt_list;           // [cap_cc] global cc index of non-twin k (ascending)
     int32_t* cls;               // [cap_cc] per global cc: k >= 0 own index in nt_list; -1 - k: twin whose root is non-twin k
     int32_t* troot;             // [cap_cc] per global cc: global cc index of the twin's root (valid where twin[] is set)
-    int32_t* rootpos;           // [cap_cc] active position decided for non-twin k (global copy of the replay's LDS table)
+    int32_t* rootpos;           // [cap_cc] scratch per non-twin k: sources before k (lm_k_mb_sources -> s_prefix)
+    int32_t* nt_src;            // [cap_cc] per non-twin k: its index in the source list, or -1 (copy of sidx in nt order)
+    int32_t* tlast;             // [cap_cc] per non-twin k: last frame of the batch in which one of its twins appears, or -1
     int32_t* s_prefix;          // [cap_frames + 2] number of sources that belong to frames before frame b of the batch
     uint32_t* tcount[2];        // [cap_tiles + 1]  pairs per tile (A: vs actives, B: vs in-batch sources)
     uint32_t* toff[2];          // [cap_tiles + 1]  exclusive prefix, toff[nt] = total
@@ -166,7 +173,7 @@ __global__ void __launch_bounds__(1024) lm_k_mb_nt(const long long* __restrict__
             if (i < C1) {
                 const unsigned o = carry + s_tab[k * 16 + wid] + (unsigned)__popcll(bal & lm_lowmask_excl(lane));
                 mb.tkey[i] = o;                                 // non-twins before this CC (the hash keys are not needed any more)
-                if (flag) { mb.nt_list[o] = (int32_t)i; mb.cls[i] = (int32_t)o; }
+                if (flag) { mb.nt_list[o] = (int32_t)i; mb.cls[i] = (int32_t)o; mb.tlast[o] = -1; }
             }
         }
         carry += s_tot;
@@ -303,7 +310,7 @@ __global__ void __launch_bounds__(256) lm_k_mb_join(const LmCcRec* __restrict__ 
                             if (hit && room) {
                                 const unsigned slot = off + s_base + basep + (unsigned)__popcll(bal & lm_lowmask_excl(lm_lane()));
                                 const int pos = s_spos[j];
-                                mb.pairs[SRC][slot] = make_uint2((unsigned)(my_cc - C0), (unsigned)pos);
+                                mb.pairs[SRC][slot] = make_uint2((unsigned)(k_first + ccl), (unsigned)pos);
                                 mb.pair_u[SRC][slot] = src_cc[pos];
                             }
                         }
@@ -343,7 +350,11 @@ __global__ void __launch_bounds__(256) lm_k_mb_eval(const LmCcRec* __restrict__ 
         // nt_list (roots are non-twins, their cls was written by lm_k_mb_nt)
         const long long C1 = frame_cc_off[f0 + B];
         for (long long i = C0 + (long long)blockIdx.x * 256 + threadIdx.x; i < C1; i += (long long)gridDim.x * 256)
-            if (mb.twin[i]) mb.cls[i] = -1 - mb.cls[mb.troot[i]];
+            if (mb.twin[i]) {
+                const int rk = mb.cls[mb.troot[i]];
+                mb.cls[i] = -1 - rk;
+                atomicMax(&mb.tlast[rk], cc[i].frame);          // the root's unique is matched again at every twin's frame
+            }
     }
     const int sub = (int)(threadIdx.x & 7);
     const unsigned grp = (blockIdx.x * 256u + threadIdx.x) >> 3, ngrp = (gridDim.x * 256u) >> 3;
@@ -358,7 +369,7 @@ __global__ void __launch_bounds__(256) lm_k_mb_eval(const LmCcRec* __restrict__ 
         if (live) {
             pr = mb.pairs[SRC][p];
             const int ui = mb.pair_u[SRC][p];
-            ci = C0 + (long long)pr.x;
+            ci = (long long)mb.nt_list[pr.x];
             rec = cc[ci];
             urec = cc[ui];
             const LmIsect is = lm_isect(rec, urec);
@@ -516,7 +527,8 @@ __global__ void __launch_bounds__(1024) lm_k_mb_sources(const LmCcRec* __restric
             const int e = base + k * 1024 + (int)threadIdx.x;
             if (e < nNT) {
                 const unsigned o = carry + s_tab[k * 16 + wid] + (unsigned)__popcll(bal & lm_lowmask_excl(lane));
-                mb.rootpos[e] = (int32_t)o;         // sources before non-twin e (rootpos is free until the replay)
+                mb.rootpos[e] = (int32_t)o;         // sources before non-twin e
+                mb.nt_src[e] = flag ? (int32_t)o : -1;
                 if (flag) {
                     mb.sidx[ci[k]] = (int32_t)o;
                     mb.s_list[o] = ci[k];
@@ -542,11 +554,15 @@ __global__ void __launch_bounds__(1024) lm_k_mb_sources(const LmCcRec* __restric
 // indices of its CCs) are fetched into registers while the previous frame is being decided.  Global state is written
 // through as the replay goes (positions / sources beyond the LDS tables fall back to it).
 // ------------------------------------------------------------------------------------------------
+#ifndef LM_MB_RT
 #define LM_MB_RT 1024           // threads of the replay workgroup (512 was measured slower: 144 vs 113 us per batch)
+#endif
 #define LM_MB_ITEMS (LM_MB_CH / LM_MB_RT)
 
-LM_DEV void lm_mb_prefetch(const LmMatchBatch& mb, unsigned pA0, unsigned pA1, unsigned pB0, unsigned pB1, long long c_abs0, int n,
-                           uint2 (&ra)[LM_MB_PFA], uint2 (&rb)[LM_MB_PFB], int (&rs)[LM_MB_ITEMS], int (&rc)[LM_MB_ITEMS])
+// what the replay needs of frame b, fetched one frame ahead: its pair lists and, per non-twin CC, the cc index, the source index
+// and the last frame one of its twins appears in
+LM_DEV void lm_mb_prefetch(const LmMatchBatch& mb, unsigned pA0, unsigned pA1, unsigned pB0, unsigned pB1, int n0, int n,
+                           uint2 (&ra)[LM_MB_PFA], uint2 (&rb)[LM_MB_PFB], int (&rs)[LM_MB_ITEMS], int (&rc)[LM_MB_ITEMS], int (&rt)[LM_MB_ITEMS])
 {
 #pragma unroll
     for (int k = 0; k < LM_MB_PFA; k++) {
@@ -562,13 +578,15 @@ LM_DEV void lm_mb_prefetch(const LmMatchBatch& mb, unsigned pA0, unsigned pA1, u
     for (int k = 0; k < LM_MB_ITEMS; k++) {
         const int i = (int)threadIdx.x * LM_MB_ITEMS + k;
         const bool on = i < n && n <= LM_MB_CH;
-        rs[k] = on ? mb.sidx[c_abs0 + i] : -1;
-        rc[k] = on ? mb.cls[c_abs0 + i] : 0;
+        rs[k] = on ? mb.nt_src[n0 + i] : -1;
+        rc[k] = on ? mb.nt_list[n0 + i] : 0;
+        rt[k] = on ? mb.tlast[n0 + i] : -1;
     }
 }
 
-// Only accepted pairs matter to the replay (tempo_count is computed by lm_k_mb_tempo).  idx >= nch: a CC of another LDS pass
-// of this frame (frames with more than LM_MB_CH CCs scan their pair lists once per pass).
+// Only accepted pairs matter to the replay (tempo_count is computed by lm_k_mb_tempo).  pr.x = accepted << 31 | index of the
+// CC in nt_list; idx >= nch: a CC of another LDS pass of this frame (frames with more than LM_MB_CH non-twins scan their pair
+// lists once per pass).
 LM_DEV void lm_mb_pair_old(uint2 pr, int f, int max_gap, unsigned rel0, unsigned nch, unsigned* s_best, const int* s_last,
                            const int32_t* __restrict__ active_last)
 {
@@ -591,18 +609,22 @@ LM_DEV void lm_mb_pair_new(uint2 pr, int f, int max_gap, unsigned rel0, unsigned
     if (lm_mb_alive(f, last, max_gap)) atomicMin(&s_best[idx], (unsigned)pos);
 }
 
+// C: replay.  Only the non-twin CCs take part: a twin is assigned its root's unique after the replay, and what it does to the
+// stream state -- the unique is matched again at the twin's frame -- is folded into the root's decision: the unique's last
+// match becomes max(f, last frame with a twin of the root).  That is equivalent for every aliveness test: all twins lie within
+// max_gap frames of the root, so the unique is alive at every frame up to the last twin's whatever else happens, and from
+// there on the value is the true one.
 __global__ void __launch_bounds__(LM_MB_RT) lm_k_mb_resolve(const LmCcRec* __restrict__ cc, const long long* __restrict__ frame_cc_off,
-                                                        int f0, int B, int32_t* __restrict__ active, int32_t* __restrict__ active_cc,
-                                                        unsigned long long* __restrict__ active_box, int32_t* __restrict__ active_last,
-                                                        LmCounters* __restrict__ cnt, int32_t* __restrict__ assign, LmMatchBatch mb,
-                                                        int max_gap, int cap_uniq)
+                                                            int f0, int B, int32_t* __restrict__ active, int32_t* __restrict__ active_cc,
+                                                            unsigned long long* __restrict__ active_box, int32_t* __restrict__ active_last,
+                                                            LmCounters* __restrict__ cnt, int32_t* __restrict__ assign, LmMatchBatch mb,
+                                                            int max_gap, int cap_uniq)
 {
     LM_DYN_SMEM(smem);
     unsigned* s_best2 = (unsigned*)smem;                // [2][LM_MB_CH], double-buffered: the next step's buffer is reset while this one is decided
     int* s_last = (int*)(smem + (size_t)LM_MB_CH * 8);  // [LM_MB_LA]
     int* s_newpos = s_last + LM_MB_LA;                  // [LM_MB_LS]
-    int* s_rootpos = s_newpos + LM_MB_LS;               // [LM_MB_RP] active position decided for non-twin k
-    __shared__ int s_c0[LM_MB_MAX_FRAMES + 1];
+    __shared__ int s_n0[LM_MB_MAX_FRAMES + 1];
     __shared__ unsigned s_tA[LM_MB_MAX_FRAMES + 1], s_tB[LM_MB_MAX_FRAMES + 1];
     __shared__ int s_fail;
     __shared__ unsigned s_wsum[LM_MB_RT / 64];
@@ -611,15 +633,14 @@ __global__ void __launch_bounds__(LM_MB_RT) lm_k_mb_resolve(const LmCcRec* __res
     const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
     const int nA0 = cnt->n_active;
     const int nS = *mb.n_src;
-    const int nNT = mb.nt_foff[B];
     int nA = nA0;
     int nU = cnt->n_uniq;
-    // every position / source / non-twin the replay can touch is covered by the LDS tables: the loop then never re-reads global
-    // memory it wrote, and its barriers only need to order LDS (prefetch loads and write-through stores stay in flight)
-    const bool lds_only = (long long)nA0 + nS <= LM_MB_LA && nS <= LM_MB_LS && nNT <= LM_MB_RP;
+    // every position / source the replay can touch is covered by the LDS tables: the loop then never re-reads global memory it
+    // wrote, and its barriers only need to order LDS (prefetch loads and write-through stores stay in flight)
+    const bool lds_only = (long long)nA0 + nS <= LM_MB_LA && nS <= LM_MB_LS;
     if (threadIdx.x == 0) s_fail = 0;
     if ((int)threadIdx.x <= B) {
-        s_c0[threadIdx.x] = (int)(frame_cc_off[f0 + threadIdx.x] - C0);
+        s_n0[threadIdx.x] = mb.nt_foff[threadIdx.x];
         const int t = mb.ftile[threadIdx.x];
         s_tA[threadIdx.x] = nt > 0 ? mb.toff[0][t] : 0u;
         s_tB[threadIdx.x] = nt > 0 ? mb.toff[1][t] : 0u;
@@ -630,18 +651,21 @@ __global__ void __launch_bounds__(LM_MB_RT) lm_k_mb_resolve(const LmCcRec* __res
     int bb = 0;
     __syncthreads();
     uint2 ra[LM_MB_PFA], rb[LM_MB_PFB];
-    int rs[LM_MB_ITEMS], rc[LM_MB_ITEMS];
-    lm_mb_prefetch(mb, s_tA[0], s_tA[1], s_tB[0], s_tB[1], C0 + s_c0[0], s_c0[1] - s_c0[0], ra, rb, rs, rc);
+    int rs[LM_MB_ITEMS], rc[LM_MB_ITEMS], rt[LM_MB_ITEMS];
+    lm_mb_prefetch(mb, s_tA[0], s_tA[1], s_tB[0], s_tB[1], s_n0[0], s_n0[1] - s_n0[0], ra, rb, rs, rc, rt);
 
     for (int b = 0; b < B; b++) {
         const int f = f0 + b;
-        const int n = s_c0[b + 1] - s_c0[b];
-        const long long c0 = C0 + s_c0[b];
+        const int n0 = s_n0[b], n = s_n0[b + 1] - n0;       // the frame's non-twin CCs
+        if (n == 0) {       // nothing to decide in this frame (uniform): no barriers
+            if (b + 1 < B) lm_mb_prefetch(mb, s_tA[b + 1], s_tA[b + 2], s_tB[b + 1], s_tB[b + 2], s_n0[b + 1], s_n0[b + 2] - s_n0[b + 1], ra, rb, rs, rc, rt);
+            continue;
+        }
         const bool single = n <= LM_MB_CH;
         const unsigned pA0 = s_tA[b], pA1 = s_tA[b + 1], pB0 = s_tB[b], pB1 = s_tB[b + 1];     // the frame's pair lists
-        for (int cb = 0; cb < n || cb == 0; cb += LM_MB_CH) {
+        for (int cb = 0; cb < n; cb += LM_MB_CH) {
             const int nch = (n - cb < LM_MB_CH) ? n - cb : LM_MB_CH;
-            const unsigned rel0 = (unsigned)s_c0[b] + (unsigned)cb;
+            const unsigned rel0 = (unsigned)(n0 + cb);
             unsigned* s_best = s_best2 + bb * LM_MB_CH;
             // ---- accepted pairs against uniques that existed before the batch / were born inside it
             if (single) {
@@ -656,40 +680,32 @@ __global__ void __launch_bounds__(LM_MB_RT) lm_k_mb_resolve(const LmCcRec* __res
                 lm_mb_pair_old(mb.pairs[0][p], f, max_gap, rel0, (unsigned)nch, s_best, s_last, active_last);
             for (unsigned p = pB0 + (single ? (unsigned)LM_MB_PFB * (unsigned)LM_MB_RT : 0u) + threadIdx.x; p < pB1; p += LM_MB_RT)
                 lm_mb_pair_new(mb.pairs[1][p], f, max_gap, rel0, (unsigned)nch, s_best, s_last, s_newpos, active_last, mb.newpos);
-            int cur_s[LM_MB_ITEMS], cur_c[LM_MB_ITEMS];
+            int cur_s[LM_MB_ITEMS], cur_c[LM_MB_ITEMS], cur_t[LM_MB_ITEMS];
 #pragma unroll
             for (int k = 0; k < LM_MB_ITEMS; k++) {
                 const int i = (int)threadIdx.x * LM_MB_ITEMS + k;
-                cur_s[k] = single ? rs[k] : (i < nch ? mb.sidx[c0 + cb + i] : -1);
-                cur_c[k] = single ? rc[k] : (i < nch ? mb.cls[c0 + cb + i] : 0);
+                const bool on = i < nch;
+                cur_s[k] = single ? rs[k] : (on ? mb.nt_src[n0 + cb + i] : -1);
+                cur_c[k] = single ? rc[k] : (on ? mb.nt_list[n0 + cb + i] : 0);
+                cur_t[k] = single ? rt[k] : (on ? mb.tlast[n0 + cb + i] : -1);
             }
             if (cb + LM_MB_CH >= n && b + 1 < B)        // next frame's lists: in flight while this one is decided
-                lm_mb_prefetch(mb, s_tA[b + 1], s_tA[b + 2], s_tB[b + 1], s_tB[b + 2], C0 + s_c0[b + 1], s_c0[b + 2] - s_c0[b + 1], ra, rb, rs, rc);
+                lm_mb_prefetch(mb, s_tA[b + 1], s_tA[b + 2], s_tB[b + 1], s_tB[b + 2], s_n0[b + 1], s_n0[b + 2] - s_n0[b + 1], ra, rb, rs, rc, rt);
             if (lds_only) lm_lds_barrier(); else __syncthreads();
             for (int i = threadIdx.x; i < LM_MB_CH; i += LM_MB_RT) s_best2[(bb ^ 1) * LM_MB_CH + i] = 0xffffffffu;     // for the next step
-            // ---- decisions; matched CCs keep the active POSITION for now (-2 - pos), translated after the replay.
-            // A twin takes its root's position (decided in an earlier frame) and refreshes that unique's last match.
+            // ---- decisions; matched CCs keep the active POSITION for now (-2 - pos), translated after the replay
             unsigned isnew[LM_MB_ITEMS], mine = 0;
 #pragma unroll
             for (int k = 0; k < LM_MB_ITEMS; k++) {
                 const int i = (int)threadIdx.x * LM_MB_ITEMS + k;
                 isnew[k] = 0;
                 if (i < nch) {
-                    unsigned best;
-                    if (cur_c[k] < 0) {
-                        const int rk = -1 - cur_c[k];
-                        best = (unsigned)(rk < LM_MB_RP ? s_rootpos[rk] : mb.rootpos[rk]);
-                    } else {
-                        best = s_best[i];
-                    }
+                    const unsigned best = s_best[i];
                     if (best != 0xffffffffu) {
-                        assign[c0 + cb + i] = -2 - (int32_t)best;
-                        if (best < LM_MB_LA) s_last[best] = f;      // several CCs may hit the same unique: same value
-                        active_last[best] = f;
-                        if (cur_c[k] >= 0) {
-                            if (cur_c[k] < LM_MB_RP) s_rootpos[cur_c[k]] = (int)best;
-                            mb.rootpos[cur_c[k]] = (int32_t)best;
-                        }
+                        const int upto = cur_t[k] > f ? cur_t[k] : f;       // matched now, and again at every twin's frame
+                        assign[cur_c[k]] = -2 - (int32_t)best;
+                        if (best < LM_MB_LA) atomicMax(&s_last[best], upto);
+                        atomicMax(&active_last[best], upto);
                     } else {
                         isnew[k] = 1;
                     }
@@ -712,22 +728,20 @@ __global__ void __launch_bounds__(LM_MB_RT) lm_k_mb_resolve(const LmCcRec* __res
 #pragma unroll
             for (int k = 0; k < LM_MB_ITEMS; k++) {
                 if (!isnew[k]) continue;
-                const long long ci = c0 + cb + (long long)threadIdx.x * LM_MB_ITEMS + k;
                 const long long idx = (long long)nU + o;
                 const int src = cur_s[k];
-                if (idx < cap_uniq && src >= 0 && cur_c[k] >= 0) {
+                if (idx < cap_uniq && src >= 0) {
                     const int pos = nA + (int)o;
-                    assign[ci] = (int32_t)idx;
+                    const int upto = cur_t[k] > f ? cur_t[k] : f;
+                    assign[cur_c[k]] = (int32_t)idx;
                     active[pos] = (int32_t)idx;
-                    active_cc[pos] = (int32_t)ci;
-                    active_last[pos] = f;
-                    if (pos < LM_MB_LA) s_last[pos] = f;
+                    active_cc[pos] = cur_c[k];
+                    active_last[pos] = upto;
+                    if (pos < LM_MB_LA) s_last[pos] = upto;
                     mb.newpos[src] = pos;
                     if (src < LM_MB_LS) s_newpos[src] = pos;
-                    if (cur_c[k] < LM_MB_RP) s_rootpos[cur_c[k]] = pos;
-                    mb.rootpos[cur_c[k]] = pos;
                 } else {
-                    // STATE: a surely matched CC or a twin found no match (a bug, not an input condition)
+                    // STATE: a surely matched CC found no match (a bug, not an input condition)
                     s_fail = idx < cap_uniq ? LM_ERR_STATE : LM_ERR_CAPACITY;
                 }
                 o++;
@@ -739,23 +753,8 @@ __global__ void __launch_bounds__(LM_MB_RT) lm_k_mb_resolve(const LmCcRec* __res
         }
     }
     __syncthreads();        // everything the replay wrote is visible to the whole block
-    // ---- after the replay: positions -> unique indices, boxes of the new actives
+    // ---- after the replay: boxes of the new actives (assignments are finished by lm_k_mb_finish)
     if (!s_fail) {
-        for (long long base = C0; base < C1; base += LM_MB_RT * 12) {     // 12 independent lookups in flight per thread
-            int v[12], u[12];
-#pragma unroll
-            for (int k = 0; k < 12; k++) {
-                const long long i = base + (long long)k * LM_MB_RT + threadIdx.x;
-                v[k] = (i < C1) ? assign[i] : 0;
-            }
-#pragma unroll
-            for (int k = 0; k < 12; k++) u[k] = (v[k] <= -2) ? active[-2 - v[k]] : 0;
-#pragma unroll
-            for (int k = 0; k < 12; k++) {
-                const long long i = base + (long long)k * LM_MB_RT + threadIdx.x;
-                if (v[k] <= -2) assign[i] = u[k];
-            }
-        }
         for (int pos = nA0 + (int)threadIdx.x; pos < nA; pos += LM_MB_RT) active_box[pos] = lm_pack_box(cc[active_cc[pos]]);
     }
     __syncthreads();
@@ -767,6 +766,21 @@ __global__ void __launch_bounds__(LM_MB_RT) lm_k_mb_resolve(const LmCcRec* __res
             cnt->n_active = nA;
             cnt->n_matched = f0 + B;
         }
+    }
+}
+
+// C': the replay left active POSITIONS (-2 - pos) in the matched non-twins' assignments and nothing in the twins': positions
+// become unique indices and every twin takes its root's unique.  A twin's thread may read its root's entry before or after the
+// root's own thread translated it; both forms are understood.
+__global__ void __launch_bounds__(256) lm_k_mb_finish(const long long* __restrict__ frame_cc_off, int f0, int B, const int32_t* __restrict__ active,
+                                                      const LmCounters* __restrict__ cnt, int32_t* __restrict__ assign, LmMatchBatch mb)
+{
+    if (cnt->error) return;
+    const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
+    for (long long i = C0 + (long long)blockIdx.x * 256 + threadIdx.x; i < C1; i += (long long)gridDim.x * 256) {
+        int32_t v = assign[mb.twin[i] ? (long long)mb.troot[i] : i];
+        if (v <= -2) v = active[-2 - v];
+        assign[i] = v;
     }
 }
 
