@@ -38,7 +38,7 @@ def parse():
     p.add_argument("--frames", type=int, default=256, help="frames per stream (= per step)")
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--width", type=int, default=1920)
-    p.add_argument("--batch", type=int, default=32, help="frames per labelling launch")
+    p.add_argument("--batch", type=int, default=64, help="frames per labelling launch")
     p.add_argument("--cpu-frames", type=int, default=200, help="prefix of the stream timed on the CPU oracle (0 = skip)")
     p.add_argument("--no-labels", action="store_true", help="do not materialise the int32 label image")
     p.add_argument("--no-pipeline", action="store_true", help="do not overlap step 03 of one stream with steps 01-02 of the next")

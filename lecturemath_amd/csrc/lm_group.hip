@@ -207,23 +207,28 @@ struct LmRenderItem { int32_t x0, y0, w, h; long long bits_off; };
 
 #define LM_RT_ROWS 64
 #define LM_RT_COLS 256
+#define LM_RT_PITCH (LM_RT_COLS / 32 + 1)      // words per tile row of one counter plane (+1: rows of a narrow item fall into distinct banks)
+#define LM_RT_PLANE (LM_RT_ROWS * LM_RT_PITCH)
 #define LM_RT_MAXHIT 96     // items of one frame that touch one tile and are painted cooperatively (more: painted by their finder)
-#define LM_RT_WPL 4         // image words per lane in flight while painting
+#define LM_RT_WPL 4         // tile words per lane in flight while painting
 
-// paints the part of `it` inside the tile at (X0, Y0) from its bit rows; lanes `lane` of `nl` share the (row, word) cells,
-// LM_RT_WPL independent loads in flight per lane, rows from a float reciprocal (exact after one correction step)
-LM_DEV void lm_render_paint(const LmRenderItem& it, int X0, int Y0, const uint32_t* __restrict__ bits, unsigned* s_cnt, int lane, int nl)
+// The reference adds every group image (0 / 255) into a uint8 frame (:674-678), so a pixel covered by k images holds -k mod 256.
+// k is kept bit-sliced: plane p holds bit p of k for 32 pixels per word.  Adding an image word = toggle plane 0, carry the bits
+// that went 1 -> 0 into plane 1, ... (the carry out of plane 7 is the mod 256).  Concurrent adds commute: a bit that is toggled
+// N times from b generates floor((b + N) / 2) carries whatever the order.  One LDS atomic per 32 pixels where images do not
+// overlap (nearly everywhere), instead of one per set pixel.
+LM_DEV void lm_render_paint(const LmRenderItem& it, int X0, int Y0, const uint32_t* __restrict__ bits, unsigned* s_pl, int lane, int nl)
 {
     const int xa = it.x0 > X0 ? it.x0 : X0, xb = (it.x0 + it.w < X0 + LM_RT_COLS) ? it.x0 + it.w : X0 + LM_RT_COLS;
     const int ya = it.y0 > Y0 ? it.y0 : Y0, yb = (it.y0 + it.h < Y0 + LM_RT_ROWS) ? it.y0 + it.h : Y0 + LM_RT_ROWS;
     const int bw = (it.w + 31) >> 5;
-    const int wlo = (xa - it.x0) >> 5, nw = ((xb - 1 - it.x0) >> 5) - wlo + 1;
+    const int jlo = (xa - X0) >> 5, nw = ((xb - 1 - X0) >> 5) - jlo + 1;        // tile words the item touches per row
     const int total = nw * (yb - ya);
     const float inv = 1.0f / (float)nw;
-    const uint32_t* src = bits + it.bits_off + (long long)(ya - it.y0) * bw + wlo;
+    const uint32_t* src = bits + it.bits_off + (long long)(ya - it.y0) * bw;
     for (int idx0 = lane; idx0 < total; idx0 += nl * LM_RT_WPL) {
-        unsigned v[LM_RT_WPL];
-        int px[LM_RT_WPL], prow[LM_RT_WPL];
+        unsigned lo[LM_RT_WPL], hi[LM_RT_WPL];
+        int col[LM_RT_WPL], slot[LM_RT_WPL];
 #pragma unroll
         for (int u = 0; u < LM_RT_WPL; u++) {
             const int idx = idx0 + u * nl;
@@ -231,21 +236,22 @@ LM_DEV void lm_render_paint(const LmRenderItem& it, int X0, int Y0, const uint32
             int j = idx - yy * nw;
             if (j < 0) { yy--; j += nw; }
             if (j >= nw) { yy++; j -= nw; }
-            v[u] = (idx < total) ? src[(long long)yy * bw + j] : 0u;
-            px[u] = it.x0 + 32 * (wlo + j);                  // frame column of bit 0
-            prow[u] = (ya - Y0 + yy) * LM_RT_COLS - X0;
+            col[u] = X0 + 32 * (jlo + j);                   // frame column of the tile word's bit 0
+            const int d = col[u] - it.x0;                   // ... and the image column under it (> -32)
+            const int sw = d >> 5;                          // floor
+            const uint32_t* r = src + (long long)yy * bw;
+            const bool on = idx < total;
+            lo[u] = (on && sw >= 0 && sw < bw) ? r[sw] : 0u;
+            hi[u] = (on && (d & 31) && sw + 1 < bw) ? r[sw + 1] : 0u;
+            slot[u] = (ya - Y0 + yy) * LM_RT_PITCH + jlo + j;
         }
 #pragma unroll
         for (int u = 0; u < LM_RT_WPL; u++) {
-            unsigned m = v[u];
-            if (px[u] < xa) m &= 0xffffffffu << (xa - px[u]);               // clip to the tile / item intersection in x
-            if (px[u] + 32 > xb) m &= 0xffffffffu >> (px[u] + 32 - xb);
-            while (m) {
-                const int bpos = __ffs((int)m) - 1;
-                m &= m - 1;
-                const int p = prow[u] + px[u] + bpos;
-                atomicAdd(&s_cnt[p >> 1], 1u << (16 * (p & 1)));
-            }
+            const int sh = (col[u] - it.x0) & 31;
+            unsigned c = sh ? ((lo[u] >> sh) | (hi[u] << (32 - sh))) : lo[u];
+            if (col[u] < xa) c &= 0xffffffffu << (xa - col[u]);             // clip to the tile / item intersection in x
+            if (col[u] + 32 > xb) c &= 0xffffffffu >> (col[u] + 32 - xb);
+            for (int p = 0; p < 8 && c; p++) c &= atomicXor(&s_pl[p * LM_RT_PLANE + slot[u]], c);
         }
     }
 }
@@ -284,13 +290,12 @@ __global__ void __launch_bounds__(256) lm_k_render_frames(const long long* __res
                                                           const LmRenderItem* __restrict__ items, const uint32_t* __restrict__ bits,
                                                           int first_frame, int W, int H, uint8_t* __restrict__ out)
 {
-    // k per pixel in 16-bit lanes, two pixels per LDS word (a pixel would need 65536 overlapping groups to overflow its lane)
-    __shared__ unsigned s_cnt[LM_RT_ROWS * LM_RT_COLS / 2];
+    __shared__ unsigned s_pl[8 * LM_RT_PLANE];      // bit-sliced k per pixel (see lm_render_paint)
     __shared__ LmRenderItem s_hit[LM_RT_MAXHIT];
     __shared__ int s_nhit;
     const int f = first_frame + blockIdx.z;
     const int X0 = blockIdx.x * LM_RT_COLS, Y0 = blockIdx.y * LM_RT_ROWS;
-    for (int i = threadIdx.x; i < LM_RT_ROWS * LM_RT_COLS / 2; i += blockDim.x) s_cnt[i] = 0;
+    for (int i = threadIdx.x; i < 8 * LM_RT_PLANE; i += blockDim.x) s_pl[i] = 0;
     if (threadIdx.x == 0) s_nhit = 0;
     __syncthreads();
     const long long i0 = frame_item_off[f], i1 = frame_item_off[f + 1];
@@ -301,27 +306,41 @@ __global__ void __launch_bounds__(256) lm_k_render_frames(const long long* __res
         if (mine.x0 < X0 + LM_RT_COLS && mine.x0 + mine.w > X0 && mine.y0 < Y0 + LM_RT_ROWS && mine.y0 + mine.h > Y0) {
             const int slot = atomicAdd(&s_nhit, 1);
             if (slot < LM_RT_MAXHIT) s_hit[slot] = mine;
-            else lm_render_paint(mine, X0, Y0, bits, s_cnt, 0, 1);      // crowded tile: the finder paints it alone
+            else lm_render_paint(mine, X0, Y0, bits, s_pl, 0, 1);      // crowded tile: the finder paints it alone
         }
     }
     __syncthreads();
     const int nhit = s_nhit < LM_RT_MAXHIT ? s_nhit : LM_RT_MAXHIT;
     const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6), lane = lm_lane();
-    for (int h = wave; h < nhit; h += nwaves) lm_render_paint(s_hit[h], X0, Y0, bits, s_cnt, lane, 64);
+    for (int h = wave; h < nhit; h += nwaves) lm_render_paint(s_hit[h], X0, Y0, bits, s_pl, lane, 64);
     __syncthreads();
     uint8_t* dst = out + (long long)blockIdx.z * W * H;
     const bool vec = ((W & 15) == 0) && ((((uintptr_t)out) & 15) == 0);
-    // 16 pixels (8 LDS words) -> one 16-byte store
+    // 16 pixels (half a plane word) -> one 16-byte store
     for (int i = threadIdx.x; i < LM_RT_ROWS * LM_RT_COLS / 16; i += blockDim.x) {
         const int yy = i / (LM_RT_COLS / 16), xq = i - yy * (LM_RT_COLS / 16);
         const int y = Y0 + yy, x = X0 + xq * 16;
         if (y >= H || x >= W) continue;
-        unsigned o[4];
+        unsigned pl[8], upper = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const unsigned w0 = s_cnt[yy * (LM_RT_COLS / 2) + xq * 8 + q * 2], w1 = s_cnt[yy * (LM_RT_COLS / 2) + xq * 8 + q * 2 + 1];
-            o[q] = ((0u - (w0 & 0xffffu)) & 0xffu) | (((0u - (w0 >> 16)) & 0xffu) << 8) | (((0u - (w1 & 0xffffu)) & 0xffu) << 16) |
-                   (((0u - (w1 >> 16)) & 0xffu) << 24);
+        for (int p = 0; p < 8; p++) {
+            pl[p] = (s_pl[p * LM_RT_PLANE + yy * LM_RT_PITCH + (xq >> 1)] >> (16 * (xq & 1))) & 0xffffu;
+            if (p) upper |= pl[p];
+        }
+        unsigned o[4];
+        if (!upper) {       // k <= 1 everywhere: bit -> 0x00 / 0xff (the multiply spreads four bits over four bytes)
+#pragma unroll
+            for (int q = 0; q < 4; q++) o[q] = ((((pl[0] >> (4 * q)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                o[q] = 0;
+                for (int t = 0; t < 4; t++) {
+                    unsigned k = 0;
+                    for (int p = 0; p < 8; p++) k |= ((pl[p] >> (4 * q + t)) & 1u) << p;
+                    o[q] |= ((0u - k) & 0xffu) << (8 * t);
+                }
+            }
         }
         uint8_t* d = dst + (long long)y * W + x;
         if (vec) {

@@ -64,7 +64,7 @@ struct LmMatchBatch {
     uint32_t* tcount[2];        // [cap_tiles + 1]  pairs per tile (A: vs actives, B: vs in-batch sources)
     uint32_t* toff[2];          // [cap_tiles + 1]  exclusive prefix, toff[nt] = total
     uint32_t* tcur[2];          // [cap_tiles + 1]  fill cursors (one reservation per workgroup)
-    uint2* pairs[2];            // x = (cc - C0) | accepted << 31, y = active position (A) / source index (B)
+    uint2* pairs[2];            // x = index in nt_list | accepted << 31, y = active position (A) / source index (B)
     int32_t* pair_u[2];         // cc index of the unique's first-seen CC (what the pair is evaluated against)
     int32_t* sidx;              // [cap_cc] per global cc: -2 undecided, -1 surely matched; after lm_k_mb_sources: k >= 0 index into
                                 // the source list for the sources, still negative for everybody else
@@ -234,7 +234,6 @@ __global__ void __launch_bounds__(256) lm_k_mb_join(const LmCcRec* __restrict__ 
     const int nt = mb.ftile[B];
     const unsigned long long* src_box = SRC == 0 ? active_box : mb.s_box;
     const int32_t* src_cc = SRC == 0 ? active_cc : mb.s_list;
-    const long long C0 = frame_cc_off[f0];
     const int ccl = (int)(threadIdx.x & 63), q = (int)(threadIdx.x >> 6);
     for (int t = blockIdx.x; t < nt; t += gridDim.x) {
         const int b = lm_mb_tile_frame(mb.ftile, B, t);
@@ -630,7 +629,6 @@ __global__ void __launch_bounds__(LM_MB_RT) lm_k_mb_resolve(const LmCcRec* __res
     __shared__ unsigned s_wsum[LM_MB_RT / 64];
     if (cnt->error) return;
     const int nt = mb.ftile[B];
-    const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
     const int nA0 = cnt->n_active;
     const int nS = *mb.n_src;
     int nA = nA0;

@@ -116,6 +116,7 @@ template <class T> static inline T atomicSub(T* p, T v) { T o = *p; *p = o - v; 
 template <class T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> static inline T atomicXor(T* p, T v) { T o = *p; *p = o ^ v; return o; }
 template <class T> static inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
 template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <class T> static inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }

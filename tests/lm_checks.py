@@ -254,6 +254,31 @@ def dot_grid_stream(n_frames=6, h=72, w=520, seed=3):
     return frames
 
 
+def blink_overlap_stream(n_frames=30, h=80, w=300):
+    """Shapes that alternate between two / three overlapping places: their groups are alive together, so their images are
+    added on top of each other in the reconstructed frames (uint8 wrap-around: k images over a pixel leave -k mod 256), at
+    columns that are not multiples of 32 and across render-tile borders (x = 256)."""
+    frames = []
+    for f in range(n_frames):
+        img = np.zeros((h, w), np.uint8)
+        img[5:9, 5:10] = 255
+        for y, x in [(20, 27), (40, 61), (50, 250), (60, 120)]:
+            if (f // 5) % 2 == 0:
+                img[y:y + 10, x:x + 10] = 255
+            else:
+                img[y + 3:y + 13, x + 8:x + 18] = 255
+        y3, x3 = [(30, 180), (38, 180), (34, 188)][(f // 4) % 3]
+        img[y3:y3 + 12, x3:x3 + 12] = 255
+        frames.append(img)
+    return frames
+
+
+def check_render_wraparound(lib):
+    r = check_grouping_oracle(lib, blink_overlap_stream())
+    values = set(np.unique(np.stack(r["clean_binary"])).tolist())
+    assert {0, 253, 254, 255} <= values, values
+
+
 def reference_c_library():
     """oracle/_ref/accessmath_lib.so: the reference's own C file compiled by oracle/Makefile (travels to the GPU box)."""
     import ctypes

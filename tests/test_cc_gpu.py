@@ -141,6 +141,11 @@ def test_grouping_crowded_tiles_vs_oracle(hip_lib, oracle_built):
     assert len(r["cc_groups"]) > 500
 
 
+def test_render_overlapping_group_images(hip_lib, oracle_built):
+    """Group images added on top of each other (pixels holding 254 and 253) at unaligned columns and across tile borders."""
+    lm_checks.check_render_wraparound(hip_lib)
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "fp32"])
 @pytest.mark.parametrize("name", ["k7_70x94", "k3_135x240", "k7_66x130_wide"])
 def test_fcn_golden(hip_lib, name, precision):

@@ -85,6 +85,10 @@ def test_grouping_crowded_tiles_vs_oracle(emu_lib, oracle_built):
     assert len(r["cc_groups"]) > 200
 
 
+def test_render_overlapping_group_images(emu_lib, oracle_built):
+    lm_checks.check_render_wraparound(emu_lib)
+
+
 def test_legacy_exports_vs_reference_c(emu_lib, oracle_built):
     lm_checks.check_legacy_exports(emu_lib)
 
