@@ -42,7 +42,7 @@ def parse():
     p.add_argument("--cpu-frames", type=int, default=200, help="prefix of the stream timed on the CPU oracle (0 = skip)")
     p.add_argument("--no-labels", action="store_true", help="do not materialise the int32 label image")
     p.add_argument("--no-pipeline", action="store_true", help="do not overlap step 03 of one stream with steps 01-02 of the next")
-    p.add_argument("--depth", type=int, default=2, help="streams in flight (pipeline slots); depth-1 host workers run step 03")
+    p.add_argument("--depth", type=int, default=3, help="streams in flight (pipeline slots); depth-1 host workers run step 03")
     p.add_argument("--seed", type=int, default=20213)
     p.add_argument("--fcn-precision", default="f16x3", choices=["f16x3", "fp32"],
                    help="MFMA operand format of the FCN conv stack (fp32 accumulate in both)")

@@ -385,7 +385,7 @@ extern "C" void lm_stream_destroy(LmStream* s)
         if (p) (void)hipFree(p);
     if (s->mb) {
         LmMatchBatch* m = s->mb;
-        void* mp[] = {m->nt_src, m->tlast, m->tcur[0], m->tcur[1], m->ftile_all, m->nt_foff, m->nt_list, m->cls, m->troot, m->rootpos, m->ftile, m->s_prefix, m->tcount[0], m->tcount[1], m->toff[0], m->toff[1], m->pairs[0], m->pairs[1], m->pair_u[0],
+        void* mp[] = {m->nt_cnt, m->nt_src, m->tlast, m->tcur[0], m->tcur[1], m->ftile_all, m->nt_foff, m->nt_list, m->cls, m->troot, m->rootpos, m->ftile, m->s_prefix, m->tcount[0], m->tcount[1], m->toff[0], m->toff[1], m->pairs[0], m->pairs[1], m->pair_u[0],
                       m->pair_u[1], m->sidx, m->s_list, m->s_box, m->newpos, m->n_src, m->ttab, m->tkey, m->twin};
         for (void* p : mp)
             if (p) (void)hipFree(p);
@@ -462,6 +462,7 @@ extern "C" LmStream* lm_stream_create(LmCtx* ctx, int max_frames, int64_t max_cc
         rc |= lm_alloc(&m->cls, (size_t)max_ccs);
         rc |= lm_alloc(&m->troot, (size_t)max_ccs);
         rc |= lm_alloc(&m->rootpos, (size_t)max_ccs);
+        rc |= lm_alloc(&m->nt_cnt, (size_t)LM_MB_MAX_FRAMES);
         rc |= lm_alloc(&m->nt_src, (size_t)max_ccs);
         rc |= lm_alloc(&m->tlast, (size_t)max_ccs);
         for (int k = 0; k < 2; k++) {
@@ -519,13 +520,14 @@ static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st)
         const int B = (n - done < LM_MB_MAX_FRAMES) ? n - done : LM_MB_MAX_FRAMES;
         const int f = f0 + done;
         s->last_match_frames = B;
-        if (s->min_recall <= 1.0 && s->min_precision <= 1.0) {     // the twin rule needs "identical crops are accepted"; otherwise twin[] stays 0
+        const int twins = (s->min_recall <= 1.0 && s->min_precision <= 1.0) ? 1 : 0;     // the twin rule needs "identical crops are accepted"; otherwise twin[] stays 0
+        if (twins) {
             (void)hipMemsetAsync(mb.ttab, 0xff, (size_t)LM_MB_TTAB * sizeof(unsigned long long), st);
             hipLaunchKernelGGL(lm_k_mb_twin_insert, ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->counters, mb);
             hipLaunchKernelGGL(lm_k_mb_twin_find, ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->counters, mb, s->max_gap);
         }
-        hipLaunchKernelGGL(lm_k_mb_nt, dim3(1), dim3(1024), 0, st, s->frame_cc_off, f, B, s->active, s->active_cc, s->active_box, s->active_last,
-                           s->counters, mb, s->max_gap);
+        hipLaunchKernelGGL(lm_k_mb_nt, dim3(B + 1), dim3(1024), 0, st, s->frame_cc_off, f, B, s->active, s->active_cc, s->active_box, s->active_last,
+                           s->counters, mb, s->max_gap, twins);
         hipLaunchKernelGGL((lm_k_mb_join<0, 0>), gj, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->counters, mb);
         hipLaunchKernelGGL((lm_k_mb_join<0, 1>), gj, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->counters, mb);
         hipLaunchKernelGGL((lm_k_mb_eval<0>), ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->active_last, s->counters, mb,

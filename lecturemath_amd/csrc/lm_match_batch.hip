@@ -58,6 +58,7 @@ struct LmMatchBatch {
     int32_t* cls;               // [cap_cc] per global cc: k >= 0 own index in nt_list; -1 - k: twin whose root is non-twin k
     int32_t* troot;             // [cap_cc] per global cc: global cc index of the twin's root (valid where twin[] is set)
     int32_t* rootpos;           // [cap_cc] scratch per non-twin k: sources before k (lm_k_mb_sources -> s_prefix)
+    int32_t* nt_cnt;            // [LM_MB_MAX_FRAMES] non-twins per frame of the batch (zeroed by lm_k_mb_twin_insert, counted by lm_k_mb_twin_find)
     int32_t* nt_src;            // [cap_cc] per non-twin k: its index in the source list, or -1 (copy of sidx in nt order)
     int32_t* tlast;             // [cap_cc] per non-twin k: last frame of the batch in which one of its twins appears, or -1
     int32_t* s_prefix;          // [cap_frames + 2] number of sources that belong to frames before frame b of the batch
@@ -122,27 +123,58 @@ LM_DEV void lm_mb_prologue(const long long* __restrict__ frame_cc_off, int f0, i
         *mb.n_src = 0;
         cnt->n_active = nA;
     }
-    const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
-    for (long long i = C0 + threadIdx.x; i < C1; i += 1024) mb.sidx[i] = -2;
 }
 
 // ------------------------------------------------------------------------------------------------
-// N: compact the non-twin CCs (the only ones that go through joins, evaluation and pair replay), give every twin its
-// root's index, and build the tile tables.  One block; ballots per 1024-CC row like lm_k_mb_sources.
+// N: compact the non-twin CCs (the only ones that go through joins, evaluation and pair replay) and build the tile tables.
+// B + 1 workgroups: workgroup b < B compacts frame b -- where its non-twins and tiles start follows from the per-frame
+// non-twin counts lm_k_mb_twin_find left in nt_cnt (twins == 0: no twin detection ran, every CC is a non-twin; the counters
+// cost lm_k_mb_twin_find +11 us, counting the flags of the earlier frames here was measured at +17 us) -- and the last
+// workgroup compacts the active list (lm_mb_prologue).
 // ------------------------------------------------------------------------------------------------
-#define LM_MB_NT_R 32
+#define LM_MB_NT_R 4
 
 __global__ void __launch_bounds__(1024) lm_k_mb_nt(const long long* __restrict__ frame_cc_off, int f0, int B, int32_t* __restrict__ active,
                                                    int32_t* __restrict__ active_cc, unsigned long long* __restrict__ active_box,
-                                                   int32_t* __restrict__ active_last, LmCounters* __restrict__ cnt, LmMatchBatch mb, int max_gap)
+                                                   int32_t* __restrict__ active_last, LmCounters* __restrict__ cnt, LmMatchBatch mb, int max_gap,
+                                                   int twins)
 {
     __shared__ unsigned s_tab[LM_MB_NT_R * 16];
     __shared__ unsigned s_tot;
+    __shared__ int s_head[6];
     if (cnt->error) return;
-    lm_mb_prologue(frame_cc_off, f0, B, active, active_cc, active_box, active_last, cnt, mb, max_gap);
-    const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
+    if ((int)blockIdx.x == B) {
+        lm_mb_prologue(frame_cc_off, f0, B, active, active_cc, active_box, active_last, cnt, mb, max_gap);
+        return;
+    }
+    const int b = (int)blockIdx.x;
     const int lane = lm_lane(), wid = (int)(threadIdx.x >> 6);
-    unsigned carry = 0;
+    if (wid == 0) {     // frames before this one (B <= 64: one per lane): non-twins, tiles of non-twins, tiles of all CCs
+        unsigned n_nt = 0, n_all = 0;
+        if (lane < B) {
+            n_all = (unsigned)(frame_cc_off[f0 + lane + 1] - frame_cc_off[f0 + lane]);
+            n_nt = twins ? (unsigned)mb.nt_cnt[lane] : n_all;
+        }
+        const unsigned t_nt = (n_nt + LM_MB_TILE - 1) / LM_MB_TILE, t_all = (n_all + LM_MB_TILE - 1) / LM_MB_TILE;
+        const unsigned i_nt = lm_wave_incl_scan(n_nt), i_tnt = lm_wave_incl_scan(t_nt), i_tall = lm_wave_incl_scan(t_all);
+        if (lane == b) {
+            s_head[0] = (int)(i_nt - n_nt); s_head[1] = (int)(i_tnt - t_nt); s_head[2] = (int)i_tnt;
+            mb.nt_foff[b] = (int32_t)(i_nt - n_nt);
+            mb.ftile[b] = (int32_t)(i_tnt - t_nt);
+            mb.ftile_all[b] = (int32_t)(i_tall - t_all);
+            if (b == B - 1) {
+                mb.nt_foff[B] = (int32_t)i_nt;
+                mb.ftile[B] = (int32_t)i_tnt;
+                mb.ftile_all[B] = (int32_t)i_tall;
+                if ((int)i_tnt > mb.cap_tiles || (int)i_tall > mb.cap_tiles) cnt->error = LM_ERR_CAPACITY;
+            }
+        }
+    }
+    __syncthreads();
+    const int t0 = s_head[1], t1 = s_head[2] + (b == B - 1 ? 1 : 0);      // this frame's tiles (the last frame also clears entry [n_tiles])
+    for (int t = t0 + (int)threadIdx.x; t < t1 && t <= mb.cap_tiles; t += 1024) { mb.tcount[0][t] = 0; mb.tcount[1][t] = 0; mb.tcur[0][t] = 0; mb.tcur[1][t] = 0; }
+    const long long C0 = frame_cc_off[f0 + b], C1 = frame_cc_off[f0 + b + 1];
+    unsigned carry = (unsigned)s_head[0];
     for (long long base = C0; base < C1; base += 1024 * LM_MB_NT_R) {
         unsigned fm = 0;
 #pragma unroll
@@ -154,14 +186,10 @@ __global__ void __launch_bounds__(1024) lm_k_mb_nt(const long long* __restrict__
             if (lane == 0) s_tab[k * 16 + wid] = (unsigned)__popcll(bal);
         }
         __syncthreads();
-        if (wid == 0) {     // exclusive scan of the 512 (row, wave) counts: 8 per lane
-            unsigned loc[8], sum = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) { loc[j] = s_tab[lane * 8 + j]; sum += loc[j]; }
-            const unsigned incl = lm_wave_incl_scan(sum);
-            unsigned run = incl - sum;
-#pragma unroll
-            for (int j = 0; j < 8; j++) { s_tab[lane * 8 + j] = run; run += loc[j]; }
+        if (wid == 0) {     // exclusive scan of the (row, wave) counts: one per lane
+            const unsigned v = s_tab[lane];
+            const unsigned incl = lm_wave_incl_scan(v);
+            s_tab[lane] = incl - v;
             if (lane == 63) s_tot = incl;
         }
         __syncthreads();
@@ -170,38 +198,14 @@ __global__ void __launch_bounds__(1024) lm_k_mb_nt(const long long* __restrict__
             const int flag = (int)((fm >> k) & 1u);
             const unsigned long long bal = __ballot(flag);
             const long long i = base + (long long)k * 1024 + threadIdx.x;
-            if (i < C1) {
+            if (flag) {
                 const unsigned o = carry + s_tab[k * 16 + wid] + (unsigned)__popcll(bal & lm_lowmask_excl(lane));
-                mb.tkey[i] = o;                                 // non-twins before this CC (the hash keys are not needed any more)
-                if (flag) { mb.nt_list[o] = (int32_t)i; mb.cls[i] = (int32_t)o; mb.tlast[o] = -1; }
+                mb.nt_list[o] = (int32_t)i; mb.cls[i] = (int32_t)o; mb.tlast[o] = -1; mb.sidx[i] = -2;
             }
         }
         carry += s_tot;
         __syncthreads();
     }
-    // per frame: first non-twin, tiles of non-twins, tiles of all CCs
-    const int b = threadIdx.x;
-    unsigned tiles_nt = 0, tiles_all = 0;
-    if (b <= B) {
-        const long long i = frame_cc_off[f0 + b];
-        mb.nt_foff[b] = (i < C1) ? (int32_t)mb.tkey[i] : (int32_t)carry;
-    }
-    __syncthreads();
-    if (b < B) {
-        tiles_nt = (unsigned)((mb.nt_foff[b + 1] - mb.nt_foff[b] + LM_MB_TILE - 1) / LM_MB_TILE);
-        tiles_all = (unsigned)((frame_cc_off[f0 + b + 1] - frame_cc_off[f0 + b] + LM_MB_TILE - 1) / LM_MB_TILE);
-    }
-    unsigned nt, nta;
-    const unsigned ex = lm_block_excl_scan<1024>(tiles_nt, &nt);
-    const unsigned exa = lm_block_excl_scan<1024>(tiles_all, &nta);
-    if (b < B) { mb.ftile[b] = (int32_t)ex; mb.ftile_all[b] = (int32_t)exa; }
-    if (b == 0) {
-        mb.ftile[B] = (int32_t)nt;
-        mb.ftile_all[B] = (int32_t)nta;
-        if ((int)nt > mb.cap_tiles || (int)nta > mb.cap_tiles) cnt->error = LM_ERR_CAPACITY;
-    }
-    if ((int)nt > mb.cap_tiles) return;
-    for (unsigned t = threadIdx.x; t <= nt; t += 1024) { mb.tcount[0][t] = 0; mb.tcount[1][t] = 0; mb.tcur[0][t] = 0; mb.tcur[1][t] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -401,6 +405,7 @@ __global__ void __launch_bounds__(256) lm_k_mb_twin_insert(const LmCcRec* __rest
     if (cnt->error) return;
     const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
     const long long n = C1 - C0;
+    if (blockIdx.x == 0 && threadIdx.x < LM_MB_MAX_FRAMES) mb.nt_cnt[threadIdx.x] = 0;      // counted by lm_k_mb_twin_find
     if (n * 2 > LM_MB_TTAB) return;
     const int sub = (int)(threadIdx.x & 7);
     const long long grp = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3, ngrp = ((long long)gridDim.x * 256) >> 3;
@@ -470,7 +475,11 @@ __global__ void __launch_bounds__(256) lm_k_mb_twin_find(const LmCcRec* __restri
         }
 #pragma unroll
         for (int d = 4; d >= 1; d >>= 1) diff |= __shfl_xor(diff, d, 8);
-        if (live && sub == 0) { mb.twin[C0 + i] = diff ? 0 : 1; mb.troot[C0 + i] = diff ? -1 : (int32_t)(C0 + root_keep); }
+        if (live && sub == 0) {
+            mb.twin[C0 + i] = diff ? 0 : 1;
+            mb.troot[C0 + i] = diff ? -1 : (int32_t)(C0 + root_keep);
+            if (diff) atomicAdd(&mb.nt_cnt[cc[C0 + i].frame - f0], 1);
+        }
     }
 }
 

@@ -68,8 +68,8 @@ def state_equal_oracle(r, o):
         assert a.shape == b.shape and (a == b).all()
 
 
-def run_stream(lib, frames, w, h, max_gap, max_batch=7, split=None, records_then_match=False, **kw):
-    fs = device.FrameStream(w, h, len(frames), 0.85, 0.85, max_gap, 20, max_batch=max_batch, lib=lib, **kw)
+def run_stream(lib, frames, w, h, max_gap, max_batch=7, split=None, records_then_match=False, thresholds=(0.85, 0.85), **kw):
+    fs = device.FrameStream(w, h, len(frames), thresholds[0], thresholds[1], max_gap, 20, max_batch=max_batch, lib=lib, **kw)
     try:
         dev = fs.be.from_host(frames)
         if records_then_match:      # all records first, then ONE matching call (chunks of 64 frames inside the library)
@@ -91,15 +91,25 @@ def check_stream_golden(lib, name, max_batch=7):
     state_equal_golden(r, g)
 
 
-def check_stream_oracle(lib, frames, max_gap, max_batch=5, **kw):
+def check_stream_oracle(lib, frames, max_gap, max_batch=5, thresholds=(0.85, 0.85), **kw):
     from oracle import cc as occ
     h, w = frames[0].shape
-    st = occ.Stability(w, h, 0.85, 0.85, max_gap)
+    st = occ.Stability(w, h, thresholds[0], thresholds[1], max_gap)
     for f in frames:
         st.add_frame(f)
-    r = run_stream(lib, np.stack(frames), w, h, max_gap, max_batch=max_batch, **kw)
+    r = run_stream(lib, np.stack(frames), w, h, max_gap, max_batch=max_batch, thresholds=thresholds, **kw)
     state_equal_oracle(r, st.result())
     return r
+
+
+def check_stream_threshold_edges(lib):
+    """Thresholds the twin shortcut must respect: exactly 1.0 (only identical crops match: everything rides on twins) and
+    above 1.0 (nothing ever matches, twin detection is off: every CC of every frame is a new unique)."""
+    frames = list(synth.binary_stream(40, 64, 96, seed=5, glyphs_per_add=3, erase_every=6, jitter_p=0.3, occluder=True, max_ext=12))
+    r = check_stream_oracle(lib, frames, 3, max_batch=16, thresholds=(1.0, 1.0))
+    assert len(r["unique_recs"]) < sum(len(fr) for fr in r["cc_idx_per_frame"])
+    r = check_stream_oracle(lib, frames, 3, max_batch=16, thresholds=(1.01, 0.5))
+    assert len(r["unique_recs"]) == sum(len(fr) for fr in r["cc_idx_per_frame"])
 
 
 def check_stream_match_paths(lib, n_frames=80, max_gap=2, seed=11):

@@ -141,6 +141,11 @@ def test_grouping_crowded_tiles_vs_oracle(hip_lib, oracle_built):
     assert len(r["cc_groups"]) > 500
 
 
+def test_stream_threshold_edges(hip_lib, oracle_built):
+    """min recall / precision of exactly 1 (twins only) and above 1 (no twin detection, nothing matches)."""
+    lm_checks.check_stream_threshold_edges(hip_lib)
+
+
 def test_render_overlapping_group_images(hip_lib, oracle_built):
     """Group images added on top of each other (pixels holding 254 and 253) at unaligned columns and across tile borders."""
     lm_checks.check_render_wraparound(hip_lib)

@@ -85,6 +85,10 @@ def test_grouping_crowded_tiles_vs_oracle(emu_lib, oracle_built):
     assert len(r["cc_groups"]) > 200
 
 
+def test_stream_threshold_edges(emu_lib, oracle_built):
+    lm_checks.check_stream_threshold_edges(emu_lib)
+
+
 def test_render_overlapping_group_images(emu_lib, oracle_built):
     lm_checks.check_render_wraparound(emu_lib)
 
