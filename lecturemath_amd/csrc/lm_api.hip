@@ -56,6 +56,7 @@ template <class T> static int lm_alloc(T** p, size_t count)
 // ------------------------------------------------------------------------------------------------
 // live profiling (event pairs around the labelling launch sequence)
 // ------------------------------------------------------------------------------------------------
+#include <mutex>
 #include <vector>
 struct LmProfile {
     std::vector<hipEvent_t> ev;     // pairs: start, stop
@@ -186,10 +187,51 @@ extern "C" LmCtx* lm_ctx_create(int width, int height, int max_batch)
 // ------------------------------------------------------------------------------------------------
 // threshold
 // ------------------------------------------------------------------------------------------------
+// x* of lm_k_thr_edge per threshold value, found once per process (0: not yet, 1: usable, 2: keep the formula kernel)
+static float g_thr_edge[256];
+static int g_thr_state[256];
+static std::mutex g_thr_mutex;
+
+static int lm_threshold_edge(int thr, hipStream_t st, float* edge, int* state)
+{
+    std::lock_guard<std::mutex> lock(g_thr_mutex);
+    if (!g_thr_state[thr]) {
+        float* d = nullptr;
+        float h[2] = {0.0f, 0.0f};
+        LM_HIP(hipMalloc(&d, 2 * sizeof(float)));
+        hipLaunchKernelGGL(lm_k_thr_edge, dim3(1), dim3(64), 0, st, thr, d);
+        const hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+        const hipError_t e2 = hipStreamSynchronize(st);
+        (void)hipFree(d);
+        LM_HIP(e);
+        LM_HIP(e2);
+        g_thr_edge[thr] = h[0];
+        g_thr_state[thr] = h[1] == 1.0f ? 1 : 2;
+    }
+    *edge = g_thr_edge[thr];
+    *state = g_thr_state[thr];
+    return LM_OK;
+}
+
 extern "C" int lm_threshold(const float* d_logits, uint8_t* d_out, int64_t n, int thr, int invert, void* stream)
 {
     if (!d_logits || !d_out || n < 0) { lm_set_error("lm_threshold: bad arguments"); return LM_ERR_ARG; }
     if (n == 0) return LM_OK;
+    const bool aligned = ((((uintptr_t)d_logits) & 15) == 0) && ((((uintptr_t)d_out) & 15) == 0);
+    float edge = 0.0f;
+    // the comparison form needs a threshold the sigmoid can straddle and 16-byte aligned buffers; its first use per threshold
+    // value synchronises the stream once
+    if (aligned && thr >= 1 && thr <= 255 && !getenv("LM_THRESHOLD_FORMULA")) {
+        int state = 0;
+        const int rc = lm_threshold_edge(thr, (hipStream_t)stream, &edge, &state);
+        if (rc) return rc;
+        if (state == 1) {
+            hipLaunchKernelGGL(lm_k_threshold_cmp, dim3(lm_blocks((n + 4095) / 4096, 1, 1 << 20)), dim3(256), 0, (hipStream_t)stream, d_logits, d_out,
+                               (long long)n, edge, invert ? 0xffu : 0u);
+            LM_HIP(hipGetLastError());
+            return LM_OK;
+        }
+    }
     hipLaunchKernelGGL(lm_k_threshold_invert, dim3(lm_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream,
                        d_logits, d_out, (long long)n, thr, invert ? 0xffu : 0u);
     LM_HIP(hipGetLastError());

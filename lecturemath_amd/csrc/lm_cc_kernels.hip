@@ -56,6 +56,77 @@ __global__ void __launch_bounds__(256) lm_k_threshold_invert(const float* __rest
     }
 }
 
+// The per-pixel formula is monotone in x, so "sigmoid(x) * 255 truncates to >= thr" is "x >= x*" for one float x*.
+// lm_k_thr_edge finds x* by bisection over the float ordinals WITH the formula above, then checks the equivalence for the 8192
+// floats around x* -- far from the edge the product differs from thr by much more than the formula's rounding error.  A failed
+// check (out[1] = 0) keeps the caller on lm_k_threshold_invert.  One wave.
+LM_DEV unsigned lm_f2ord(float x) { const unsigned b = __builtin_bit_cast(unsigned, x); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+LM_DEV float lm_ord2f(unsigned o) { return __builtin_bit_cast(float, (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+
+__global__ void __launch_bounds__(64) lm_k_thr_edge(int thr, float* __restrict__ out)
+{
+    // ordinals of -inf .. +inf; the formula is false at -inf and true at +inf for 0 < thr <= 255 (the caller checks)
+    unsigned lo = lm_f2ord(-__builtin_huge_valf()), hi = lm_f2ord(__builtin_huge_valf());     // invariant: formula(lo) = 0, formula(hi) = 255
+    while (hi - lo > 1) {
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        if (lm_thr_px(lm_ord2f(mid), thr, 0u)) hi = mid; else lo = mid;
+    }
+    const float edge = lm_ord2f(hi);
+    int good = 1;
+    for (int k = 0; k < 128; k++) {
+        const unsigned o = hi - 4096u + (unsigned)(k * 64) + threadIdx.x;
+        const float x = lm_ord2f(o);
+        const unsigned want = lm_thr_px(x, thr, 0u);
+        const unsigned got = (x >= edge) ? 255u : 0u;
+        if (want != got) good = 0;
+    }
+    good = __ballot(!good) == 0ull;
+    if (threadIdx.x == 0) { out[0] = edge; out[1] = good ? 1.0f : 0.0f; }
+}
+
+#if LM_HIP_EMULATED
+LM_DEV float4 lm_ld_stream(const float4* p) { return *p; }
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
+#else
+typedef float lm_f4v __attribute__((ext_vector_type(4)));
+LM_DEV float4 lm_ld_stream(const float4* p)        // read once: do not keep it in the caches
+{
+    const lm_f4v v = __builtin_nontemporal_load((const lm_f4v*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+#endif
+
+// K0': out = (x >= edge) ? hi : lo per pixel; 16 pixels per thread and trip (four 16-byte loads in flight, one 16-byte store).
+LM_DEV unsigned lm_cmp4(float4 v, float edge, unsigned on, unsigned off)
+{
+    return ((v.x >= edge) ? on : off) | (((v.y >= edge) ? on : off) << 8) | (((v.z >= edge) ? on : off) << 16) | (((v.w >= edge) ? on : off) << 24);
+}
+
+__global__ void __launch_bounds__(256) lm_k_threshold_cmp(const float* __restrict__ logits, uint8_t* __restrict__ out, long long n, float edge,
+                                                          unsigned flip)
+{
+    const unsigned on = 255u ^ flip, off = flip;
+    const long long n4 = n >> 2;
+    const float4* src = (const float4*)logits;
+    unsigned* dst = (unsigned*)out;
+    // a workgroup takes 4 x 256 consecutive 4-pixel groups per trip: every load / store instruction of a wave is contiguous
+    for (long long base = (long long)blockIdx.x * 1024; base < n4; base += (long long)gridDim.x * 1024) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const long long i = base + k * 256 + threadIdx.x;
+            v[k] = (i < n4) ? lm_ld_stream(src + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const long long i = base + k * 256 + threadIdx.x;
+            if (i < n4) __builtin_nontemporal_store(lm_cmp4(v[k], edge, on, off), dst + i);
+        }
+    }
+    const long long tail = n4 * 4 + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (tail < n) out[tail] = (uint8_t)((logits[tail] >= edge) ? on : off);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1 helper: non-zero bytes of a dword -> 4 bits (the bit packing itself is fused into lm_k_band)
 // ------------------------------------------------------------------------------------------------

@@ -112,6 +112,31 @@ def check_stream_threshold_edges(lib):
     assert len(r["unique_recs"]) == sum(len(fr) for fr in r["cc_idx_per_frame"])
 
 
+def check_threshold_paths(lib):
+    """lm_threshold_invert's comparison form (x >= x*, x* found on the device with the formula) vs the formula kernel
+    (LM_THRESHOLD_FORMULA=1) for several thresholds: logits packed around each edge ulp by ulp, +-inf, NaN, a ragged tail."""
+    rng = np.random.default_rng(9)
+    lab = device.FrameLabeler(64, 64, 1, lib)
+    try:
+        for thr in (1, 2, 77, 127, 128, 129, 254, 255):
+            centre = np.float32(np.log((thr / 255.0) / max(1.0 - thr / 255.0, 1e-9)))
+            around = (np.full(20001, centre, np.float32).view(np.int32) + np.arange(-10000, 10001, dtype=np.int32)).view(np.float32)
+            x = np.concatenate([around, rng.normal(0, 6, 30000).astype(np.float32),
+                                np.array([np.inf, -np.inf, np.nan, 0.0, -0.0, 88.0, -88.0, 104.0, -104.0], np.float32)])
+            x = x[:len(x) - (len(x) % 16) + 5]          # 5 pixels beyond the last 16-pixel group
+            dev = lab.be.from_host(x)
+            fast = lab.be.to_host(lab.threshold_invert(dev, thr))
+            os.environ["LM_THRESHOLD_FORMULA"] = "1"
+            try:
+                formula = lab.be.to_host(lab.threshold_invert(dev, thr))
+            finally:
+                del os.environ["LM_THRESHOLD_FORMULA"]
+            assert (fast == formula).all(), thr
+            assert 0 < int((fast == 255).sum()) < len(x)
+    finally:
+        lab.close()
+
+
 def check_stream_match_paths(lib, n_frames=80, max_gap=2, seed=11):
     """The batched matcher (default), the per-frame kernels (LM_MATCH_PER_FRAME=1) and the oracle agree on a stream whose
     uniques are created, retired (small max_gap) and re-created inside one matching batch, for several batch shapes."""

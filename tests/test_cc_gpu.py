@@ -141,6 +141,11 @@ def test_grouping_crowded_tiles_vs_oracle(hip_lib, oracle_built):
     assert len(r["cc_groups"]) > 500
 
 
+def test_threshold_comparison_form(hip_lib):
+    """x >= x* (the kernel that runs) == the sigmoid formula kernel, ulp by ulp around the edge of eight thresholds."""
+    lm_checks.check_threshold_paths(hip_lib)
+
+
 def test_stream_threshold_edges(hip_lib, oracle_built):
     """min recall / precision of exactly 1 (twins only) and above 1 (no twin detection, nothing matches)."""
     lm_checks.check_stream_threshold_edges(hip_lib)

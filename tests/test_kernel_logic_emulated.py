@@ -25,6 +25,10 @@ def test_threshold_golden(emu_lib):
     lab.close()
 
 
+def test_threshold_comparison_form(emu_lib):
+    lm_checks.check_threshold_paths(emu_lib)
+
+
 def test_stream_vs_oracle_small(emu_lib, oracle_built):
     frames = list(synth.binary_stream(24, 96, 160, seed=5, glyphs_per_add=4, erase_every=9, jitter_p=0.4, occluder=True,
                                       max_ext=16))
