@@ -183,6 +183,7 @@ def main():
     # Every step still does all of its work inside the timed region; only consecutive, independent steps overlap.
     import concurrent.futures
     depth = 1 if a.no_pipeline else max(2, a.depth)
+    prio = os.environ.get("LM_BENCH_PRIO", "front")       # which side's HIP streams get the higher priority: front | back | none
     slots = []
     for _ in range(depth):
         fs = device.FrameStream(W, H, F, 0.85, 0.85, 85, 20, max_batch=a.batch, lib=lib)
@@ -190,32 +191,50 @@ def main():
                       "labels": None if a.no_labels else torch.empty((a.batch, H, W), dtype=torch.int32, device="cuda"),
                       "clean": torch.empty((a.batch, H, W), dtype=torch.uint8, device="cuda"),
                       # steps 01-02 are the bandwidth-bound part: their stream gets the higher priority, step 03's small kernels fill in
-                      "s_front": torch.cuda.Stream(priority=0 if os.environ.get("LM_BENCH_NO_PRIO") else -1), "s_back": torch.cuda.Stream(),
+                      "s_front": torch.cuda.Stream(priority=-1 if prio == "front" else 0), "s_back": torch.cuda.Stream(priority=-1 if prio == "back" else 0),
                       "done": torch.cuda.Event(),
-                      "rdone": torch.cuda.Event(), "gr": None})
+                      "rdone": torch.cuda.Event(), "gr": None, "recorded": []})
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, depth - 1))
+
+    # LM_BENCH_SPLIT=1 (experiment, measured no gain: 66-71 k frames/s against 68-70 k): the bandwidth-bound half of steps 01-02
+    # (threshold, labelling, records: "wide") of ALL slots goes through one HIP stream, so two labelling launches never share the
+    # GPU; the temporal matching of a slot (small latency-bound kernels) runs on the slot's own stream behind an event per batch,
+    # under the wide kernels of the next batches / the next step.
+    split = depth > 1 and bool(os.environ.get("LM_BENCH_SPLIT"))
+    s_wide = torch.cuda.Stream(priority=-1 if prio == "front" else 0) if split else None
 
     def front(sl):
         """steps 01 (threshold) + 02 (label, records, matching) of one stream"""
         fs, binary, labels = sl["fs"], sl["binary"], sl["labels"]
-        with torch.cuda.stream(sl["s_front"]):
-            stream = sl["s_front"].cuda_stream
+        s_rec = s_wide if split else sl["s_front"]
+        with torch.cuda.stream(s_rec):
+            stream = s_rec.cuda_stream
             if sl.get("gr") is not None:            # the previous step of this slot: its rendering must be done before
                 sl["rdone"].synchronize()           # its tables go away and its buffers are reused
                 sl["gr"].close()
                 sl["gr"] = None
             fs.reset()
             lib.check(lib.lm_threshold_invert(logits.data_ptr(), binary.data_ptr(), F * H * W, 128, stream))
-            for f0 in range(0, F, a.batch):
+            for k, f0 in enumerate(range(0, F, a.batch)):
                 n = min(a.batch, F - f0)
                 # the label image of a batch is an output of the labelling kernel; the same buffer is reused per batch
-                lib.check(lib.lm_stream_push(fs.handle, binary[f0:f0 + n].data_ptr(), n,
-                                             labels.data_ptr() if labels is not None else None, stream))
+                if not split:
+                    lib.check(lib.lm_stream_push(fs.handle, binary[f0:f0 + n].data_ptr(), n,
+                                                 labels.data_ptr() if labels is not None else None, stream))
+                    continue
+                lib.check(lib.lm_stream_push_records(fs.handle, binary[f0:f0 + n].data_ptr(), n,
+                                                     labels.data_ptr() if labels is not None else None, stream))
+                while len(sl["recorded"]) <= k:
+                    sl["recorded"].append(torch.cuda.Event())
+                sl["recorded"][k].record(s_rec)
+                sl["s_front"].wait_event(sl["recorded"][k])
+                lib.check(lib.lm_stream_match(fs.handle, n, sl["s_front"].cuda_stream))
             sl["done"].record(sl["s_front"])
 
     def back(sl):
         """step 03: grouping + reconstruction of every frame (frames_from_groups), rendered batch by batch"""
         torch.cuda.set_device(local_rank)
+        tq = time.perf_counter()
         with torch.cuda.stream(sl["s_back"]):
             sl["s_back"].wait_event(sl["done"])
             gr = device.Grouping(sl["fs"], max_gap=85, min_times=3, t_window=5, min_recall=0.5, img_threshold=0.5, reconstruct=True)
@@ -230,19 +249,24 @@ def main():
                 gr.close()
             else:
                 sl["gr"] = gr
+        if os.environ.get("LM_BENCH_VERBOSE"):
+            sys.stderr.write("   step 03 worker: %.3f ms (from %.3f ms)\n" % ((time.perf_counter() - tq) * 1e3, tq * 1e3))
         return info
 
     def run_steps(k):
         pending = [None] * depth
         info = None
         for i in range(k):
-            if os.environ.get("LM_BENCH_VERBOSE"):
-                sys.stderr.write("step %d starts at %.3f ms\n" % (i, time.perf_counter() * 1e3))
+            ta = time.perf_counter()
             sl = slots[i % depth]
             if pending[i % depth] is not None:
                 info = pending[i % depth].result()          # the slot's previous step must be finished before it is reused
+            tb = time.perf_counter()
             front(sl)
             pending[i % depth] = pool.submit(back, sl)
+            if os.environ.get("LM_BENCH_VERBOSE"):
+                sys.stderr.write("step %d: at %.3f ms, waited %.3f ms for its slot, enqueued steps 01-02 in %.3f ms\n"
+                                 % (i, ta * 1e3, (tb - ta) * 1e3, (time.perf_counter() - tb) * 1e3))
         for p in pending:
             if p is not None:
                 info = p.result()
@@ -294,6 +318,20 @@ def main():
             dist.destroy_process_group()
         return
 
+    # the same launch sequence once more with nothing else in flight (after the timed region): in the pipeline, kernels of the
+    # other streams' steps share the GPU with it, which stretches the live figure without saying anything about the kernels
+    alone_ms = None
+    if depth > 1:
+        sl = slots[0]
+        lib.check(lib.lm_ctx_set_profiling(sl["fs"].labeler.ctx, 1))
+        front(sl)
+        torch.cuda.synchronize()
+        ms2, calls2, nfr2 = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        lib.check(lib.lm_ctx_profile_read(sl["fs"].labeler.ctx, ctypes.addressof(ms2), ctypes.addressof(calls2), ctypes.addressof(nfr2)))
+        lib.check(lib.lm_ctx_set_profiling(sl["fs"].labeler.ctx, 0))
+        if calls2.value > 0 and nfr2.value == nfr.value * calls2.value // max(calls.value, 1):
+            alone_ms = ms2.value / calls2.value
+
     launch_ms = ms.value / max(calls.value, 1)
     frames_per_launch = nfr.value / max(calls.value, 1)
     algo_bytes = ALGO_BYTES_PER_PX * W * H * frames_per_launch
@@ -308,6 +346,10 @@ def main():
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_src, "launch_ms": round(launch_ms, 4), "frames_per_launch": frames_per_launch,
                 "algorithmic_bytes_per_launch": int(algo_bytes), "label_image_written": labels is not None}
+    if alone_ms:
+        roofline["alone"] = {"launch_ms": round(alone_ms, 4), "achieved": round(algo_bytes / (alone_ms * 1e-3) / 1e9, 2),
+                             "frac": round(algo_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "note": "same launches after the timed region, no other stream's step in flight"}
 
     # ---- CPU baseline: the oracle (C port, 1 thread) on a prefix of the same stream
     cpu = None
@@ -334,7 +376,7 @@ def main():
                                "reconstructed frames"
                                % (W, H, F),
                    "frames_per_step": F, "batch": a.batch, "stages_not_in_timed_region": ["fcn conv stack (logits are synthetic, SURVEY 8(d) config 3)"],
-                   "stream": dict({k: k1[k] for k in ("n_cc", "n_unique", "tempo_count")}, n_groups=int(ginfo[2]), n_split=int(ginfo[0])), "parallelism": "independent streams per GPU", "pipeline_depth": depth},
+                   "stream": dict({k: k1[k] for k in ("n_cc", "n_unique", "tempo_count")}, n_groups=int(ginfo[2]), n_split=int(ginfo[0])), "parallelism": "independent streams per GPU", "pipeline_depth": depth, "matching_on_own_hip_stream": bool(split)},
         "roofline": roofline, "cpu_baseline": cpu, "gen_seconds": round(gen_s, 2),
     }
     print(json.dumps(out))
