@@ -566,6 +566,7 @@ __global__ void __launch_bounds__(1024) lm_k_mb_sources(const LmCcRec* __restric
 #define LM_MB_RT 1024           // threads of the replay workgroup (512 was measured slower: 144 vs 113 us per batch)
 #endif
 #define LM_MB_ITEMS (LM_MB_CH / LM_MB_RT)
+#define LM_MB_SCAN_DIRECT 512   // chunks of at most this many CCs rank their new uniques without the scan barrier
 
 // what the replay needs of frame b, fetched one frame ahead: its pair lists and, per non-twin CC, the cc index, the source index
 // and the last frame one of its twins appears in
@@ -719,17 +720,29 @@ __global__ void __launch_bounds__(LM_MB_RT) lm_k_mb_resolve(const LmCcRec* __res
                 }
                 mine += isnew[k];
             }
-            // exclusive scan of the new-unique flags with ONE barrier: wave totals to LDS, every thread sums the waves before it
-            // (s_wsum is rewritten only after the barrier that ends this chunk)
+            // exclusive scan of the new-unique flags.  Few CCs (the usual frame): no barrier -- a CC is new iff its s_best entry
+            // is still empty, so every wave counts the new ones of the waves before it (and all of them) itself.  Many: ONE
+            // barrier -- wave totals to LDS, every thread sums the waves before it (s_wsum is rewritten only after the barrier
+            // that ends this chunk).
             const unsigned incl = lm_wave_incl_scan(mine);
-            if (lm_lane() == 63) s_wsum[threadIdx.x >> 6] = incl;
-            if (lds_only) lm_lds_barrier(); else __syncthreads();
             unsigned tot = 0, before = 0;
+            if (nch <= LM_MB_SCAN_DIRECT) {
+                const int w0 = (int)(threadIdx.x >> 6) * 64 * LM_MB_ITEMS;      // first CC of this wave
+                for (int base = 0; base < nch; base += 64) {
+                    const int i = base + lm_lane();
+                    const unsigned c = (unsigned)__popcll(__ballot(i < nch && s_best[i] == 0xffffffffu));
+                    tot += c;
+                    before += (base < w0) ? c : 0u;
+                }
+            } else {
+                if (lm_lane() == 63) s_wsum[threadIdx.x >> 6] = incl;
+                if (lds_only) lm_lds_barrier(); else __syncthreads();
 #pragma unroll
-            for (int w = 0; w < LM_MB_RT / 64; w++) {
-                const unsigned t = s_wsum[w];
-                before += (w < (int)(threadIdx.x >> 6)) ? t : 0u;
-                tot += t;
+                for (int w = 0; w < LM_MB_RT / 64; w++) {
+                    const unsigned t = s_wsum[w];
+                    before += (w < (int)(threadIdx.x >> 6)) ? t : 0u;
+                    tot += t;
+                }
             }
             unsigned o = before + incl - mine;
 #pragma unroll
