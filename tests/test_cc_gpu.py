@@ -86,6 +86,14 @@ def test_full_size_1080p_label_vs_oracle(hip_lib, oracle_built):
     lab.close()
 
 
+def test_full_size_stream_1080p_vs_oracle(hip_lib, oracle_built):
+    """The first 96 frames of the bench stream (1920x1080, ~1100 CCs per frame) through 64-frame launches -- one full matching
+    batch, one partial -- vs the oracle: records, crops, uniques, assignments, tempo_count."""
+    frames = list(synth.binary_stream(256, 1080, 1920, seed=20213))[:96]
+    r = lm_checks.check_stream_oracle(hip_lib, frames, max_gap=85, max_batch=64)
+    assert len(r["unique_recs"]) > 1000
+
+
 def test_full_size_properties_4k(hip_lib):
     """3840x2160 (BASELINE.json config 5 size): size-independent properties instead of the oracle:
     relabelling the foreground mask of the labels reproduces them (idempotence), counts sum to the ink."""
