@@ -18,6 +18,7 @@
 // Per chunk a block stages in LDS the (16+KH-1) x (16+KW-1) x CK input patch (pixel stride CK+4 floats: the
 // 16 B A-fragment reads of 16 neighbouring pixels then fall on distinct banks) and the chunk's weights for ALL
 // taps, pre-packed on the host in fragment order [tap][kstep][nblock][lane][4].
+#include <mutex>
 #include "lm_common.h"
 
 #include <vector>
@@ -972,7 +973,7 @@ static int lm_small_layer(LmFcn* f, int layer, const float* in, int ips, int C, 
 
 // forward() of the non-reconstruction branch (:364-403) on one RGB frame resident on the device.
 // Outputs (device, fp32): d_out [h*w] binarization logit, d_text [h*w] text-mask logit, d_rec [3][h*w] reconstruction.
-extern "C" int lm_fcn_forward(LmFcn* f, const uint8_t* d_rgb, int h, int w, float* d_out, float* d_text, float* d_rec, void* stream)
+static int lm_fcn_forward_impl(LmFcn* f, const uint8_t* d_rgb, int h, int w, float* d_out, float* d_text, float* d_rec, void* stream)
 {
     if (!f || !d_rgb || h < 32 || w < 32 || h > f->max_h || w > f->max_w || (long long)h * w > (long long)f->max_h * f->max_w) {
         lm_set_error("lm_fcn_forward: bad arguments (frame %dx%d, network sized for %dx%d)", w, h, f ? f->max_w : 0, f ? f->max_h : 0);
@@ -1030,4 +1031,32 @@ extern "C" int lm_fcn_forward(LmFcn* f, const uint8_t* d_rgb, int h, int w, floa
     if (d_rec) hipLaunchKernelGGL(lm_k_nhwc4_to_chw3, dim3((unsigned)std::min<long long>((npx + 255) / 256, 8192)), dim3(256), 0, st, f->rec4, d_rec, npx);
     LM_HIP(hipGetLastError());
     return LM_OK;
+}
+
+// Forward passes are chained on the device even when they are issued on different HIP streams (or by different engines): two of
+// them running concurrently were measured to disturb each other (sporadic 1e-3 .. 2e-2 errors in the one-channel heads, none
+// with a single pass in flight or next to other kernels; DESIGN.md 7, open issue), so a pass waits for the event the previous
+// one recorded.
+static std::mutex g_fcn_mutex;
+#if !LM_HIP_EMULATED
+static hipEvent_t g_fcn_done = nullptr;
+static hipStream_t g_fcn_last_stream = nullptr;
+#endif
+
+extern "C" int lm_fcn_forward(LmFcn* f, const uint8_t* d_rgb, int h, int w, float* d_out, float* d_text, float* d_rec, void* stream)
+{
+    std::lock_guard<std::mutex> lock(g_fcn_mutex);
+#if !LM_HIP_EMULATED
+    hipStream_t st = (hipStream_t)stream;
+    if (!g_fcn_done) LM_HIP(hipEventCreateWithFlags(&g_fcn_done, hipEventDisableTiming));
+    else if (st != g_fcn_last_stream) LM_HIP(hipStreamWaitEvent(st, g_fcn_done, 0));
+#endif
+    const int rc = lm_fcn_forward_impl(f, d_rgb, h, w, d_out, d_text, d_rec, stream);
+#if !LM_HIP_EMULATED
+    if (rc == LM_OK) {
+        LM_HIP(hipEventRecord(g_fcn_done, st));
+        g_fcn_last_stream = st;
+    }
+#endif
+    return rc;
 }

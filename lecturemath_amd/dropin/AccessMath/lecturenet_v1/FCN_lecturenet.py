@@ -60,6 +60,19 @@ class FCN_LectureNet:
         """Extension: uint8 RGB [H,W,3] (numpy or device tensor) -> device fp32 (logit, text logit, reconstruction)."""
         return self._get_engine(int(rgb_u8.shape[0]), int(rgb_u8.shape[1])).forward(rgb_u8)
 
+    def binarize_frames_device(self, rgb_frames, binary_threshold=128):
+        """Extension for whole videos: uint8 RGB [n,H,W,3] (numpy or device tensor) -> device uint8 [n,H,W], the worker's inverted
+        binary (ink = 255; :452-467 + FCN_lecturenet_binarizer.py:54); nothing leaves the device."""
+        n, h, w = int(rgb_frames.shape[0]), int(rgb_frames.shape[1]), int(rgb_frames.shape[2])
+        eng = self._get_engine(h, w)
+        lib, be = eng.lib, eng.be
+        out = be.empty((n, h, w), np.uint8)
+        for i in range(n):
+            logits, _, _ = eng.forward(rgb_frames[i])
+            dst = out[i] if be.device else out[i:i + 1]
+            lib.check(lib.lm_threshold_invert(_lib.ptr(logits), _lib.ptr(dst), h * w, int(binary_threshold), be.stream()))
+        return out
+
     def binarize(self, PIL_image, return_others=False, force_binary=False, binary_treshold=128, apply_sigmoid=True):
         o_width, o_height = PIL_image.size
         width, height = o_width, o_height

@@ -57,7 +57,6 @@ class LecturePipeline:
         self.estimator = CCStabilityEstimator(self.width, self.height, c.get_float("CC_STABILITY_MIN_RECALL"),
                                               c.get_float("CC_STABILITY_MIN_PRECISION"), c.get_int("CC_STABILITY_MAX_GAP"), verbose)
         self.frame_times, self.frame_indices = [], []
-        self._labeler = None
 
     # ---- step 01 + 02 ------------------------------------------------------------------------------------------------
     def _stamp(self, n, times, indices):
@@ -74,19 +73,19 @@ class LecturePipeline:
     def add_rgb_frames(self, rgb, times=None, indices=None):
         """uint8 [n, H, W, 3]: FCN-LectureNet logits -> sigmoid * 255 >= threshold -> inverted binary (ink = 255), all on the device
         (FCN_lecturenet.py:452-467 + FCN_lecturenet_binarizer.py:54), then step 02."""
-        from lecturemath_amd import _lib, device
         if self.network is None:
             raise ValueError("LecturePipeline(network=...) is needed for RGB input")
         thr = self.configuration.get_int("FCN_BINARIZER_BINARY_THRESHOLD", 128)
         n = int(rgb.shape[0])
-        if self._labeler is None:
-            self._labeler = device.FrameLabeler(self.width, self.height, 1, self.lib)
-        out = self.be.empty((n, self.height, self.width), np.uint8)
-        px = self.height * self.width
-        for i in range(n):
-            logits, _, _ = self.network.forward_logits(rgb[i])
-            dst = out[i] if not isinstance(out, np.ndarray) else out[i:i + 1]
-            self.lib.check(self.lib.lm_threshold_invert(_lib.ptr(logits), _lib.ptr(dst), px, thr, self.be.stream()))
+        if hasattr(self.network, "binarize_frames_device"):
+            out = self.network.binarize_frames_device(rgb, thr)
+        else:                                   # any object with forward_logits(rgb_u8 [H,W,3]) -> (logits, text, rec) on the device
+            from lecturemath_amd import _lib
+            out = self.be.empty((n, self.height, self.width), np.uint8)
+            for i in range(n):
+                logits, _, _ = self.network.forward_logits(rgb[i])
+                dst = out[i] if not isinstance(out, np.ndarray) else out[i:i + 1]
+                self.lib.check(self.lib.lm_threshold_invert(_lib.ptr(logits), _lib.ptr(dst), self.height * self.width, thr, self.be.stream()))
         self.estimator.add_frames_device(out)
         self._stamp(n, times, indices)
 

@@ -190,3 +190,34 @@ def test_fcn_shipped_config_vs_oracle(hip_lib, precision):
     assert np.abs(text - t[0, 0].numpy()).max() <= 1e-3
     assert np.abs(rec - r[0].numpy()).max() <= 1e-3
     eng.close()
+
+
+def test_fcn_two_engines_on_two_streams(hip_lib):
+    """Two engines fed from two HIP streams at 1080p give the single-stream logits bit for bit: the library chains forward
+    passes on the device (two passes actually overlapping were measured to disturb each other's one-channel heads)."""
+    import torch
+    from lecturemath_amd import _lib, fcn
+    from oracle import fcn as ofcn
+    h, w = 1080, 1920
+    sd = ofcn.random_state_dict(ofcn.SHIPPED_WIDTHS, pixel_kernel=7, seed=0)
+    engines = []
+    for _ in range(2):
+        e = fcn.FcnEngine(ofcn.SHIPPED_WIDTHS, 7, 3, h, w, hip_lib, precision="f16x3")
+        e.load_state_dict(sd)
+        engines.append(e)
+    rgb, _ = synth.whiteboard_rgb(h, w, 1500, seed=20211)
+    d = torch.from_numpy(rgb).cuda()
+    gold = [t.clone() for t in engines[0].forward(d)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for _ in range(4):
+        res = []
+        for e, st in zip(engines, streams):
+            with torch.cuda.stream(st):
+                res.append(e.forward(d))
+        torch.cuda.synchronize()
+        for r in res:
+            for a, b in zip(gold, r):
+                assert bool((a == b).all())
+    for e in engines:
+        e.close()
