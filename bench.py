@@ -277,6 +277,20 @@ def main():
                 sl["gr"] = None
         return info
 
+    def stream_digest(fs):
+        """sha1 over everything steps 01-02 leave in the stream: CC records with their unique assignments, frame offsets, bit
+        crops, active list"""
+        import hashlib
+        r = fs.read()
+        h = hashlib.sha1()
+        for key in ("rec", "frame_off", "crop_off", "crop", "active"):
+            h.update(np.ascontiguousarray(r[key]).tobytes())
+        return h.hexdigest()
+
+    # one step with nothing else in flight: the reference result for the steps that overlap in the pipeline
+    front(slots[0])
+    torch.cuda.synchronize()
+    digest_alone = stream_digest(slots[0]["fs"])
     run_steps(max(a.warmup, 0))
     torch.cuda.synchronize()
     fs = slots[0]["fs"]
@@ -312,6 +326,9 @@ def main():
     ms, calls, nfr = ctypes.c_double(tot_ms), ctypes.c_int64(tot_calls), ctypes.c_int64(tot_fr)
     k1 = fs.counters()
     assert k0 is None or k1 == k0, "steps are not reproducible: %r vs %r" % (k0, k1)
+    # every slot's last step (they ran overlapped) left bit for bit what the step alone left
+    for sl in slots[:min(depth, a.steps)]:
+        assert stream_digest(sl["fs"]) == digest_alone, "a pipelined step differs from the same step run alone"
 
     if rank != 0:
         if world > 1:
