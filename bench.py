@@ -253,6 +253,8 @@ def main():
             sys.stderr.write("   step 03 worker: %.3f ms (from %.3f ms)\n" % ((time.perf_counter() - tq) * 1e3, tq * 1e3))
         return info
 
+    max_fronts = int(os.environ.get("LM_BENCH_MAX_FRONTS", "0"))
+
     def run_steps(k):
         pending = [None] * depth
         info = None
@@ -261,6 +263,8 @@ def main():
             sl = slots[i % depth]
             if pending[i % depth] is not None:
                 info = pending[i % depth].result()          # the slot's previous step must be finished before it is reused
+            if max_fronts and i >= max_fronts:           # at most max_fronts steps' 01-02 halves queued on the GPU
+                slots[(i - max_fronts) % depth]["done"].synchronize()
             tb = time.perf_counter()
             front(sl)
             pending[i % depth] = pool.submit(back, sl)
