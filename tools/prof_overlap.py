@@ -5,9 +5,12 @@ import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name,start,end,stream_id from kernels order by start").fetchall()
 th = [r for r in rows if "threshold" in r[0]]
-skip = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+# bench.py: one step alone (reference digest) + 2 warm-up steps, then the timed steps, then one more step alone (un-shared timing)
+skip = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 t0 = th[skip][1]
-R = [r for r in rows if r[1] >= t0]
+last_alone = th[-1][1] if len(th) > skip + 1 else max(r[2] for r in rows) + 1
+t_end = max(r[2] for r in rows if "lm_k_render_frames" in r[0] and r[1] < last_alone)
+R = [r for r in rows if r[1] >= t0 and r[2] <= t_end]
 def union(iv):
     iv = sorted(iv); out = []; cs, ce = iv[0]
     for s, e in iv[1:]:
@@ -24,7 +27,7 @@ def inter(a, b):
         else: j += 1
     return t
 t1 = max(r[2] for r in R)
-steps = len(th) - skip
+steps = len([r for r in th if t0 <= r[1] < t_end])
 allu = union([(r[1], r[2]) for r in R])
 print("steps %d: wall %.2f ms/step, kernel sum %.2f, busy %.2f, idle %.2f" % (steps, (t1 - t0) / 1e6 / steps, sum(r[2] - r[1] for r in R) / 1e6 / steps,
       length(allu) / 1e6 / steps, ((t1 - t0) - length(allu)) / 1e6 / steps))
