@@ -42,7 +42,7 @@ def parse():
     p.add_argument("--cpu-frames", type=int, default=200, help="prefix of the stream timed on the CPU oracle (0 = skip)")
     p.add_argument("--no-labels", action="store_true", help="do not materialise the int32 label image")
     p.add_argument("--no-pipeline", action="store_true", help="do not overlap step 03 of one stream with steps 01-02 of the next")
-    p.add_argument("--depth", type=int, default=3, help="streams in flight (pipeline slots); depth-1 host workers run step 03")
+    p.add_argument("--depth", type=int, default=5, help="streams in flight (pipeline slots); depth-1 host workers run step 03")
     p.add_argument("--seed", type=int, default=20213)
     p.add_argument("--fcn-precision", default="f16x3", choices=["f16x3", "fp32"],
                    help="MFMA operand format of the FCN conv stack (fp32 accumulate in both)")
@@ -178,12 +178,14 @@ def main():
     del mask
     gen_s = time.time() - t0
 
-    # Two pipeline slots: while slot A's stream is in step 03 (host list bookkeeping + group images + frame rendering, on
-    # its own HIP stream, driven by a worker thread -- ctypes releases the GIL), slot B labels and matches the next stream.
-    # Every step still does all of its work inside the timed region; only consecutive, independent steps overlap.
+    # Pipeline slots (--depth): while some slots' streams are in step 03 (host list bookkeeping + group images + frame rendering,
+    # on their own HIP streams, driven by worker threads -- ctypes releases the GIL), the next slots label and match the next
+    # streams.  Every step still does all of its work inside the timed region; only consecutive, independent steps overlap.
     import concurrent.futures
     depth = 1 if a.no_pipeline else max(2, a.depth)
     prio = os.environ.get("LM_BENCH_PRIO", "front")       # which side's HIP streams get the higher priority: front | back | none
+    # unless LM_BENCH_NO_SPLIT is set the slot's own stream only carries the matching kernels: normal priority (see `split` below)
+    front_prio = -1 if (prio == "front" and (depth == 1 or os.environ.get("LM_BENCH_NO_SPLIT"))) else 0
     slots = []
     for _ in range(depth):
         fs = device.FrameStream(W, H, F, 0.85, 0.85, 85, 20, max_batch=a.batch, lib=lib)
@@ -191,19 +193,21 @@ def main():
                       "labels": None if a.no_labels else torch.empty((a.batch, H, W), dtype=torch.int32, device="cuda"),
                       "clean": torch.empty((a.batch, H, W), dtype=torch.uint8, device="cuda"),
                       # steps 01-02 are the bandwidth-bound part: their stream gets the higher priority, step 03's small kernels fill in
-                      "s_front": torch.cuda.Stream(priority=-1 if prio == "front" else 0), "s_back": torch.cuda.Stream(priority=-1 if prio == "back" else 0),
+                      "s_front": torch.cuda.Stream(priority=front_prio), "s_back": torch.cuda.Stream(priority=-1 if prio == "back" else 0),
                       "done": torch.cuda.Event(),
                       "rdone": torch.cuda.Event(), "gr": None, "recorded": []})
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, depth - 1))
 
-    # LM_BENCH_SPLIT=1 (experiment, measured no gain: 66-71 k frames/s against 68-70 k): the bandwidth-bound half of steps 01-02
-    # (threshold, labelling, records: "wide") of ALL slots goes through one HIP stream, so two labelling launches never share the
-    # GPU; the temporal matching of a slot (small latency-bound kernels) runs on the slot's own stream behind an event per batch,
-    # under the wide kernels of the next batches / the next step.
-    split = depth > 1 and bool(os.environ.get("LM_BENCH_SPLIT"))
+    # The bandwidth-bound half of steps 01-02 (threshold, labelling, records: "wide") of ALL slots goes through ONE high-priority
+    # HIP stream, so two labelling launches never share the GPU; the temporal matching of a slot (small latency-bound kernels,
+    # among them a single-workgroup replay) runs on the slot's own normal-priority stream behind an event per batch, under the
+    # wide kernels of the next batches / the next steps.  (The streams must differ in priority: with both high the runtime puts
+    # them on one hardware queue and nothing overlaps -- 62-71 k frames/s; as below 73-76 k at depth 5.)  LM_BENCH_NO_SPLIT=1:
+    # every slot's steps 01-02 on its own high-priority stream (67-71 k at depth 3, with dips to 50-55 k).
+    split = depth > 1 and not os.environ.get("LM_BENCH_NO_SPLIT")
     s_wide = torch.cuda.Stream(priority=-1 if prio == "front" else 0) if split else None
 
-    def front(sl):
+    def front(sl, split=split):
         """steps 01 (threshold) + 02 (label, records, matching) of one stream"""
         fs, binary, labels = sl["fs"], sl["binary"], sl["labels"]
         s_rec = s_wide if split else sl["s_front"]
@@ -291,8 +295,8 @@ def main():
             h.update(np.ascontiguousarray(r[key]).tobytes())
         return h.hexdigest()
 
-    # one step with nothing else in flight: the reference result for the steps that overlap in the pipeline
-    front(slots[0])
+    # one step with nothing else in flight, on one stream: the reference result for the steps that overlap in the pipeline
+    front(slots[0], split=False)
     torch.cuda.synchronize()
     digest_alone = stream_digest(slots[0]["fs"])
     run_steps(max(a.warmup, 0))
@@ -345,7 +349,7 @@ def main():
     if depth > 1:
         sl = slots[0]
         lib.check(lib.lm_ctx_set_profiling(sl["fs"].labeler.ctx, 1))
-        front(sl)
+        front(sl, split=False)
         torch.cuda.synchronize()
         ms2, calls2, nfr2 = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
         lib.check(lib.lm_ctx_profile_read(sl["fs"].labeler.ctx, ctypes.addressof(ms2), ctypes.addressof(calls2), ctypes.addressof(nfr2)))
