@@ -83,12 +83,11 @@ def fcn_flops(widths, pk, kk, h, w):
 def main_fcn(a):
     import torch
     from lecturemath_amd import _lib, fcn, synth
-    from oracle import fcn as ofcn
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     lib = _lib.load()
     H, W = a.height, a.width
-    widths, pk = ofcn.SHIPPED_WIDTHS, 7
-    sd = ofcn.random_state_dict(widths, pixel_kernel=pk, seed=0)
+    widths, pk = synth.FCN_SHIPPED_WIDTHS, 7
+    sd = synth.fcn_random_state_dict(widths, pixel_kernel=pk, seed=0)
     eng = fcn.FcnEngine(widths, pk, 3, H, W, lib, precision=a.fcn_precision)
     eng.load_state_dict(sd)
     rgb, _ = synth.whiteboard_rgb(H, W, 1500, seed=20211)
@@ -110,6 +109,7 @@ def main_fcn(a):
     tflops = fl / (gpu_ms * 1e-3) / 1e12
     cpu = None
     if a.cpu_frames > 0:
+        from oracle import fcn as ofcn          # the checker / CPU baseline leg only
         torch.set_num_threads(os.cpu_count())
         t0 = time.perf_counter()
         with torch.no_grad():

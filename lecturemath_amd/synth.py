@@ -114,3 +114,48 @@ def logits_from_binary(binary, seed=0, margin=4.0, noise=0.5):
     lg = np.where(binary > 0, -margin, margin).astype(np.float32)
     lg += (rng.random(binary.shape, dtype=np.float32) - 0.5) * (2.0 * noise)
     return lg
+
+
+# FCN-LectureNet at the shipped configuration (configs/FCN_LectureNet.conf:109-132):
+# (down 1..5, mid, then (transposed conv, conv) widths of up blocks 5..1, pixel branch 1, 2)
+FCN_SHIPPED_WIDTHS = (48, 96, 192, 384, 768, 768, 384, 384, 192, 192, 96, 96, 48, 48, 32, 32, 32, 16)
+
+
+def fcn_random_state_dict(widths=FCN_SHIPPED_WIDTHS, pixel_kernel=7, kernel=3, seed=0):
+    """Random-init weights with the reference network's state_dict keys and shapes (there are no checkpoints offline): scaled
+    normal conv weights, small biases, BatchNorm statistics away from (0, 1) so that folding them matters."""
+    import torch
+    gen = torch.Generator().manual_seed(seed)
+    d1, d2, d3, d4, d5, mid, u5, c5, u4, c4, u3, c3, u2, c2, u1, c1, pm1, pm2 = widths
+    sd = {}
+
+    def add_conv(name, shape, fan):
+        sd[name + ".weight"] = torch.randn(shape, generator=gen) * (2.0 / fan) ** 0.5
+        sd[name + ".bias"] = (torch.rand(shape[0] if name.startswith("conv") or name.startswith("mid") else shape[1], generator=gen) - 0.5) * 0.2
+
+    def add_bn(name, c):
+        sd[name + ".weight"] = 0.5 + torch.rand(c, generator=gen)
+        sd[name + ".bias"] = torch.randn(c, generator=gen) * 0.1
+        sd[name + ".running_mean"] = torch.randn(c, generator=gen) * 0.1
+        sd[name + ".running_var"] = 0.5 + torch.rand(c, generator=gen)
+        sd[name + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.int64)
+
+    def add_block(name, cin, cout, k):
+        add_conv(name + ".0", (cout, cin, k, k), (cin + cout) * k * k)
+        add_bn(name + ".1", cout)
+
+    chain = [3, d1, d2, d3, d4, d5]
+    for n in range(1, 6):
+        add_block("conv_down_block_%d" % n, chain[n - 1], chain[n], kernel)
+    add_block("mid_block", d5, mid, kernel)
+    for n, cin, up, out, skip in ((5, mid, u5, c5, d5), (4, c5, u4, c4, d4), (3, c4, u3, c3, d3), (2, c3, u2, c2, d2), (1, c2, u1, c1, d1)):
+        add_conv("transposed_conv_%d" % n, (cin, up, 2, 2), (cin + up) * 4)
+        add_bn("upsample_block_%d.0" % n, up)
+        add_block("conv_up_block_%d" % n, up + skip, out, kernel)
+    add_block("conv_pixels_1", 3 + c1, pm1, pixel_kernel)
+    add_block("conv_pixels_2", 3 + pm1, pm2, pixel_kernel)
+    add_block("conv_out", 3 + pm2, 1, pixel_kernel)
+    add_block("conv_text_mask_out", c1, 1, pixel_kernel)
+    add_block("conv_reconstruct", c1, 3, kernel)
+    return sd
+
