@@ -1,20 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- frames/sec of the hot path (binarize-threshold + CC labelling + CC records + temporal matching
-+ space-time grouping with frame reconstruction) on a synthetic 1080p stream, per BASELINE.json (configs[2], the configuration the
-metric is quoted on: the synthetic 1080p stream on one MI355X; `--frames 10000` is its full length).
+"""bench.py -- frames/sec of the hot path on BASELINE.json configs[2]: ONE synthetic 10,000-frame 1080p stream per step,
+fp32 logits resident in HBM -> threshold+invert -> CC labelling (int32 label image written) -> CC statistics / records / bit
+crops -> temporal matching over the whole stream (state carried across all 10,000 frames) -> step 03 (grouping, ages, group
+images) -> reconstruction of all 10,000 frames.
 
-A "step" is one pass of the hot path over one synthetic stream of --frames frames whose fp32 logits are
-already resident in HBM.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
-processes an independent stream of the same shape (the reference's outer loop is over independent
-lectures, console_ui_process.py:121-148), no data-path collective: weak scaling.
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+N = 1: a "step" is one pass over the whole stream.  Batches of the stream pipeline inside a step (matching of batch k runs on
+its own HIP stream under the labelling of batch k+1) and step 03 of step i overlaps steps 01-02 of step i+1 (--depth slots;
+--depth 1 disables that).  N > 1 (configs[3]): the SAME stream is frame-range sharded (contiguous blocks of ceil(F/N) frames
+per rank, lecturemath_amd/sharded.py): every rank thresholds + labels its block, the packed CC records travel to rank 0 in
+one RCCL transfer per rank, rank 0 replays the matching and runs step 03; strong scaling, digests equal to N = 1.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     the CC-labelling launch sequence (lm_label_batch: pack, rowscan, rowoff, union, resolve,
-               write_labels), HBM bound: achieved = 5 B/px * W*H * frames_per_launch / mean launch duration,
-               timed live with HIP events on the launching stream inside the timed region
-  cpu_baseline the oracle (C port of the reference path, single thread) on a bounded prefix of the same stream
+  roofline      labelling launch sequence (lm_label_batch), HBM bound: 5 B/px x W x H x frames per launch / mean launch
+                duration, HIP events on the launching stream INSIDE the timed region
+  cpu_baseline  the C oracle (single thread) on a bounded prefix of the same stream
+  parity        sha256 digests of the step 02/03 products of the last timed step vs the digests the reference produced on the
+                same stream (tests/golden/g9_stream1080p_digests.json)
+  fcn           configs[1] measured in the same process: FCN-LectureNet forward at 1080p (ms/frame, algorithmic TFLOP/s,
+                max |logit - oracle|) and the CPU oracle's rate
+  e2e_rgb       RGB frames -> FCN -> threshold -> ... -> step 03 -> reconstructed frames, frames/s
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -25,34 +34,34 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALGO_BYTES_PER_PX = 5           # 1 B uint8 in + 4 B int32 label out
+MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16/bf16 MFMA peak
+FCN_MFMA_PER_PRODUCT = {"f16": 1, "f16x2": 2, "f16x3": 3}
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=40,
-                   help="timed steps; a step is one 256-frame stream, so the default run covers the 10k frames of BASELINE configs[2]")
-    p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--frames", type=int, default=256, help="frames per stream (= per step)")
+    p.add_argument("--steps", type=int, default=5, help="timed steps; a step is one pass over the whole stream")
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--frames", type=int, default=10000, help="frames of the stream (BASELINE configs[2]: 10,000)")
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--batch", type=int, default=64, help="frames per labelling launch")
     p.add_argument("--cpu-frames", type=int, default=200, help="prefix of the stream timed on the CPU oracle (0 = skip)")
     p.add_argument("--no-labels", action="store_true", help="do not materialise the int32 label image")
-    p.add_argument("--no-pipeline", action="store_true", help="do not overlap step 03 of one stream with steps 01-02 of the next")
-    p.add_argument("--depth", type=int, default=5, help="streams in flight (pipeline slots); depth-1 host workers run step 03")
+    p.add_argument("--depth", type=int, default=2, help="N = 1: streams in flight (step 03 of one step under steps 01-02 of the next); 1 = none")
     p.add_argument("--seed", type=int, default=20213)
-    p.add_argument("--fcn-precision", default="f16x3", choices=["f16x3", "fp32"],
-                   help="MFMA operand format of the FCN conv stack (fp32 accumulate in both)")
+    p.add_argument("--fcn-precision", default=os.environ.get("LM_FCN_PRECISION", "f16x3"), choices=["f16", "f16x2", "f16x3", "fp32"],
+                   help="MFMA operand format of the FCN conv stack (fp32 accumulate in all)")
+    p.add_argument("--fcn-frames", type=int, default=5, help="frames timed for the `fcn` object (0 = skip fcn and e2e_rgb)")
+    p.add_argument("--e2e-frames", type=int, default=64, help="RGB frames of the `e2e_rgb` measurement (0 = skip)")
+    p.add_argument("--no-fcn-oracle", action="store_true", help="skip the CPU oracle forward pass (max |logit diff|, FCN cpu baseline)")
     p.add_argument("--workload", default="stream", choices=["stream", "fcn"],
-                   help="stream = configs[2] (headline metric); fcn = configs[1], FCN-LectureNet inference on one 1080p frame")
+                   help="stream = configs[2]/[3] (headline metric); fcn = configs[1] alone")
     return p.parse_args()
-
-
-MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
-MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16/bf16 MFMA peak (spec); the f16x3 path executes 3 MFMA flops per algorithmic flop
 
 
 def fcn_flops(widths, pk, kk, h, w):
@@ -80,71 +89,164 @@ def fcn_flops(widths, pk, kk, h, w):
     return f
 
 
-def main_fcn(a):
+# ----------------------------------------------------------------------------------------------------------------------
+# configs[1]: FCN-LectureNet inference at 1080p, measured in this process
+# ----------------------------------------------------------------------------------------------------------------------
+def measure_fcn(a, lib, H, W, n_frames, with_oracle):
     import torch
-    from lecturemath_amd import _lib, fcn, synth
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    lib = _lib.load()
-    H, W = a.height, a.width
+    from lecturemath_amd import fcn, synth
     widths, pk = synth.FCN_SHIPPED_WIDTHS, 7
     sd = synth.fcn_random_state_dict(widths, pixel_kernel=pk, seed=0)
     eng = fcn.FcnEngine(widths, pk, 3, H, W, lib, precision=a.fcn_precision)
     eng.load_state_dict(sd)
     rgb, _ = synth.whiteboard_rgb(H, W, 1500, seed=20211)
     d_rgb = torch.from_numpy(rgb).cuda()
-    lab = None
-    for _ in range(a.warmup):
-        eng.forward(d_rgb)
+    for _ in range(2):
+        out, text, rec = eng.forward(d_rgb)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(a.steps):
+    for _ in range(n_frames):
         out, text, rec = eng.forward(d_rgb)
     e1.record()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    gpu_ms = e0.elapsed_time(e1) / a.steps
+    wall = time.perf_counter() - t0
+    gpu_ms = e0.elapsed_time(e1) / n_frames
     fl = fcn_flops(widths, pk, 3, H, W)
     tflops = fl / (gpu_ms * 1e-3) / 1e12
-    cpu = None
-    if a.cpu_frames > 0:
+    res = {"workload": "configs[1]: FCN-LectureNet (shipped widths, 15.8 M params, random init + randomised BN), one %dx%d frame" % (W, H),
+           "precision": a.fcn_precision, "frames_timed": n_frames, "ms_per_frame": round(gpu_ms, 3), "frames_per_s": round(n_frames / wall, 2),
+           "gflop_per_frame": round(fl / 1e9, 1), "algorithmic_tflops": round(tflops, 2)}
+    if a.fcn_precision == "fp32":
+        res.update({"peak_tflops": MFMA_F32_PEAK_TFLOPS, "frac_of_peak_algorithmic": round(tflops / MFMA_F32_PEAK_TFLOPS, 4)})
+    else:
+        k = FCN_MFMA_PER_PRODUCT[a.fcn_precision]
+        res.update({"peak_tflops": MFMA_F16_PEAK_TFLOPS, "frac_of_peak_algorithmic": round(tflops / MFMA_F16_PEAK_TFLOPS, 4),
+                    "mfma_per_product": k, "executed_tflops": round(k * tflops, 2)})
+    if with_oracle:
         from oracle import fcn as ofcn          # the checker / CPU baseline leg only
         torch.set_num_threads(os.cpu_count())
         t0 = time.perf_counter()
         with torch.no_grad():
             o, t, r = ofcn.forward(sd, ofcn.prepare_image(rgb))
         cdt = time.perf_counter() - t0
-        err = float((out.cpu() - o[0, 0]).abs().max())
-        cpu = {"value": round(1.0 / cdt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": "one 1080p frame, oracle/fcn.py (torch fp32 CPU functional restatement); max |logit diff| vs HIP = %.2e" % err}
-    out = {
-        "metric": "frames/sec FCN-LectureNet binarizer inference @1080p", "value": round(a.steps / dt, 3), "unit": "frames/s", "n_gpus": 1,
-        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if a.fcn_precision == "fp32" else "f16x3 (fp16-split operands, fp32 accumulate)", "data": "synthetic",
-        "config": {"workload": "configs[1]: FCN-LectureNet (shipped widths, 15.8 M params, random init + randomised BN) forward on one "
-                               "%dx%d synthetic whiteboard frame" % (W, H), "gflop_per_frame": round(fl / 1e9, 1)},
-        "roofline": ({"bound": "mfma", "kernel": "lm_fcn_forward[lm_k_conv_mfma + heads]", "achieved": round(tflops, 2),
-                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-                      "launch_ms": round(gpu_ms, 3)} if a.fcn_precision == "fp32" else
-                     {"bound": "mfma", "kernel": "lm_fcn_forward[lm_k_conv_mfma_h + heads]", "achieved": round(3 * tflops, 2),
-                      "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(3 * tflops / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
-                      "launch_ms": round(gpu_ms, 3), "algorithmic_tflops": round(tflops, 2),
-                      "note": "achieved counts the executed f16 MFMA flops (3 per algorithmic flop: hi.hi + hi.lo + lo.hi)"}),
-        "cpu_baseline": cpu}
-    # MFMA-pipe utilisation from the PMC pass committed under profiles/ (not collectable live): busy cycles of the matrix pipe
-    # over the conv-stack dispatches, as opposed to `frac` above, which prices useful flops against the dense peak
-    ppath = os.path.join(ROOT, "profiles", "r01_fcn_mfma_pmc_%s.json" % a.fcn_precision)
-    if os.path.exists(ppath) and (W, H) == (1920, 1080):
-        out["roofline"]["mfma_util_pmc"] = json.load(open(ppath))["conv_stack_mfma_util"]
-        out["roofline"]["mfma_util_pmc_source"] = "profiles/" + os.path.basename(ppath) + " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)"
+        res["max_abs_logit_diff_vs_oracle"] = float((out.cpu() - o[0, 0]).abs().max())
+        res["max_abs_text_diff_vs_oracle"] = float((text.cpu() - t[0, 0]).abs().max())
+        res["max_abs_rec_diff_vs_oracle"] = float((rec.cpu() - r[0]).abs().max())
+        res["tolerance"] = 1e-3
+        res["cpu_baseline"] = {"value": round(1.0 / cdt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "one 1080p frame, oracle/fcn.py (torch fp32 CPU restatement of FCN_lecturenet.py:260-403)"}
+    return res, eng, sd
+
+
+def measure_e2e_rgb(a, lib, eng, H, W, n_frames):
+    """RGB uint8 frames resident in HBM -> FCN logits -> threshold+invert -> label/records/matching -> step 03 -> all frames
+    reconstructed.  Random-init weights: the binarization is whatever the network emits (CC counts are reported)."""
+    import torch
+    from lecturemath_amd import _lib, device, synth
+    rgb = torch.from_numpy(np.stack(list(synth.whiteboard_stream(n_frames, H, W)))).cuda()
+    logits = torch.empty((n_frames, H, W), dtype=torch.float32, device="cuda")
+    binary = torch.empty((n_frames, H, W), dtype=torch.uint8, device="cuda")
+    clean = torch.empty((n_frames, H, W), dtype=torch.uint8, device="cuda")
+    labels = torch.empty((min(a.batch, n_frames), H, W), dtype=torch.int32, device="cuda")
+    fs = device.FrameStream(W, H, n_frames, 0.85, 0.85, 85, 20, max_batch=min(a.batch, n_frames), max_ccs=n_frames * 131072,
+                            max_crop_words=n_frames * (1 << 21), lib=lib)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def once():
+        fs.reset()
+        for i in range(n_frames):
+            lib.check(lib.lm_fcn_forward(eng.handle, rgb[i].data_ptr(), H, W, logits[i].data_ptr(), None, None, st))
+        lib.check(lib.lm_threshold_invert(logits.data_ptr(), binary.data_ptr(), n_frames * H * W, 128, st))
+        for f0 in range(0, n_frames, a.batch):
+            n = min(a.batch, n_frames - f0)
+            lib.check(lib.lm_stream_push(fs.handle, binary[f0:f0 + n].data_ptr(), n, labels.data_ptr(), st))
+        gr = device.Grouping(fs, max_gap=85, min_times=3, t_window=5, min_recall=0.5, img_threshold=0.5, reconstruct=True)
+        gr.render(0, n_frames, clean)
+        torch.cuda.synchronize()
+        sc = gr.array("scalars")
+        gr.close()
+        return sc
+
+    try:
+        once()
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            sc = once()
+        dt = (time.perf_counter() - t0) / reps
+        k = fs.counters()
+        return {"workload": "%d RGB %dx%d frames of one evolving synthetic whiteboard, resident in HBM: FCN (%s) -> threshold+invert -> label -> records -> "
+                            "matching -> step 03 -> %d reconstructed frames" % (n_frames, W, H, a.fcn_precision, n_frames),
+                "frames": n_frames, "value": round(n_frames / dt, 2), "unit": "frames/s", "ms_per_frame": round(dt / n_frames * 1e3, 3),
+                "stream": {"n_cc": k["n_cc"], "n_unique": k["n_unique"], "n_groups": int(sc[2])}}
+    except _lib.LecturemathError as e:
+        return {"error": str(e)}
+    finally:
+        fs.close()
+
+
+def main_fcn(a):
+    import torch
+    from lecturemath_amd import _lib
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    lib = _lib.load()
+    res, eng, _ = measure_fcn(a, lib, a.height, a.width, max(a.steps, 1), not a.no_fcn_oracle and a.cpu_frames > 0)
+    fp32 = a.fcn_precision == "fp32"
+    tfl = res["algorithmic_tflops"] if fp32 else res["executed_tflops"]
+    peak = MFMA_F32_PEAK_TFLOPS if fp32 else MFMA_F16_PEAK_TFLOPS
+    out = {"metric": "frames/sec FCN-LectureNet binarizer inference @1080p", "value": res["frames_per_s"], "unit": "frames/s", "n_gpus": 1,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_frame"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32" if fp32 else a.fcn_precision + " operands, fp32 accumulate", "data": "synthetic",
+           "config": {"workload": res["workload"], "gflop_per_frame": res["gflop_per_frame"]},
+           "roofline": {"bound": "mfma", "kernel": "lm_fcn_forward[conv stack]", "achieved": tfl, "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(tfl / peak, 4), "traffic": None, "launch_ms": res["ms_per_frame"],
+                        "algorithmic_tflops": res["algorithmic_tflops"],
+                        "note": "achieved counts executed MFMA flops (%d per algorithmic flop)" % (1 if fp32 else res["mfma_per_product"])},
+           "cpu_baseline": res.get("cpu_baseline"), "fcn": res}
     print(json.dumps(out))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# configs[2] / configs[3]: the stream
+# ----------------------------------------------------------------------------------------------------------------------
+def make_logits(torch, synth, F, H, W, seed, f0, f1, chunk=250):
+    """fp32 logits of frames [f0, f1) of the stream, resident in HBM (83 GB for 10,000 frames at 1080p): +-4 around the ink
+    mask plus uniform noise, so that threshold+invert reproduces the generator's frame.  The generator
+    is sequential, so every rank walks the whole stream and keeps its block."""
+    logits = torch.empty((f1 - f0, H, W), dtype=torch.float32, device="cuda")
+    gen = torch.Generator(device="cuda")
+    buf = []
+
+    def flush(first):
+        if not buf:
+            return
+        mask = torch.from_numpy(np.stack(buf)).cuda()
+        gen.manual_seed(1234 + first)
+        dst = logits[first - f0:first - f0 + len(buf)]
+        dst.copy_(torch.where(mask > 0, -4.0, 4.0))
+        dst += torch.rand(dst.shape, generator=gen, device="cuda", dtype=torch.float32) - 0.5
+        buf.clear()
+
+    first = f0
+    for t, fr in enumerate(synth.binary_stream(min(F, f1), H, W, seed=seed)):
+        if t < f0:
+            continue
+        buf.append(fr)
+        if len(buf) == chunk:
+            flush(first)
+            first = t + 1
+    flush(first)
+    return logits
 
 
 def main():
     a = parse()
     if a.workload == "fcn":
         return main_fcn(a)
+    import concurrent.futures
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -162,78 +264,88 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    from lecturemath_amd import _lib, device, synth
+    from lecturemath_amd import _lib, device, digests, sharded, synth
     lib = _lib.load()
     assert lib.is_device_build
 
-    H, W, F = a.height, a.width, a.frames
-    # ---- synthetic stream (host, numpy) -> logits resident in HBM
+    H, W, F, B = a.height, a.width, a.frames, a.batch
+    f_lo, f_hi = sharded.frame_range(F, rank, world)
+    n_mine = f_hi - f_lo
     t0 = time.time()
-    frames_host = np.stack(list(synth.binary_stream(F, H, W, seed=a.seed + rank)))
-    mask = torch.from_numpy(frames_host).cuda()
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(1234 + rank)
-    logits = torch.where(mask > 0, -4.0, 4.0).to(torch.float32)
-    logits += (torch.rand(logits.shape, generator=gen, device="cuda", dtype=torch.float32) - 0.5)
-    del mask
+    logits = make_logits(torch, synth, F, H, W, a.seed, f_lo, f_hi)
+    torch.cuda.synchronize()
     gen_s = time.time() - t0
 
-    # Pipeline slots (--depth): while some slots' streams are in step 03 (host list bookkeeping + group images + frame rendering,
-    # on their own HIP streams, driven by worker threads -- ctypes releases the GIL), the next slots label and match the next
-    # streams.  Every step still does all of its work inside the timed region; only consecutive, independent steps overlap.
-    import concurrent.futures
-    depth = 1 if a.no_pipeline else max(2, a.depth)
-    prio = os.environ.get("LM_BENCH_PRIO", "front")       # which side's HIP streams get the higher priority: front | back | none
-    # unless LM_BENCH_NO_SPLIT is set the slot's own stream only carries the matching kernels: normal priority (see `split` below)
-    front_prio = -1 if (prio == "front" and (depth == 1 or os.environ.get("LM_BENCH_NO_SPLIT"))) else 0
+    # capacities of a stream (records 32 B, crop words 4 B; sized from the generator's densities with headroom -- a capacity
+    # error is raised by the library, never silent)
+    cap_frames = F if rank == 0 else max(n_mine, 1)
+    max_ccs = cap_frames * 4096
+    max_words = cap_frames * (1 << 17)
+
+    depth = max(1, a.depth) if world == 1 else 1
+    prio = os.environ.get("LM_BENCH_PRIO", "front")
+    split = not os.environ.get("LM_BENCH_NO_SPLIT")
+    # The bandwidth-bound half of steps 01-02 (threshold, labelling, records: "wide") of ALL slots goes through ONE high-priority
+    # HIP stream, so two labelling launches never share the GPU; the temporal matching of a slot (small latency-bound kernels)
+    # runs on the slot's own normal-priority stream behind an event per batch, under the wide kernels of the next batches.
+    # (The streams must differ in priority: with both high the runtime puts them on one hardware queue and nothing overlaps.)
+    s_wide = torch.cuda.Stream(priority=-1 if prio == "front" else 0)
     slots = []
     for _ in range(depth):
-        fs = device.FrameStream(W, H, F, 0.85, 0.85, 85, 20, max_batch=a.batch, lib=lib)
-        slots.append({"fs": fs, "binary": torch.empty((F, H, W), dtype=torch.uint8, device="cuda"),
-                      "labels": None if a.no_labels else torch.empty((a.batch, H, W), dtype=torch.int32, device="cuda"),
-                      "clean": torch.empty((a.batch, H, W), dtype=torch.uint8, device="cuda"),
-                      # steps 01-02 are the bandwidth-bound part: their stream gets the higher priority, step 03's small kernels fill in
-                      "s_front": torch.cuda.Stream(priority=front_prio), "s_back": torch.cuda.Stream(priority=-1 if prio == "back" else 0),
-                      "done": torch.cuda.Event(),
-                      "rdone": torch.cuda.Event(), "gr": None, "recorded": []})
-    pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, depth - 1))
+        fs = device.FrameStream(W, H, cap_frames, 0.85, 0.85, 85, 20, max_batch=B, max_ccs=max_ccs, max_crop_words=max_words, lib=lib)
+        slots.append({"fs": fs, "clean": torch.empty((B, H, W), dtype=torch.uint8, device="cuda"),
+                      "s_match": torch.cuda.Stream(priority=0), "s_back": torch.cuda.Stream(priority=0),
+                      "done": torch.cuda.Event(), "rdone": torch.cuda.Event(), "gr": None, "recorded": []})
+    # binary frames and the label image live for one batch: written by threshold / the labeller, consumed in order on s_wide
+    binary = torch.empty((B, H, W), dtype=torch.uint8, device="cuda")
+    labels = None if a.no_labels else torch.empty((B, H, W), dtype=torch.int32, device="cuda")
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, depth))
 
-    # The bandwidth-bound half of steps 01-02 (threshold, labelling, records: "wide") of ALL slots goes through ONE high-priority
-    # HIP stream, so two labelling launches never share the GPU; the temporal matching of a slot (small latency-bound kernels,
-    # among them a single-workgroup replay) runs on the slot's own normal-priority stream behind an event per batch, under the
-    # wide kernels of the next batches / the next steps.  (The streams must differ in priority: with both high the runtime puts
-    # them on one hardware queue and nothing overlaps -- 62-71 k frames/s; as below 73-76 k at depth 5.)  LM_BENCH_NO_SPLIT=1:
-    # every slot's steps 01-02 on its own high-priority stream (67-71 k at depth 3, with dips to 50-55 k).
-    split = depth > 1 and not os.environ.get("LM_BENCH_NO_SPLIT")
-    s_wide = torch.cuda.Stream(priority=-1 if prio == "front" else 0) if split else None
-
-    def front(sl, split=split):
-        """steps 01 (threshold) + 02 (label, records, matching) of one stream"""
-        fs, binary, labels = sl["fs"], sl["binary"], sl["labels"]
-        s_rec = s_wide if split else sl["s_front"]
-        with torch.cuda.stream(s_rec):
-            stream = s_rec.cuda_stream
-            if sl.get("gr") is not None:            # the previous step of this slot: its rendering must be done before
+    def front(sl, match=True, use_split=split):
+        """steps 01 (threshold) + 02 (label, records; matching when `match`) of this rank's block of the stream"""
+        fs = sl["fs"]
+        with torch.cuda.stream(s_wide):
+            ws = s_wide.cuda_stream
+            if sl["gr"] is not None:                # the previous step of this slot: its rendering must be done before
                 sl["rdone"].synchronize()           # its tables go away and its buffers are reused
                 sl["gr"].close()
                 sl["gr"] = None
             fs.reset()
-            lib.check(lib.lm_threshold_invert(logits.data_ptr(), binary.data_ptr(), F * H * W, 128, stream))
-            for k, f0 in enumerate(range(0, F, a.batch)):
-                n = min(a.batch, F - f0)
-                # the label image of a batch is an output of the labelling kernel; the same buffer is reused per batch
-                if not split:
-                    lib.check(lib.lm_stream_push(fs.handle, binary[f0:f0 + n].data_ptr(), n,
-                                                 labels.data_ptr() if labels is not None else None, stream))
+            for k, f0 in enumerate(range(0, n_mine, B)):
+                n = min(B, n_mine - f0)
+                lib.check(lib.lm_threshold_invert(logits[f0:f0 + n].data_ptr(), binary.data_ptr(), n * H * W, 128, ws))
+                lp = labels.data_ptr() if labels is not None else None
+                if match and not use_split:
+                    lib.check(lib.lm_stream_push(fs.handle, binary.data_ptr(), n, lp, ws))
                     continue
-                lib.check(lib.lm_stream_push_records(fs.handle, binary[f0:f0 + n].data_ptr(), n,
-                                                     labels.data_ptr() if labels is not None else None, stream))
-                while len(sl["recorded"]) <= k:
-                    sl["recorded"].append(torch.cuda.Event())
-                sl["recorded"][k].record(s_rec)
-                sl["s_front"].wait_event(sl["recorded"][k])
-                lib.check(lib.lm_stream_match(fs.handle, n, sl["s_front"].cuda_stream))
-            sl["done"].record(sl["s_front"])
+                lib.check(lib.lm_stream_push_records(fs.handle, binary.data_ptr(), n, lp, ws))
+                if match:
+                    while len(sl["recorded"]) <= k:
+                        sl["recorded"].append(torch.cuda.Event())
+                    sl["recorded"][k].record(s_wide)
+                    sl["s_match"].wait_event(sl["recorded"][k])
+                    lib.check(lib.lm_stream_match(fs.handle, n, sl["s_match"].cuda_stream))
+            if match and use_split:
+                sl["done"].record(sl["s_match"])
+            else:
+                sl["done"].record(s_wide)
+
+    def gather_and_match(sl):
+        """N > 1: the packed blocks of ranks 1.. travel to rank 0 (one transfer per rank), which appends and matches them"""
+        fs = sl["fs"]
+        with torch.cuda.stream(sl["s_match"]):
+            sl["s_match"].wait_event(sl["done"])
+            if rank != 0:
+                blk = fs.pack(0, n_mine)
+                torch.cuda.current_stream().synchronize()
+                sharded.gather_blocks(blk, dst=0)
+                return
+            blocks = sharded.gather_blocks(torch.empty(32, dtype=torch.uint8, device="cuda"), dst=0)
+            for r in range(1, world):
+                fs.append_packed(blocks[r])
+                r0, r1 = sharded.frame_range(F, r, world)
+                fs.match(r1 - r0)
+            sl["done"].record(sl["s_match"])
 
     def back(sl):
         """step 03: grouping + reconstruction of every frame (frames_from_groups), rendered batch by batch"""
@@ -241,69 +353,60 @@ def main():
         tq = time.perf_counter()
         with torch.cuda.stream(sl["s_back"]):
             sl["s_back"].wait_event(sl["done"])
+            if os.environ.get("LM_BENCH_VERBOSE"):
+                sl["done"].synchronize()
+                sys.stderr.write("   steps 01-02 finished on the GPU %.1f ms after step 03 was submitted\n" % ((time.perf_counter() - tq) * 1e3))
+                tq = time.perf_counter()
             gr = device.Grouping(sl["fs"], max_gap=85, min_times=3, t_window=5, min_recall=0.5, img_threshold=0.5, reconstruct=True)
-            for f0 in range(0, F, a.batch):
-                n = min(a.batch, F - f0)
+            for f0 in range(0, F, B):
+                n = min(B, F - f0)
                 gr.render(f0, n, sl["clean"][:n])
             info = gr.array("scalars")
-            # rendering is only enqueued here: the worker goes on to the next stream's step 03 while the GPU draws
-            sl["rdone"].record(sl["s_back"])
-            if os.environ.get("LM_BENCH_SYNC_RENDER"):
-                sl["s_back"].synchronize()
-                gr.close()
-            else:
-                sl["gr"] = gr
-        if os.environ.get("LM_BENCH_VERBOSE"):
-            sys.stderr.write("   step 03 worker: %.3f ms (from %.3f ms)\n" % ((time.perf_counter() - tq) * 1e3, tq * 1e3))
+            sl["rdone"].record(sl["s_back"])        # rendering is only enqueued here; awaited before the slot is reused / at the end
+            sl["gr"] = gr
+            if os.environ.get("LM_BENCH_VERBOSE"):
+                t1 = time.perf_counter()
+                sl["rdone"].synchronize()
+                sys.stderr.write("   step 03: tables %.1f ms, rendering done %.1f ms later\n" % ((t1 - tq) * 1e3, (time.perf_counter() - t1) * 1e3))
         return info
-
-    max_fronts = int(os.environ.get("LM_BENCH_MAX_FRONTS", "0"))
 
     def run_steps(k):
         pending = [None] * depth
         info = None
+        verbose = bool(os.environ.get("LM_BENCH_VERBOSE"))
         for i in range(k):
-            ta = time.perf_counter()
             sl = slots[i % depth]
+            ta = time.perf_counter()
             if pending[i % depth] is not None:
                 info = pending[i % depth].result()          # the slot's previous step must be finished before it is reused
-            if max_fronts and i >= max_fronts:           # at most max_fronts steps' 01-02 halves queued on the GPU
-                slots[(i - max_fronts) % depth]["done"].synchronize()
             tb = time.perf_counter()
-            front(sl)
-            pending[i % depth] = pool.submit(back, sl)
-            if os.environ.get("LM_BENCH_VERBOSE"):
-                sys.stderr.write("step %d: at %.3f ms, waited %.3f ms for its slot, enqueued steps 01-02 in %.3f ms\n"
-                                 % (i, ta * 1e3, (tb - ta) * 1e3, (time.perf_counter() - tb) * 1e3))
+            front(sl, match=(rank == 0))
+            tc = time.perf_counter()
+            if world > 1:
+                gather_and_match(sl)
+            if rank == 0:
+                pending[i % depth] = pool.submit(back, sl)
+            if verbose:
+                sys.stderr.write("rank %d step %d: waited %.1f ms for its slot, enqueued steps 01-02 in %.1f ms, gather %.1f ms\n"
+                                 % (rank, i, (tb - ta) * 1e3, (tc - tb) * 1e3, (time.perf_counter() - tc) * 1e3))
         for p in pending:
             if p is not None:
                 info = p.result()
         for sl in slots:
             if sl["gr"] is not None:
                 sl["rdone"].synchronize()
-                sl["gr"].close()
-                sl["gr"] = None
         return info
 
-    def stream_digest(fs):
-        """sha1 over everything steps 01-02 leave in the stream: CC records with their unique assignments, frame offsets, bit
-        crops, active list"""
-        import hashlib
-        r = fs.read()
-        h = hashlib.sha1()
-        for key in ("rec", "frame_off", "crop_off", "crop", "active"):
-            h.update(np.ascontiguousarray(r[key]).tobytes())
-        return h.hexdigest()
+    def close_groups():
+        for sl in slots:
+            if sl["gr"] is not None:
+                sl["rdone"].synchronize()
+                sl["gr"].close()
+                sl["gr"] = None
 
-    # one step with nothing else in flight, on one stream: the reference result for the steps that overlap in the pipeline
-    front(slots[0], split=False)
-    torch.cuda.synchronize()
-    digest_alone = stream_digest(slots[0]["fs"])
     run_steps(max(a.warmup, 0))
     torch.cuda.synchronize()
-    fs = slots[0]["fs"]
-    labels = slots[0]["labels"]
-    k0 = fs.counters() if a.warmup > 0 else None      # also surfaces capacity errors before timing
+    k0 = slots[0]["fs"].counters() if a.warmup > 0 else None      # also surfaces capacity errors before timing
     for sl in slots:
         lib.check(lib.lm_ctx_set_profiling(sl["fs"].labeler.ctx, 1))
 
@@ -322,7 +425,6 @@ def main():
         dt = float(t.item())
 
     # ---- roofline of the labelling launch sequence (events recorded inside the timed region)
-    import ctypes
     tot_ms, tot_calls, tot_fr = 0.0, 0, 0
     for sl in slots:
         ms, calls, nfr = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
@@ -331,53 +433,78 @@ def main():
         tot_ms += ms.value
         tot_calls += calls.value
         tot_fr += nfr.value
-    ms, calls, nfr = ctypes.c_double(tot_ms), ctypes.c_int64(tot_calls), ctypes.c_int64(tot_fr)
-    k1 = fs.counters()
-    assert k0 is None or k1 == k0, "steps are not reproducible: %r vs %r" % (k0, k1)
-    # every slot's last step (they ran overlapped) left bit for bit what the step alone left
-    identical = all(stream_digest(sl["fs"]) == digest_alone for sl in slots[:min(depth, a.steps)])
-    if not identical:
-        sys.stderr.write("bench.py: a pipelined step differs from the same step run alone -- the rate below is NOT a valid result\n")
-        if os.environ.get("LM_BENCH_STRICT"):
-            raise AssertionError("a pipelined step differs from the same step run alone")
 
     if rank != 0:
         if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
+    k1 = slots[0]["fs"].counters()
+    assert k0 is None or k1 == k0, "steps are not reproducible: %r vs %r" % (k0, k1)
+
+    # ---- parity: digests of what the last timed step of every slot left, against the reference's digests of the same stream
+    used = slots[:min(depth, max(a.steps, 1))]
+    dg = [digests.from_device(sl["fs"], sl["gr"]) for sl in used if sl["gr"] is not None]
+    sums = []
+    if used and used[0]["gr"] is not None:
+        sl = used[0]
+        with torch.cuda.stream(sl["s_back"]):
+            for f0 in range(0, F, B):
+                n = min(B, F - f0)
+                sl["gr"].render(f0, n, sl["clean"][:n])
+                sums.append(device.frame_sums(sl["clean"][:n], lib))
+        if dg:
+            dg[0]["clean_frame_sums"] = digests.sums_digest(np.concatenate(sums))
+    def core(d):
+        return {k: v for k, v in d.items() if k != "clean_frame_sums"}
+
+    parity = {"digests": dg[0] if dg else None, "all_slots_identical": all(core(d) == core(dg[0]) for d in dg),
+              "counters": {k: k1[k] for k in ("n_cc", "n_unique", "tempo_count")}, "reference": None, "match": None}
+    gpath = os.path.join(ROOT, "tests", "golden", "g9_stream1080p_digests.json")
+    if os.path.exists(gpath) and (W, H, a.seed) == (1920, 1080, 20213) and dg:
+        ref = json.load(open(gpath)).get(str(F))
+        if ref:
+            keys = [k for k in dg[0] if k in ref]
+            parity["reference"] = "tests/golden/g9_stream1080p_digests.json[%d] (the reference run on the same stream in the build container)" % F
+            parity["match"] = bool(all(dg[0][k] == ref[k] for k in keys) and ref["tempo_count"] == k1["tempo_count"] and ref["n_cc"] == k1["n_cc"])
+            parity["compared"] = keys + ["tempo_count", "n_cc"]
+    if parity["match"] is False or not parity["all_slots_identical"]:
+        sys.stderr.write("bench.py: digests differ (reference match: %r, slots identical: %r) -- the rate below is NOT a valid result\n"
+                         % (parity["match"], parity["all_slots_identical"]))
+        if os.environ.get("LM_BENCH_STRICT"):
+            raise AssertionError("parity digests differ")
+
     # the same launch sequence once more with nothing else in flight (after the timed region): in the pipeline, kernels of the
-    # other streams' steps share the GPU with it, which stretches the live figure without saying anything about the kernels
+    # matching stream share the GPU with it
     alone_ms = None
-    if depth > 1:
+    if world == 1 and not os.environ.get("LM_BENCH_NO_ALONE"):
+        close_groups()
         sl = slots[0]
         lib.check(lib.lm_ctx_set_profiling(sl["fs"].labeler.ctx, 1))
-        front(sl, split=False)
+        front(sl, match=False)
         torch.cuda.synchronize()
         ms2, calls2, nfr2 = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
         lib.check(lib.lm_ctx_profile_read(sl["fs"].labeler.ctx, ctypes.addressof(ms2), ctypes.addressof(calls2), ctypes.addressof(nfr2)))
         lib.check(lib.lm_ctx_set_profiling(sl["fs"].labeler.ctx, 0))
-        if calls2.value > 0 and nfr2.value == nfr.value * calls2.value // max(calls.value, 1):
-            alone_ms = ms2.value / calls2.value
+        if calls2.value > 0:
+            alone_ms = ms2.value / calls2.value         # the same mix of launches as one timed step
+    close_groups()
 
-    launch_ms = ms.value / max(calls.value, 1)
-    frames_per_launch = nfr.value / max(calls.value, 1)
+    launch_ms = tot_ms / max(tot_calls, 1)
+    frames_per_launch = tot_fr / max(tot_calls, 1)
     algo_bytes = ALGO_BYTES_PER_PX * W * H * frames_per_launch
     achieved = algo_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01_label_traffic_pmc.json")
-    if os.path.exists(tpath) and (W, H) == (1920, 1080):
-        tj = json.load(open(tpath))     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch sequence (not collectable live)
-        traffic = int(tj["traffic_bytes_per_frame"] * frames_per_launch)
-        traffic_src = "profiles/r01_label_traffic_pmc.json (separate rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes, gfx950 FETCH x2 correction on the image read)"
     roofline = {"bound": "hbm", "kernel": "lm_label_batch[lm_k_band+lm_k_seam_union+lm_k_flatten_flag+lm_k_apply_labels+lm_k_write_labels]",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "traffic_source": traffic_src, "launch_ms": round(launch_ms, 4), "frames_per_launch": frames_per_launch,
-                "algorithmic_bytes_per_launch": int(algo_bytes), "label_image_written": labels is not None}
+                "traffic": None, "traffic_note": "PMC passes cannot be collected inside this process; see profiles/ for the rocprofv3 --pmc runs of this command",
+                "launch_ms": round(launch_ms, 4), "launches": tot_calls, "frames_per_launch": round(frames_per_launch, 2),
+                "algorithmic_bytes_per_launch": int(algo_bytes), "label_image_written": labels is not None,
+                "timed": "HIP events around every lm_label_batch inside the timed region"}
     if alone_ms:
         roofline["alone"] = {"launch_ms": round(alone_ms, 4), "achieved": round(algo_bytes / (alone_ms * 1e-3) / 1e9, 2),
                              "frac": round(algo_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                             "note": "same launches after the timed region, no other stream's step in flight"}
+                             "note": "same launches after the timed region, no matching kernels in flight"}
 
     # ---- CPU baseline: the oracle (C port, 1 thread) on a prefix of the same stream
     cpu = None
@@ -394,22 +521,34 @@ def main():
                "sample": "first %d frames of the same stream: threshold+invert, label, stats, crops, temporal matching "
                          "(oracle/cc_oracle.c, single thread; host has %d cores)" % (n, os.cpu_count())}
 
-    total_frames = F * a.steps * world
     out = {
-        "metric": "frames/sec end-to-end binarize+CC+group @1080p", "value": round(total_frames / dt, 2), "unit": "frames/s",
+        "metric": "frames/sec end-to-end binarize+CC+group @1080p", "value": round(F * a.steps / dt, 2), "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "configs[2]: synthetic %dx%d binary-board stream, %d frames/stream/GPU: fp32 logits -> "
-                               "threshold+invert -> CC label (int32 image) -> CC stats/records/crops -> temporal matching -> grouping (step 03) + "
-                               "reconstructed frames"
-                               % (W, H, F),
-                   "frames_per_step": F, "batch": a.batch, "stages_not_in_timed_region": ["fcn conv stack (logits are synthetic, SURVEY 8(d) config 3)"],
-                   "stream": dict({k: k1[k] for k in ("n_cc", "n_unique", "tempo_count")}, n_groups=int(ginfo[2]), n_split=int(ginfo[0])), "parallelism": "independent streams per GPU", "pipeline_depth": depth, "matching_on_own_hip_stream": bool(split),
-                   "pipelined_steps_bit_identical_to_step_alone": bool(identical)},
-        "roofline": roofline, "cpu_baseline": cpu, "gen_seconds": round(gen_s, 2),
+        "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "configs[%d]: ONE synthetic %dx%d binary-board stream of %d frames per step%s: fp32 logits in HBM -> threshold+invert -> "
+                               "CC label (int32 image) -> CC stats/records/crops -> temporal matching over the whole stream -> grouping (step 03) + all "
+                               "%d frames reconstructed" % (2 if world == 1 else 3, W, H, F,
+                                                            "" if world == 1 else ", frame-range sharded over %d ranks (records gathered to rank 0)" % world, F),
+                   "frames_per_step": F, "frames_per_stream": F, "batch": B,
+                   "stages_not_in_timed_region": ["fcn conv stack (logits are synthetic, SURVEY 8(d) config 3; measured separately in `fcn` / `e2e_rgb`)"],
+                   "stream": dict({k: k1[k] for k in ("n_cc", "n_unique", "tempo_count")}, n_groups=int(ginfo[2]), n_split=int(ginfo[0])),
+                   "parallelism": "one stream on one GPU" if world == 1 else "frame-range shards of one stream, gather to rank 0",
+                   "pipeline_depth": depth, "matching_on_own_hip_stream": bool(split)},
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "gen_seconds": round(gen_s, 2),
     }
+    if world == 1 and a.fcn_frames > 0:
+        del logits
+        for sl in slots:
+            sl["fs"].close()
+        torch.cuda.empty_cache()
+        res, eng, _ = measure_fcn(a, lib, H, W, a.fcn_frames, not a.no_fcn_oracle)
+        out["fcn"] = res
+        if a.e2e_frames > 0:
+            out["e2e_rgb"] = measure_e2e_rgb(a, lib, eng, H, W, a.e2e_frames)
+        eng.close()
     print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -112,6 +112,17 @@ int lm_stream_push(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* 
 int lm_stream_push_records(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* d_labels, void* stream);
 int lm_stream_match(LmStream* s, int n_frames, void* stream);
 
+/* Frame-range sharding across the GPUs of a node: the CC records + crops of frames
+ * [first_frame, first_frame + n_frames) of a stream as ONE flat DEVICE buffer (32-byte aligned), so that the gather to the rank
+ * that replays the temporal matching is one RCCL send/recv per rank -- no pickling, no host copy.  Replaces the reference's
+ * per-lecture pickles as the hand-off between the per-frame half (labeler.py:116-191) and add_frame's matching
+ * (cc_stability_estimator.py:71-145).  lm_stream_pack_size synchronises and returns the bytes lm_stream_pack will write;
+ * lm_stream_append_packed appends a packed block behind the last frame of `s` (frame numbers and crop offsets are rebased on
+ * the device); the appended frames are unmatched until lm_stream_match. */
+int lm_stream_pack_size(LmStream* s, int first_frame, int n_frames, int64_t* h_bytes, void* stream);
+int lm_stream_pack(LmStream* s, int first_frame, int n_frames, void* d_buf, int64_t bytes, void* stream);
+int lm_stream_append_packed(LmStream* s, const void* d_buf, int64_t bytes, void* stream);
+
 /* Diagnostic: sizes of the last batch handed to the batched matcher (lm_match_batch.hip):
  * out5 = {in-batch sources, CC tiles, pairs against earlier uniques, pairs against in-batch sources, frames}. Synchronises. */
 int lm_stream_match_stats(LmStream* s, int64_t* out5, void* stream);

@@ -421,14 +421,14 @@ extern "C" int CC_AgeBoundaries(int* labels, float* ages, int width, int height,
 extern "C" void lm_stream_destroy(LmStream* s)
 {
     if (!s) return;
-    void* ptrs[] = {s->cc, s->assign, s->frame_cc_off, s->crop, s->active_cc, s->active_box, s->active_last, s->active, s->counters, s->best,
+    void* ptrs[] = {s->cc, s->assign, s->frame_cc_off, s->crop, s->chash, s->active_cc, s->active_box, s->active_last, s->active, s->counters, s->best,
                     s->batch_cc_base, s->batch_word_base};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->mb) {
         LmMatchBatch* m = s->mb;
         void* mp[] = {m->nt_cnt, m->nt_src, m->tlast, m->tcur[0], m->tcur[1], m->ftile_all, m->nt_foff, m->nt_list, m->cls, m->troot, m->rootpos, m->ftile, m->s_prefix, m->tcount[0], m->tcount[1], m->toff[0], m->toff[1], m->pairs[0], m->pairs[1], m->pair_u[0],
-                      m->pair_u[1], m->sidx, m->s_list, m->s_box, m->newpos, m->n_src, m->ttab, m->tkey, m->twin};
+                      m->pair_u[1], m->sidx, m->s_list, m->s_box, m->newpos, m->n_src, m->ttab, m->tkey, m->twin, m->big[0], m->big[1], m->n_big};
         for (void* p : mp)
             if (p) (void)hipFree(p);
         delete m;
@@ -451,6 +451,7 @@ extern "C" int lm_stream_reset(LmStream* s, void* stream)
     LM_HIP(hipMemsetAsync(s->counters, 0, sizeof(LmCounters), (hipStream_t)stream));
     LM_HIP(hipMemsetAsync(s->best, 0xff, (size_t)s->ctx->g.cap * sizeof(unsigned long long), (hipStream_t)stream));
     LM_HIP(hipMemsetAsync(s->frame_cc_off, 0, sizeof(long long), (hipStream_t)stream));
+    LM_HIP(hipMemsetAsync(s->chash, 0, (size_t)s->cap_cc * sizeof(uint32_t), (hipStream_t)stream));     // lm_k_emit adds into it
     s->frames_pushed = 0;
     s->frames_matched = 0;
     return LM_OK;
@@ -479,6 +480,7 @@ extern "C" LmStream* lm_stream_create(LmCtx* ctx, int max_frames, int64_t max_cc
     rc |= lm_alloc(&s->assign, (size_t)max_ccs);
     rc |= lm_alloc(&s->frame_cc_off, (size_t)max_frames + 1);
     rc |= lm_alloc(&s->crop, (size_t)max_crop_words);
+    rc |= lm_alloc(&s->chash, (size_t)max_ccs);
     rc |= lm_alloc(&s->active_cc, (size_t)max_uniques);
     rc |= lm_alloc(&s->active_box, (size_t)max_uniques);
     rc |= lm_alloc(&s->active_last, (size_t)max_uniques);
@@ -522,6 +524,10 @@ extern "C" LmStream* lm_stream_create(LmCtx* ctx, int max_frames, int64_t max_cc
         rc |= lm_alloc(&m->ttab, (size_t)LM_MB_TTAB);
         rc |= lm_alloc(&m->tkey, (size_t)max_ccs);
         rc |= lm_alloc(&m->twin, (size_t)max_ccs);
+        m->cap_big = 1u << 16;
+        rc |= lm_alloc(&m->big[0], (size_t)m->cap_big);
+        rc |= lm_alloc(&m->big[1], (size_t)m->cap_big);
+        rc |= lm_alloc(&m->n_big, (size_t)2);
 #if !LM_HIP_EMULATED
         if (rc == LM_OK &&
             hipFuncSetAttribute((const void*)lm_k_mb_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LM_MB_RESOLVE_SMEM) != hipSuccess)
@@ -557,7 +563,7 @@ static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st)
         return;
     }
     const LmMatchBatch mb = *s->mb;
-    const dim3 gj(LM_HIP_EMULATED ? 2 : 128, LM_HIP_EMULATED ? 2 : 8), gt(LM_HIP_EMULATED ? 2 : 1024), ge(LM_HIP_EMULATED ? 2 : 2048);
+    const dim3 gj(LM_HIP_EMULATED ? 2 : 128, LM_HIP_EMULATED ? 2 : 8), gt(LM_HIP_EMULATED ? 2 : 1024), ge(LM_HIP_EMULATED ? 2 : 2048), gb(LM_HIP_EMULATED ? 2 : 1024);
     for (int done = 0; done < n;) {
         const int B = (n - done < LM_MB_MAX_FRAMES) ? n - done : LM_MB_MAX_FRAMES;
         const int f = f0 + done;
@@ -565,8 +571,11 @@ static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st)
         const int twins = (s->min_recall <= 1.0 && s->min_precision <= 1.0) ? 1 : 0;     // the twin rule needs "identical crops are accepted"; otherwise twin[] stays 0
         if (twins) {
             (void)hipMemsetAsync(mb.ttab, 0xff, (size_t)LM_MB_TTAB * sizeof(unsigned long long), st);
-            hipLaunchKernelGGL(lm_k_mb_twin_insert, ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->counters, mb);
-            hipLaunchKernelGGL(lm_k_mb_twin_find, ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->counters, mb, s->max_gap);
+            const dim3 gc(LM_HIP_EMULATED ? 2 : 256);
+            hipLaunchKernelGGL(lm_k_mb_twin_insert, gc, dim3(256), 0, st, s->cc, s->chash, s->frame_cc_off, f, B, s->counters, mb);
+            hipLaunchKernelGGL(lm_k_mb_twin_probe, gc, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->counters, mb, s->max_gap);
+            hipLaunchKernelGGL(lm_k_mb_twin_cmp, ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->counters, mb);
+            hipLaunchKernelGGL(lm_k_mb_twin_final, gc, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->counters, mb);
         }
         hipLaunchKernelGGL(lm_k_mb_nt, dim3(B + 1), dim3(1024), 0, st, s->frame_cc_off, f, B, s->active, s->active_cc, s->active_box, s->active_last,
                            s->counters, mb, s->max_gap, twins);
@@ -574,11 +583,15 @@ static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st)
         hipLaunchKernelGGL((lm_k_mb_join<0, 1>), gj, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->counters, mb);
         hipLaunchKernelGGL((lm_k_mb_eval<0>), ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->active_last, s->counters, mb,
                            s->min_recall, s->min_precision, s->max_gap);
+        hipLaunchKernelGGL((lm_k_mb_eval_big<0>), gb, dim3(256), 0, st, s->cc, s->crop, s->active_last, s->counters, mb, s->min_recall, s->min_precision,
+                           s->max_gap);
         hipLaunchKernelGGL(lm_k_mb_sources, dim3(1), dim3(1024), 0, st, s->cc, s->frame_cc_off, f, B, s->counters, mb);
         hipLaunchKernelGGL((lm_k_mb_join<1, 0>), gj, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->counters, mb);
         hipLaunchKernelGGL((lm_k_mb_join<1, 1>), gj, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->counters, mb);
         hipLaunchKernelGGL((lm_k_mb_eval<1>), ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->active_last, s->counters, mb,
                            s->min_recall, s->min_precision, s->max_gap);
+        hipLaunchKernelGGL((lm_k_mb_eval_big<1>), gb, dim3(256), 0, st, s->cc, s->crop, s->active_last, s->counters, mb, s->min_recall, s->min_precision,
+                           s->max_gap);
         hipLaunchKernelGGL(lm_k_mb_resolve, dim3(1), dim3(LM_MB_RT), LM_MB_RESOLVE_SMEM, st, s->cc, s->frame_cc_off, f, B, s->active, s->active_cc,
                            s->active_box, s->active_last, s->counters, s->assign, mb, s->max_gap, s->cap_uniq);
         hipLaunchKernelGGL(lm_k_mb_finish, dim3(160), dim3(256), 0, st, s->frame_cc_off, f, B, s->active, s->counters, s->assign, mb);
@@ -616,8 +629,8 @@ static int lm_stream_push_impl(LmStream* s, const uint8_t* d_binary, int n_frame
                            s->frame_cc_off, s->batch_cc_base, s->batch_word_base, s->cap_cc, s->cap_words, s->cap_frames);
         hipLaunchKernelGGL(lm_k_emit, dim3(LM_HIP_EMULATED ? 2 : 320, B), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff, c->final_label,
                            c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x, c->st_count, c->kept_label, c->kept_cropoff,
-                           c->frame_kept, s->batch_cc_base, s->batch_word_base, s->cc, s->crop, s->frames_pushed, g.WW, g.H,
-                           g.cap);
+                           c->frame_kept, c->frame_cropwords, s->batch_cc_base, s->batch_word_base, s->cc, s->crop, s->chash, s->frames_pushed, g.WW,
+                           g.H, g.cap);
         if (do_match) {
             lm_launch_match_frames(s, s->frames_pushed, B, st);
             s->frames_matched += B;
@@ -770,6 +783,8 @@ extern "C" int lm_stream_import(LmStream* s, const int32_t* h_rec, const int64_t
         if (e == hipSuccess && n_crop_words > 0) e = hipMemcpyAsync(s->crop, h_crop, (size_t)n_crop_words * sizeof(uint32_t), hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(lm_k_unpack_records, dim3(lm_blocks(n_cc, 256)), dim3(256), 0, st, d_rec, d_off, (long long)n_cc, s->cc, s->assign);
+            hipLaunchKernelGGL(lm_k_crop_hash, dim3(lm_blocks(n_crop_words / 64 + 1, 4, 2048)), dim3(256), 0, st, s->cc, s->crop, 0ll, (long long)n_cc,
+                               (unsigned long long)n_crop_words, s->chash);
             e = hipStreamSynchronize(st);
         }
         (void)hipFree(d_rec);
@@ -837,6 +852,176 @@ extern "C" int lm_stream_read(LmStream* s, int32_t* h_rec, int64_t* h_frame_off,
     if (h_crop && k[2] > 0) LM_HIP(hipMemcpyAsync(h_crop, s->crop, (size_t)k[2] * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     if (h_active && k[4] > 0) LM_HIP(hipMemcpyAsync(h_active, s->active, (size_t)k[4] * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     LM_HIP(hipStreamSynchronize(st));
+    return LM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Frame-range sharding: the CC records + crops of whole frames as ONE flat device buffer, so that the gather to
+// the rank that replays the temporal matching is one send / recv per rank over RCCL (no pickling, no host copy).
+// Layout (bytes): [0,32) header int64 {n_frames, n_cc, n_words, magic}; int64 kept-CC counts per frame, padded to a multiple
+// of four entries; the 32-byte LmCcRec records (frame numbers relative to the block's first frame, crop offsets relative to
+// its first crop word); the uint32 crop words.
+// ------------------------------------------------------------------------------------------------
+#define LM_PACK_MAGIC 0x4c4d504b31ll   /* "LMPK1" */
+
+static inline size_t lm_pack_rec_off(long long n_frames) { return 32 + (size_t)((n_frames + 3) & ~3ll) * 8; }
+static inline size_t lm_pack_bytes(long long n_frames, long long n_cc, long long n_words)
+{
+    return lm_pack_rec_off(n_frames) + (size_t)n_cc * sizeof(LmCcRec) + (size_t)n_words * 4;
+}
+
+__global__ void __launch_bounds__(256) lm_k_pack_block(const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
+                                                       const long long* __restrict__ frame_cc_off, int first, int n_frames, long long c0,
+                                                       long long n_cc, unsigned long long w0, long long nw, long long* __restrict__ head,
+                                                       LmCcRec* __restrict__ orec, uint32_t* __restrict__ ocrop)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+    if (tid == 0) { head[0] = n_frames; head[1] = n_cc; head[2] = nw; head[3] = LM_PACK_MAGIC; }
+    for (long long i = tid; i < n_frames; i += nth) head[4 + i] = frame_cc_off[first + i + 1] - frame_cc_off[first + i];
+    for (long long i = tid; i < n_cc; i += nth) {
+        LmCcRec r = cc[c0 + i];
+        r.frame -= first;
+        r.crop_off -= w0;
+        orec[i] = r;
+    }
+    for (long long i = tid; i < nw; i += nth) ocrop[i] = crop[w0 + i];
+}
+
+__global__ void __launch_bounds__(256) lm_k_append_block(const LmCcRec* __restrict__ irec, const uint32_t* __restrict__ icrop, long long n_cc,
+                                                         long long nw, LmCcRec* __restrict__ cc, uint32_t* __restrict__ crop,
+                                                         const LmCounters* __restrict__ cnt)
+{
+    const long long c0 = cnt->n_cc;
+    const unsigned long long w0 = cnt->n_words;
+    const int f0 = cnt->n_frames;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+    for (long long i = tid; i < n_cc; i += nth) {
+        LmCcRec r = irec[i];
+        r.frame += f0;
+        r.crop_off += w0;
+        cc[c0 + i] = r;
+    }
+    for (long long i = tid; i < nw; i += nth) crop[w0 + i] = icrop[i];
+}
+
+// one workgroup, after lm_k_append_block: exclusive scan of the block's per-frame counts -> frame_cc_off, then the counters
+__global__ void __launch_bounds__(1024) lm_k_append_offsets(const long long* __restrict__ head, long long* __restrict__ frame_cc_off,
+                                                            LmCounters* __restrict__ cnt)
+{
+    const int n_frames = (int)head[0];
+    const long long c0 = cnt->n_cc;
+    const int f0 = cnt->n_frames;
+    unsigned long long carry = 0;
+    for (int base = 0; base < n_frames; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        const unsigned k = (i < n_frames) ? (unsigned)head[4 + i] : 0u;
+        unsigned tot;
+        const unsigned ex = lm_block_excl_scan<1024>(k, &tot);
+        if (i < n_frames) frame_cc_off[f0 + i] = c0 + (long long)(carry + ex);
+        carry += tot;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        frame_cc_off[f0 + n_frames] = c0 + head[1];
+        cnt->n_cc = c0 + head[1];
+        cnt->n_words += (unsigned long long)head[2];
+        cnt->n_frames = f0 + n_frames;
+    }
+}
+
+// record range [c0, c0 + n_cc) and crop-word range [w0, w0 + nw) of frames [first, first + n); synchronises the stream
+static int lm_pack_query(LmStream* s, int first, int n, long long* c0, long long* n_cc, unsigned long long* w0, long long* nw, hipStream_t st)
+{
+    LmCounters h;
+    long long c01[2] = {0, 0};
+    LM_HIP(hipMemcpyAsync(&h, s->counters, sizeof(h), hipMemcpyDeviceToHost, st));
+    LM_HIP(hipMemcpyAsync(&c01[0], s->frame_cc_off + first, sizeof(long long), hipMemcpyDeviceToHost, st));
+    LM_HIP(hipMemcpyAsync(&c01[1], s->frame_cc_off + first + n, sizeof(long long), hipMemcpyDeviceToHost, st));
+    LM_HIP(hipStreamSynchronize(st));
+    if (h.error) { lm_set_error("lm_stream_pack: stream capacity exceeded on device"); return h.error; }
+    *c0 = c01[0];
+    *n_cc = c01[1] - c01[0];
+    *w0 = 0;
+    *nw = 0;
+    if (*n_cc > 0) {
+        // records are emitted in (frame, label) order and their crops appended in the same order: the block's words are contiguous
+        LmCcRec r0, r1;
+        unsigned long long w1 = h.n_words;
+        LM_HIP(hipMemcpyAsync(&r0, s->cc + c01[0], sizeof(LmCcRec), hipMemcpyDeviceToHost, st));
+        if (c01[1] < h.n_cc) LM_HIP(hipMemcpyAsync(&r1, s->cc + c01[1], sizeof(LmCcRec), hipMemcpyDeviceToHost, st));
+        LM_HIP(hipStreamSynchronize(st));
+        if (c01[1] < h.n_cc) w1 = r1.crop_off;
+        *w0 = r0.crop_off;
+        *nw = (long long)(w1 - r0.crop_off);
+    }
+    return LM_OK;
+}
+
+extern "C" int lm_stream_pack_size(LmStream* s, int first_frame, int n_frames, int64_t* h_bytes, void* stream)
+{
+    if (!s || !h_bytes || first_frame < 0 || n_frames < 0 || first_frame + n_frames > s->frames_pushed) {
+        lm_set_error("lm_stream_pack_size: bad arguments (frames [%d, %d) of %d pushed)", first_frame, first_frame + n_frames, s ? s->frames_pushed : 0);
+        return LM_ERR_ARG;
+    }
+    long long c0, n_cc, nw;
+    unsigned long long w0;
+    const int rc = lm_pack_query(s, first_frame, n_frames, &c0, &n_cc, &w0, &nw, (hipStream_t)stream);
+    if (rc) return rc;
+    *h_bytes = (int64_t)lm_pack_bytes(n_frames, n_cc, nw);
+    return LM_OK;
+}
+
+extern "C" int lm_stream_pack(LmStream* s, int first_frame, int n_frames, void* d_buf, int64_t bytes, void* stream)
+{
+    if (!s || !d_buf || first_frame < 0 || n_frames < 0 || first_frame + n_frames > s->frames_pushed || (((uintptr_t)d_buf) & 31)) {
+        lm_set_error("lm_stream_pack: bad arguments (32-byte aligned device buffer, frames [%d, %d) of %d pushed)", first_frame,
+                     first_frame + n_frames, s ? s->frames_pushed : 0);
+        return LM_ERR_ARG;
+    }
+    long long c0, n_cc, nw;
+    unsigned long long w0;
+    const int rc = lm_pack_query(s, first_frame, n_frames, &c0, &n_cc, &w0, &nw, (hipStream_t)stream);
+    if (rc) return rc;
+    const size_t need = lm_pack_bytes(n_frames, n_cc, nw);
+    if ((size_t)bytes < need) { lm_set_error("lm_stream_pack: buffer of %lld bytes, %lld needed", (long long)bytes, (long long)need); return LM_ERR_CAPACITY; }
+    char* b = (char*)d_buf;
+    const size_t rec_off = lm_pack_rec_off(n_frames);
+    hipLaunchKernelGGL(lm_k_pack_block, dim3(lm_blocks(n_cc + nw / 4 + n_frames, 256, 4096)), dim3(256), 0, (hipStream_t)stream, s->cc, s->crop,
+                       s->frame_cc_off, first_frame, n_frames, c0, n_cc, w0, nw, (long long*)b, (LmCcRec*)(b + rec_off),
+                       (uint32_t*)(b + rec_off + (size_t)n_cc * sizeof(LmCcRec)));
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+extern "C" int lm_stream_append_packed(LmStream* s, const void* d_buf, int64_t bytes, void* stream)
+{
+    if (!s || !d_buf || bytes < 32 || (((uintptr_t)d_buf) & 31)) { lm_set_error("lm_stream_append_packed: bad arguments"); return LM_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    long long head[4];
+    LM_HIP(hipMemcpyAsync(head, d_buf, sizeof(head), hipMemcpyDeviceToHost, st));
+    LmCounters h;
+    LM_HIP(hipMemcpyAsync(&h, s->counters, sizeof(h), hipMemcpyDeviceToHost, st));
+    LM_HIP(hipStreamSynchronize(st));
+    if (head[3] != LM_PACK_MAGIC || head[0] < 0 || head[1] < 0 || head[2] < 0 || (size_t)bytes < lm_pack_bytes(head[0], head[1], head[2])) {
+        lm_set_error("lm_stream_append_packed: not a packed block (or truncated: %lld bytes)", (long long)bytes);
+        return LM_ERR_ARG;
+    }
+    if (h.error) { lm_set_error("lm_stream_append_packed: stream capacity exceeded on device"); return h.error; }
+    if (s->frames_pushed + head[0] > s->cap_frames || h.n_cc + head[1] > s->cap_cc || h.n_words + (unsigned long long)head[2] > s->cap_words) {
+        lm_set_error("lm_stream_append_packed: stream too small (frames %lld/%d, ccs %lld/%lld, crop words %llu/%llu)", s->frames_pushed + head[0],
+                     s->cap_frames, h.n_cc + head[1], s->cap_cc, h.n_words + (unsigned long long)head[2], s->cap_words);
+        return LM_ERR_CAPACITY;
+    }
+    const char* b = (const char*)d_buf;
+    const size_t rec_off = lm_pack_rec_off(head[0]);
+    hipLaunchKernelGGL(lm_k_append_block, dim3(lm_blocks(head[1] + head[2] / 4 + 1, 256, 4096)), dim3(256), 0, st, (const LmCcRec*)(b + rec_off),
+                       (const uint32_t*)(b + rec_off + (size_t)head[1] * sizeof(LmCcRec)), head[1], head[2], s->cc, s->crop, s->counters);
+    if (head[1] > 0)
+        hipLaunchKernelGGL(lm_k_crop_hash, dim3(lm_blocks(head[2] / 64 + 1, 4, 2048)), dim3(256), 0, st, s->cc, s->crop, (long long)h.n_cc, head[1],
+                           h.n_words + (unsigned long long)head[2], s->chash);
+    hipLaunchKernelGGL(lm_k_append_offsets, dim3(1), dim3(1024), 0, st, (const long long*)b, s->frame_cc_off, s->counters);
+    LM_HIP(hipGetLastError());
+    s->frames_pushed += (int)head[0];
     return LM_OK;
 }
 

@@ -15,7 +15,7 @@
 #include "lm_common.h"
 
 #if LM_HIP_EMULATED
-extern char lm_emu_dynsmem[];
+extern char* lm_emu_dynsmem;
 #define LM_DYN_SMEM(name) char* name = lm_emu_dynsmem
 #else
 #define LM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]

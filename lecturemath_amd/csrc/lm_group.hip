@@ -100,33 +100,38 @@ __global__ void __launch_bounds__(256) lm_k_pair_overlap(const LmCcRec* __restri
 // ------------------------------------------------------------------------------------------------
 struct LmGimgItem {
     int32_t x0, y0, w, h;        // group box origin and size
-    int32_t mem_off, mem_cnt;    // slice of the member list
     long long img_off;           // byte offset of the item's (h x w) uint8 image
     long long bits_off;          // word offset of the same image as bit rows (ceil(w / 32) words per row), what the renderer reads
 };
 struct LmGimgMember { int32_t cc; int32_t count; };
-struct LmGimgUnit { int32_t item; int16_t tx, ty; };
+// work unit = one 64 x 64 tile of an item's box with the members whose boxes touch it (a group box is mostly empty and a
+// member is a glyph-sized CC: listing the members per tile keeps the work linear in the members, not members x tiles)
+struct LmGimgUnit { int32_t item; int16_t tx, ty; uint32_t mem_off, mem_cnt; };
 
 #define LM_GT 64   // tile side
 
-LM_DEV void lm_gimg_accumulate(const LmGimgItem& it, int tx, int ty, const LmGimgMember* __restrict__ members,
+LM_DEV void lm_gimg_accumulate(const LmGimgItem& it, const LmGimgUnit& un, const LmGimgMember* __restrict__ members,
                                const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop, int* s_mask)
 {
     // tile covers x in [X0, X0+64), y in [Y0, Y0+64) of the frame
-    const int X0 = it.x0 + tx * LM_GT, Y0 = it.y0 + ty * LM_GT;
+    const int X0 = it.x0 + un.tx * LM_GT, Y0 = it.y0 + un.ty * LM_GT;
     for (int i = threadIdx.x; i < LM_GT * LM_GT; i += blockDim.x) s_mask[i] = 0;
     __syncthreads();
     const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6), lane = lm_lane();
-    for (int m = wave; m < it.mem_cnt; m += nwaves) {
-        const LmGimgMember mem = members[it.mem_off + m];
+    for (int m = wave; m < (int)un.mem_cnt; m += nwaves) {
+        const LmGimgMember mem = members[un.mem_off + m];
         const LmCcRec r = cc[mem.cc];
         if (r.max_x < X0 || r.min_x >= X0 + LM_GT || r.max_y < Y0 || r.min_y >= Y0 + LM_GT) continue;
         const int wx0 = r.min_x >> 5, nw = (r.max_x >> 5) - wx0 + 1;
         const int ya = r.min_y > Y0 ? r.min_y : Y0;
         const int yb = r.max_y < Y0 + LM_GT - 1 ? r.max_y : Y0 + LM_GT - 1;
-        const int total = nw * (yb - ya + 1);
+        // only the crop words under the tile's 64 columns (a large component's rows are tens of words wide)
+        const int ja = (X0 >> 5) > wx0 ? (X0 >> 5) - wx0 : 0;
+        const int jb = ((X0 + LM_GT - 1) >> 5) - wx0 < nw - 1 ? ((X0 + LM_GT - 1) >> 5) - wx0 : nw - 1;
+        const int tw = jb - ja + 1;
+        const int total = tw * (yb - ya + 1);
         for (int idx = lane; idx < total; idx += 64) {
-            const int rr = idx / nw, j = idx - rr * nw;
+            const int rr = idx / tw, j = ja + (idx - rr * tw);
             const int y = ya + rr;
             unsigned wbits = crop[r.crop_off + (unsigned long long)((y - r.min_y) * nw + j)];
             const int xw = (wx0 + j) * 32;
@@ -142,17 +147,18 @@ LM_DEV void lm_gimg_accumulate(const LmGimgItem& it, int tx, int ty, const LmGim
 }
 
 __global__ void __launch_bounds__(256) lm_k_gimg_max(const LmGimgItem* __restrict__ items, const LmGimgUnit* __restrict__ units,
-                                                     int n_units, const LmGimgMember* __restrict__ members,
+                                                     const unsigned* __restrict__ n_units_p, const LmGimgMember* __restrict__ members,
                                                      const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
                                                      int32_t* __restrict__ item_max)
 {
     __shared__ int s_mask[LM_GT * LM_GT];
     __shared__ int s_max;
+    const int n_units = (int)*n_units_p;        // the unit list is compacted on the device (lm_k_gimg_units)
     for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
         const LmGimgUnit un = units[u];
         const LmGimgItem it = items[un.item];
         if (threadIdx.x == 0) s_max = 0;
-        lm_gimg_accumulate(it, un.tx, un.ty, members, cc, crop, s_mask);
+        lm_gimg_accumulate(it, un, members, cc, crop, s_mask);
         int mx = 0;
         for (int i = threadIdx.x; i < LM_GT * LM_GT; i += blockDim.x) mx = s_mask[i] > mx ? s_mask[i] : mx;
         if (mx) atomicMax(&s_max, mx);
@@ -162,26 +168,24 @@ __global__ void __launch_bounds__(256) lm_k_gimg_max(const LmGimgItem* __restric
     }
 }
 
+// The segment image ((mask / mask.max()) >= thr, float64 like numpy, :630; max >= 1 by construction) is kept as bit rows: the
+// renderer reads bits, and the reference's uint8 arrays are expanded from them on demand (lm_k_gimg_expand).  Tiles that no
+// member touches are never visited: their words were cleared before the launch (all zero <=> below any positive threshold).
 __global__ void __launch_bounds__(256) lm_k_gimg_write(const LmGimgItem* __restrict__ items, const LmGimgUnit* __restrict__ units,
-                                                       int n_units, const LmGimgMember* __restrict__ members,
+                                                       const unsigned* __restrict__ n_units_p, const LmGimgMember* __restrict__ members,
                                                        const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
-                                                       const int32_t* __restrict__ item_max, double thr, uint8_t* __restrict__ images,
-                                                       uint32_t* __restrict__ bits)
+                                                       const int32_t* __restrict__ item_max, double thr, uint32_t* __restrict__ bits)
 {
     __shared__ int s_mask[LM_GT * LM_GT];
+    const int n_units = (int)*n_units_p;
     for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
         const LmGimgUnit un = units[u];
         const LmGimgItem it = items[un.item];
-        lm_gimg_accumulate(it, un.tx, un.ty, members, cc, crop, s_mask);
+        lm_gimg_accumulate(it, un, members, cc, crop, s_mask);
         const double mx = (double)item_max[un.item];
         const int tw = (it.w - un.tx * LM_GT < LM_GT) ? it.w - un.tx * LM_GT : LM_GT;
         const int th = (it.h - un.ty * LM_GT < LM_GT) ? it.h - un.ty * LM_GT : LM_GT;
-        for (int i = threadIdx.x; i < tw * th; i += blockDim.x) {
-            const int yy = i / tw, xx = i - yy * tw;
-            const double v = (double)s_mask[yy * LM_GT + xx] / mx;      // float64 like numpy (:630); max >= 1 by construction
-            images[it.img_off + (long long)(un.ty * LM_GT + yy) * it.w + (un.tx * LM_GT + xx)] = (v >= thr) ? 255 : 0;
-        }
-        // the same decisions as bit rows: a 64-px tile row is two whole words of the item's row
+        // a 64-px tile row is two whole words of the item's row
         const int bw = (it.w + 31) >> 5;
         for (int i = threadIdx.x; i < th * 2; i += blockDim.x) {
             const int yy = i >> 1, hf = i & 1;
@@ -450,6 +454,365 @@ __global__ void __launch_bounds__(256) lm_k_bitimg_pair_any(const LmBitImage* __
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// G7: the neighbour structure of the stable uniques, built and kept on the device.
+// compute_overlapping_stable_cc (:245-306) joins ALL stable uniques by box (no time limit), so a 10,000-frame lecture has
+// ~10^5 stable uniques and ~10^7 overlapping pairs: lists of that size are built, filtered and aggregated here; the host only
+// sees what the order-dependent group merge (:308-413) needs.
+//   adjacency      row i (stable index) = every j != i whose box overlaps, ASCENDING (count / scan / fill, one wave per row:
+//                  the ballot order is the output order).  The reference's pair list sorted by (idx1, idx2) (:274) visits, for
+//                  a unique u, first the pairs (c, u) with c < u by ascending c, then the pairs (u, b) by ascending b: u's
+//                  neighbour lists are its partners in ascending order, i.e. the rows of this adjacency.
+//   match          pixel overlap of every entry (computed for i < j, mirrored by binary search in row j)
+//   aov / tov      all_overlapping_cc / time_overlapping_cc rows (:291-304) compacted out of the adjacency in order
+//   strong         tov entries with recall >= min_recall (:336): the only edges compute_groups follows -> host
+// ------------------------------------------------------------------------------------------------
+template <int FILL>
+__global__ void __launch_bounds__(256) lm_k_adj_rows(const unsigned long long* __restrict__ box, int n, unsigned* __restrict__ cnt_or_off,
+                                                     int32_t* __restrict__ adj, int32_t* __restrict__ arow)
+{
+    const int lane = lm_lane();
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+    for (int i = wave; i < n; i += nwaves) {
+        const unsigned long long bi = box[i];
+        const unsigned base = FILL ? cnt_or_off[i] : 0u;
+        unsigned c = 0;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            const bool hit = j < n && j != i && lm_box_hit_packed(bi, box[j]);
+            const unsigned long long m = __ballot(hit);
+            if (FILL && hit) {
+                const unsigned p = base + c + (unsigned)__popcll(m & lm_lowmask_excl(lane));
+                adj[p] = j;
+                arow[p] = i;
+            }
+            c += (unsigned)__popcll(m);
+        }
+        if (!FILL && lane == 0) cnt_or_off[i] = c;
+    }
+}
+
+// exclusive scan of n counters into n + 1 offsets (in place allowed); one workgroup.  *total receives the 64-bit sum.
+__global__ void __launch_bounds__(1024) lm_k_scan_u32(const unsigned* __restrict__ in, unsigned* __restrict__ out, int n,
+                                                      unsigned long long* __restrict__ total)
+{
+    unsigned long long carry = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        const unsigned v = (i < n) ? in[i] : 0u;
+        unsigned tot;
+        const unsigned ex = lm_block_excl_scan<1024>(v, &tot);
+        if (i < n) out[i] = (unsigned)(carry + ex);
+        carry += tot;
+    }
+    if (threadIdx.x == 0) { out[n] = (unsigned)carry; *total = carry; }
+}
+
+// pixel overlap of the entries with row < partner; 16 lanes share one entry
+__global__ void __launch_bounds__(256) lm_k_adj_match(const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
+                                                      const int32_t* __restrict__ scc, const int32_t* __restrict__ adj,
+                                                      const int32_t* __restrict__ arow, long long ne, int32_t* __restrict__ match)
+{
+    const int sub = (int)(threadIdx.x & 15);
+    const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ngroups = ((long long)gridDim.x * blockDim.x) >> 4;
+    const long long ne_pad = (ne + 3) & ~3ll;        // whole waves stay in the loop for the shuffles
+    for (long long p = group; p < ne_pad; p += ngroups) {
+        int m = 0;
+        const bool live = p < ne && arow[p] < adj[p];
+        if (live) {
+            const LmCcRec a = cc[scc[arow[p]]], u = cc[scc[adj[p]]];
+            const LmIsect is = lm_isect(a, u);
+            m = lm_overlap_words(a, u, is, crop, sub, 16);
+        }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) m += __shfl_xor(m, d, 16);
+        if (live && sub == 0) match[p] = m;
+    }
+}
+
+// entries with row > partner: the value of the mirrored entry (rows are ascending: binary search)
+__global__ void __launch_bounds__(256) lm_k_adj_mirror(const unsigned* __restrict__ off, const int32_t* __restrict__ adj,
+                                                       const int32_t* __restrict__ arow, long long ne, int32_t* __restrict__ match)
+{
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < ne; p += (long long)gridDim.x * blockDim.x) {
+        const int i = arow[p], j = adj[p];
+        if (i < j) continue;
+        unsigned lo = off[j], hi = off[j + 1];          // first entry of row j that is >= i
+        while (lo < hi) {
+            const unsigned mid = (lo + hi) >> 1;
+            if (adj[mid] < i) lo = mid + 1; else hi = mid;
+        }
+        match[p] = match[lo];
+    }
+}
+
+struct LmAdjTab {
+    const unsigned* off; const int32_t* adj; const int32_t* match;
+    const int32_t *size, *first, *last, *uid;       // per stable unique: pixels of its first-seen CC, first / last frame, unique index
+    int n, t_window;
+    double min_recall;
+};
+
+// 0: no common pixel (not a neighbour at all, :291); 1: all_overlapping only; 2: also inside the temporal window (:299)
+LM_DEV int lm_adj_kind(const LmAdjTab& A, int i, int j, int m)
+{
+    if (m <= 0) return 0;       // recall > 0 or precision > 0  <=>  match > 0 (sizes are positive)
+    return (A.last[i] + A.t_window >= A.first[j] && A.last[j] + A.t_window >= A.first[i]) ? 2 : 1;
+}
+
+// MODE 0: per-row counts {aov, tov, strong} + total_intersections;  MODE 1: compacted rows at the scanned offsets
+struct LmAdjOut {
+    unsigned *aov_off, *tov_off, *str_off;           // MODE 0: counts written here; MODE 1: scanned offsets
+    int32_t *aov_j, *aov_other, *aov_matched, *aov_size_other, *aov_size_self;
+    int32_t* tov_other; double *tov_recall, *tov_precision;
+    int32_t* str_j;
+    unsigned long long* total_intersections;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256) lm_k_adj_lists(const LmAdjTab A, const LmAdjOut O)
+{
+    const int lane = lm_lane();
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+    for (int i = wave; i < A.n; i += nwaves) {
+        const unsigned e0 = A.off[i], e1 = A.off[i + 1];
+        const int si = A.size[i];
+        unsigned ca = 0, ct = 0, cs = 0, inter = 0;
+        const unsigned ba = MODE ? O.aov_off[i] : 0u, bt = MODE ? O.tov_off[i] : 0u, bs = MODE ? O.str_off[i] : 0u;
+        for (unsigned eb = e0; eb < e1; eb += 64) {
+            const unsigned e = eb + (unsigned)lane;
+            int kind = 0, j = 0, m = 0;
+            if (e < e1) { j = A.adj[e]; m = A.match[e]; kind = lm_adj_kind(A, i, j, m); }
+            const int sj = kind ? A.size[j] : 1;
+            const double r_self = (double)m / (double)si, r_other = (double)m / (double)sj;     // connected_component.py:239-240
+            const bool strong = kind == 2 && r_self >= A.min_recall;                               // :336, recall relative to the iterating CC
+            const unsigned long long ma = __ballot(kind >= 1), mt = __ballot(kind == 2), ms = __ballot(strong);
+            if (MODE) {
+                const unsigned long long below = lm_lowmask_excl(lane);
+                if (kind >= 1) {
+                    const unsigned p = ba + ca + (unsigned)__popcll(ma & below);
+                    const int sa = (i < j) ? si : sj;                                           // the pair's idx1 < idx2 side
+                    O.aov_j[p] = j;
+                    O.aov_other[p] = A.uid[j];
+                    O.aov_matched[p] = (int)((double)sa * ((double)m / (double)sa));          // float64 round trip, can be match - 1 (:294)
+                    O.aov_size_other[p] = sj;
+                    O.aov_size_self[p] = si;
+                }
+                if (kind == 2) {
+                    const unsigned p = bt + ct + (unsigned)__popcll(mt & below);
+                    O.tov_other[p] = A.uid[j];
+                    O.tov_recall[p] = r_self;
+                    O.tov_precision[p] = r_other;
+                }
+                if (strong) O.str_j[bs + cs + (unsigned)__popcll(ms & below)] = j;
+            } else {
+                inter += (unsigned)__popcll(__ballot(kind == 2 && i < j));
+            }
+            ca += (unsigned)__popcll(ma); ct += (unsigned)__popcll(mt); cs += (unsigned)__popcll(ms);
+        }
+        if (!MODE && lane == 0) {
+            O.aov_off[i] = ca; O.tov_off[i] = ct; O.str_off[i] = cs;
+            if (inter) atomicAdd(O.total_intersections, (unsigned long long)inter);
+        }
+    }
+}
+
+// per stable unique: box, size of its first-seen CC
+__global__ void __launch_bounds__(256) lm_k_stable_gather(const LmCcRec* __restrict__ cc, const int32_t* __restrict__ scc, int n,
+                                                          unsigned long long* __restrict__ box, int32_t* __restrict__ size)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const LmCcRec r = cc[scc[i]];
+        box[i] = lm_pack_box(r);
+        size[i] = r.size;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// G8: compute_conflicting_groups (:446-500): every all_overlapping pair (idx1 < idx2) whose members sit in different groups
+// adds {matched, unmatched, area_union, area_intersection} to the (g1, g2) and (g2, g1) entries.  Aggregated in a hash table
+// keyed by the unordered group pair (64-bit CAS, integer atomics: all four quantities are integers); `first` keeps the smallest
+// entry index that touched the key = the pair's insertion rank in the reference's dict-of-dicts (rows ascending, partners
+// ascending).  The host only orders the few distinct group pairs.
+// ------------------------------------------------------------------------------------------------
+struct LmConfTable { unsigned long long* key; unsigned long long *matched, *unmatched, *uni, *inter, *first; unsigned cap_mask; int* overflow; };
+#define LM_CONF_EMPTY 0xffffffffffffffffull
+
+__global__ void __launch_bounds__(256) lm_k_conflicts(const unsigned* __restrict__ aov_off, const int32_t* __restrict__ aov_j,
+                                                      const int32_t* __restrict__ aov_matched, const int32_t* __restrict__ aov_size_other,
+                                                      const int32_t* __restrict__ aov_size_self, const unsigned long long* __restrict__ box,
+                                                      const int32_t* __restrict__ sgid, int n, const LmConfTable T)
+{
+    const int lane = lm_lane();
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+    for (int i = wave; i < n; i += nwaves) {
+        const unsigned e0 = aov_off[i], e1 = aov_off[i + 1];
+        const int gi = sgid[i];
+        const unsigned long long bi = box[i];
+        const int ix0 = (int)(bi & 0xffff), ix1 = (int)((bi >> 16) & 0xffff), iy0 = (int)((bi >> 32) & 0xffff), iy1 = (int)(bi >> 48);
+        for (unsigned e = e0 + (unsigned)lane; e < e1; e += 64) {
+            const int j = aov_j[e];
+            if (j < i) continue;                                                 // `if not idx1 < idx2: continue`
+            const int gj = sgid[j];
+            if (gi == gj) continue;
+            const unsigned long long bj = box[j];
+            const int jx0 = (int)(bj & 0xffff), jx1 = (int)((bj >> 16) & 0xffff), jy0 = (int)((bj >> 32) & 0xffff), jy1 = (int)(bj >> 48);
+            long long inter = 0;
+            if (ix0 <= jx1 && jx0 <= ix1 && iy0 <= jy1 && jy0 <= iy1)
+                inter = (long long)((ix1 < jx1 ? ix1 : jx1) - (ix0 > jx0 ? ix0 : jx0) + 1) * ((iy1 < jy1 ? iy1 : jy1) - (iy0 > jy0 ? iy0 : jy0) + 1);
+            const long long uni = (long long)(ix1 - ix0 + 1) * (iy1 - iy0 + 1) + (long long)(jx1 - jx0 + 1) * (jy1 - jy0 + 1) - inter;
+            const long long matched = aov_matched[e];
+            const long long unmatched = (long long)aov_size_self[e] + aov_size_other[e] - 2 * matched;
+            const unsigned glo = (unsigned)(gi < gj ? gi : gj), ghi = (unsigned)(gi < gj ? gj : gi);
+            const unsigned long long key = ((unsigned long long)glo << 32) | ghi;
+            unsigned h = (unsigned)((key * 0x9e3779b97f4a7c15ull) >> 32) & T.cap_mask;
+            bool placed = false;
+            for (unsigned probe = 0; probe <= T.cap_mask; probe++) {
+                const unsigned long long old = atomicCAS(&T.key[h], LM_CONF_EMPTY, key);
+                if (old == LM_CONF_EMPTY || old == key) { placed = true; break; }
+                h = (h + 1) & T.cap_mask;
+            }
+            if (!placed) { *T.overflow = 1; continue; }
+            atomicAdd(&T.matched[h], (unsigned long long)matched);
+            atomicAdd(&T.unmatched[h], (unsigned long long)unmatched);
+            atomicAdd(&T.uni[h], (unsigned long long)uni);
+            atomicAdd(&T.inter[h], (unsigned long long)inter);
+            atomicMin(&T.first[h], (unsigned long long)e);
+        }
+    }
+}
+
+struct LmConfRow { unsigned long long key, matched, unmatched, uni, inter, first; };
+
+__global__ void __launch_bounds__(256) lm_k_conf_compact(const LmConfTable T, unsigned cap, LmConfRow* __restrict__ out, unsigned* __restrict__ n_out,
+                                                         unsigned out_cap)
+{
+    for (unsigned h = blockIdx.x * blockDim.x + threadIdx.x; h < cap; h += gridDim.x * blockDim.x) {
+        const unsigned long long k = T.key[h];
+        if (k == LM_CONF_EMPTY) continue;
+        const unsigned p = atomicAdd(n_out, 1u);
+        if (p < out_cap) out[p] = LmConfRow{k, T.matched[h], T.unmatched[h], T.uni[h], T.inter[h], T.first[h]};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// G9: tables of the group-image kernels, built on the device.  For every (group, member) the segments [ages[j], ages[j+1]]
+// (both ends included, :617-619) that hold entries of the member: binary searches in the member's ascending frame list.
+// The member goes into the list of every 64 x 64 tile of the item's box that its own box touches: MODE 0 counts per tile,
+// MODE 1 writes {first-seen CC, entry count} at the scanned offsets (order inside a tile is irrelevant: the image is an
+// integer sum).  Tiles without members are never visited.
+// ------------------------------------------------------------------------------------------------
+struct LmGimgTab {
+    const int32_t *slot_group, *slot_unique, *slot_cc;       // per group-member slot: group, unique index, first-seen CC
+    int n_slots;
+    const int32_t* ages; const int64_t* ages_off;             // group_ages CSR
+    const int64_t* gitem_first;                                // first item of every group
+    const int64_t* ulist_off; const int32_t* ulist_frame;      // frames of every unique's entries, ascending
+    const int64_t* tile_off;                                   // first tile of every item
+    const int32_t* bounds;                                     // group boxes
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256) lm_k_gimg_members(const LmGimgTab T, unsigned* __restrict__ tile_cnt, const unsigned* __restrict__ tile_moff,
+                                                         LmGimgMember* __restrict__ members, const LmCcRec* __restrict__ cc)
+{
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < T.n_slots; s += gridDim.x * blockDim.x) {
+        const int g = T.slot_group[s], u = T.slot_unique[s];
+        const int32_t* ag = T.ages + T.ages_off[g];
+        const int na = (int)(T.ages_off[g + 1] - T.ages_off[g]), ns = na - 1;
+        if (ns <= 0) continue;
+        const int32_t* fe = T.ulist_frame + T.ulist_off[u];
+        const int n = (int)(T.ulist_off[u + 1] - T.ulist_off[u]);
+        const int first = fe[0], last = fe[n - 1];
+        // segments that can hold an entry: ag[j+1] >= first and ag[j] <= last
+        int lo = 0, hi = ns;                        // smallest j with ag[j + 1] >= first
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (ag[mid + 1] < first) lo = mid + 1; else hi = mid; }
+        const int j_lo = lo;
+        lo = 0; hi = ns;                            // number of j with ag[j] <= last
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (ag[mid] <= last) lo = mid + 1; else hi = mid; }
+        const int j_hi = lo - 1;
+        if (j_hi < j_lo) continue;
+        // tiles of the group box the member's box touches (the same for every segment)
+        const int gx0 = T.bounds[g * 4 + 0], gy0 = T.bounds[g * 4 + 2], gw = T.bounds[g * 4 + 1] - gx0 + 1;
+        const LmCcRec r = cc[T.slot_cc[s]];
+        const int ntx = (gw + LM_GT - 1) / LM_GT;
+        const int tx0 = (r.min_x - gx0) / LM_GT, tx1 = (r.max_x - gx0) / LM_GT, ty0 = (r.min_y - gy0) / LM_GT, ty1 = (r.max_y - gy0) / LM_GT;
+        const long long item0 = T.gitem_first[g];
+        for (int j = j_lo; j <= j_hi; j++) {
+            int a = 0, b = n;                       // first entry >= ag[j]
+            while (a < b) { const int mid = (a + b) >> 1; if (fe[mid] < ag[j]) a = mid + 1; else b = mid; }
+            const int e_lo = a;
+            b = n;                                  // first entry > ag[j + 1]
+            while (a < b) { const int mid = (a + b) >> 1; if (fe[mid] <= ag[j + 1]) a = mid + 1; else b = mid; }
+            const int count = a - e_lo;
+            if (count <= 0) continue;
+            const long long t0 = T.tile_off[item0 + j];
+            for (int ty = ty0; ty <= ty1; ty++)
+                for (int tx = tx0; tx <= tx1; tx++) {
+                    const long long t = t0 + (long long)ty * ntx + tx;
+                    const unsigned pos = atomicAdd(&tile_cnt[t], 1u);
+                    if (MODE) members[tile_moff[t] + pos] = LmGimgMember{T.slot_cc[s], count};
+                }
+        }
+    }
+}
+
+// tiles with members (all tiles when `all`) -> work units (any order)
+__global__ void __launch_bounds__(256) lm_k_gimg_units(const unsigned* __restrict__ tile_moff, long long n_tiles, const int64_t* __restrict__ tile_off,
+                                                       const LmGimgItem* __restrict__ items, int n_items, int all, LmGimgUnit* __restrict__ units,
+                                                       unsigned* __restrict__ n_units)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n_tiles; t += (long long)gridDim.x * blockDim.x) {
+        const unsigned m0 = tile_moff[t], m1 = tile_moff[t + 1];
+        if (m1 == m0 && !all) continue;
+        int lo = 0, hi = n_items;           // item of tile t: largest k with tile_off[k] <= t
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tile_off[mid] <= t) lo = mid; else hi = mid; }
+        const int ntx = (items[lo].w + LM_GT - 1) / LM_GT;
+        const long long rel = t - tile_off[lo];
+        const unsigned p = atomicAdd(n_units, 1u);
+        units[p] = LmGimgUnit{lo, (int16_t)(rel % ntx), (int16_t)(rel / ntx), m0, m1 - m0};
+    }
+}
+
+// exclusive scan of a large counter array in three launches: per-chunk scans, scan of the chunk sums (one workgroup), add
+#define LM_SCAN_CHUNK 4096
+__global__ void __launch_bounds__(1024) lm_k_scan_chunks(const unsigned* __restrict__ in, unsigned* __restrict__ out, long long n,
+                                                         unsigned* __restrict__ chunk_sum)
+{
+    const long long c0 = (long long)blockIdx.x * LM_SCAN_CHUNK;
+    unsigned carry = 0;
+    for (int base = 0; base < LM_SCAN_CHUNK; base += 1024) {
+        const long long i = c0 + base + (long long)threadIdx.x;
+        const unsigned v = (i < n) ? in[i] : 0u;
+        unsigned tot;
+        const unsigned ex = lm_block_excl_scan<1024>(v, &tot);
+        if (i < n) out[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) chunk_sum[blockIdx.x] = carry;
+}
+
+__global__ void __launch_bounds__(256) lm_k_scan_add(unsigned* __restrict__ out, long long n, const unsigned* __restrict__ chunk_off, int n_chunks)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = (i < n) ? out[i] + chunk_off[i / LM_SCAN_CHUNK] : chunk_off[n_chunks];
+}
+
+// bit rows of one item -> the reference's uint8 0 / 255 image (lm_group_array(LM_G_GIMG), on demand)
+__global__ void __launch_bounds__(256) lm_k_gimg_expand(const LmGimgItem* __restrict__ items, int n_items, const uint32_t* __restrict__ bits,
+                                                        uint8_t* __restrict__ images)
+{
+    for (int k = blockIdx.y; k < n_items; k += gridDim.y) {
+        const LmGimgItem it = items[k];
+        const int bw = (it.w + 31) >> 5;
+        const long long px = (long long)it.w * it.h;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < px; i += (long long)gridDim.x * blockDim.x) {
+            const int y = (int)(i / it.w), x = (int)(i - (long long)y * it.w);
+            images[it.img_off + i] = ((bits[it.bits_off + (long long)y * bw + (x >> 5)] >> (x & 31)) & 1u) ? 255 : 0;
+        }
+    }
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -466,10 +829,7 @@ struct LmGroups {
     std::vector<int32_t> ulist_cc;              // global cc index of each entry (frame and raw label follow from the record)
     std::vector<int32_t> assign;                // [n_cc] unique index per kept CC after the split
     std::vector<int32_t> stable;                // stable unique indices, ascending
-    std::vector<int32_t> pair_a, pair_b, pair_match;      // bbox-overlapping stable pairs (unique indices, a < b), sorted
     int64_t total_intersections;
-    std::vector<int64_t> tov_off; std::vector<int32_t> tov_other; std::vector<double> tov_recall, tov_precision;
-    std::vector<int64_t> aov_off; std::vector<int32_t> aov_other, aov_matched, aov_size_other, aov_size_self;
     std::vector<int64_t> grp_off; std::vector<int32_t> grp_members;     // cc_groups
     std::vector<int32_t> gid_of_unique;         // [n_uniq] group of a unique or -1
     std::vector<int64_t> ages_off; std::vector<int32_t> ages;           // group_ages
@@ -478,10 +838,22 @@ struct LmGroups {
     std::vector<int32_t> bounds;                // [n_groups][4] min_x, max_x, min_y, max_y
     std::vector<int64_t> gimg_off;              // [n_items + 1] byte offsets of the segment images (item order: group, segment)
     std::vector<int64_t> gimg_item_off;         // [n_groups + 1] first item of every group
-    std::vector<uint8_t> gimg_host;             // filled on demand
+    // materialised from the device tables on first request (lm_group_array): a long lecture has ~10^7 overlapping pairs
+    bool have_pairs = false, have_nbr = false;
+    std::vector<int32_t> pair_a, pair_b, pair_match;      // bbox-overlapping stable pairs (unique indices, a < b), sorted
+    std::vector<int64_t> tov_off; std::vector<int32_t> tov_other; std::vector<double> tov_recall, tov_precision;
+    std::vector<int64_t> aov_off; std::vector<int32_t> aov_other, aov_matched, aov_size_other, aov_size_self;
+    std::vector<uint8_t> gimg_host;
     // ---- device
-    uint8_t* d_images = nullptr;
-    uint32_t* d_gbits = nullptr;                // the same images as bit rows (renderer input)
+    int n_stable = 0;
+    long long n_adj = 0, n_aov = 0, n_tov = 0;
+    unsigned* d_adj_off = nullptr; int32_t *d_adj = nullptr, *d_arow = nullptr, *d_match = nullptr;
+    unsigned *d_aov_off = nullptr, *d_tov_off = nullptr;
+    int32_t *d_aov_j = nullptr, *d_aov_other = nullptr, *d_aov_matched = nullptr, *d_aov_size_other = nullptr, *d_aov_size_self = nullptr;
+    int32_t* d_tov_other = nullptr; double *d_tov_recall = nullptr, *d_tov_precision = nullptr;
+    LmGimgItem* d_items = nullptr;
+    int n_items = 0;
+    uint32_t* d_gbits = nullptr;                // the segment images as bit rows (renderer input)
     std::vector<int64_t> gbits_off;             // [n_items] word offsets into d_gbits
     long long* d_frame_item_off = nullptr;
     LmRenderItem* d_render_items = nullptr;
@@ -489,6 +861,9 @@ struct LmGroups {
     char* arena = nullptr;                      // bump arena (the stream's cached one when it was free)
     size_t arena_cap = 0, arena_used = 0, arena_want = 0;
     bool arena_cached = false;
+    char* pin = nullptr;                        // pinned host staging (D2H / H2D at PCIe rate instead of the pageable path)
+    size_t pin_cap = 0, pin_used = 0;
+    std::vector<void*> pin_owned;
 };
 
 // Device memory for one lm_group_run: bump allocation from the arena, hipMalloc only for what does not fit.
@@ -507,6 +882,21 @@ static void* lm_galloc(LmGroups* g, size_t bytes)
     return p;
 }
 
+// pinned host memory for one run (bump; what does not fit the first block is allocated on its own)
+static void* lm_gpin(LmGroups* g, size_t bytes)
+{
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (g->pin && g->pin_used + need <= g->pin_cap) {
+        void* p = g->pin + g->pin_used;
+        g->pin_used += need;
+        return p;
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, need ? need : 256) != hipSuccess) { lm_set_error("lm_group_run: hipHostMalloc(%zu) failed", need); return nullptr; }
+    g->pin_owned.push_back(p);
+    return p;
+}
+
 #define LM_G_ARRAYS 40
 enum {
     LM_G_UNIQ_CC = 0, LM_G_ULIST_OFF, LM_G_ULIST_CC, LM_G_ASSIGN, LM_G_STABLE, LM_G_PAIR_A, LM_G_PAIR_B, LM_G_PAIR_MATCH,
@@ -516,12 +906,26 @@ enum {
     LM_G_GIMG_OFF, LM_G_GIMG_ITEM_OFF, LM_G_GIMG, LM_G_SCALARS
 };
 
+// host vector -> device (through pinned staging: the async copy is then a real DMA and the vector may go away at once)
 template <class T> static int lm_upload(LmGroups* g, const std::vector<T>& v, T** d, hipStream_t st)
 {
     *d = (T*)lm_galloc(g, (v.size() ? v.size() : 1) * sizeof(T));
     if (!*d) return LM_ERR_HIP;
-    // the host vectors outlive the copy: they are members of g or locals that live until the final stream sync
-    if (!v.empty()) LM_HIP(hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    if (v.empty()) return LM_OK;
+    void* stage = lm_gpin(g, v.size() * sizeof(T));
+    if (!stage) return LM_ERR_HIP;
+    memcpy(stage, v.data(), v.size() * sizeof(T));
+    LM_HIP(hipMemcpyAsync(*d, stage, v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    return LM_OK;
+}
+
+// device -> host vector (synchronises the stream)
+template <class T> static int lm_download(LmGroups* g, const T* d, size_t n, std::vector<T>& v, hipStream_t st)
+{
+    v.resize(n);
+    if (!n) return LM_OK;
+    LM_HIP(hipMemcpyAsync(v.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, st));
+    LM_HIP(hipStreamSynchronize(st));
     return LM_OK;
 }
 
@@ -529,6 +933,8 @@ extern "C" void lm_group_destroy(LmGroups* g)
 {
     if (!g) return;
     for (void* p : g->d_owned) (void)hipFree(p);
+    for (void* p : g->pin_owned) (void)hipHostFree(p);
+    if (g->pin) (void)hipHostFree(g->pin);
     if (g->arena) {
         LmStream* s = g->s;
         if (g->arena_cached) {
@@ -546,21 +952,29 @@ extern "C" void lm_group_destroy(LmGroups* g)
     delete g;
 }
 
-#define LM_GROUP_THREADS 4     // host threads tabulating group images
-
 // LM_GROUP_TIMING=1 prints the wall time of every phase of lm_group_run to stderr
 struct LmPhaseTimer {
     bool on;
     std::chrono::steady_clock::time_point t;
     LmPhaseTimer() : on(getenv("LM_GROUP_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
-    void mark(const char* what)
+    void mark(const char* what, hipStream_t st = nullptr, bool sync = false)
     {
         if (!on) return;
+        if (sync) (void)hipStreamSynchronize(st);
         auto n = std::chrono::steady_clock::now();
-        fprintf(stderr, "[lm_group] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        fprintf(stderr, "[lm_group] %-36s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
         t = n;
     }
 };
+
+static inline unsigned lm_gblocks(long long items, int per_block, unsigned max_blocks)
+{
+    if (LM_HIP_EMULATED) return 2;
+    long long b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > (long long)max_blocks) b = max_blocks;
+    return (unsigned)b;
+}
 
 static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st)
 {
@@ -574,29 +988,37 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
     const int nU0 = (int)k[3];
     g->n_frames = F;
     g->n_uniq0 = nU0;
-    // ---- records to the host
-    std::vector<int32_t> rec((size_t)std::max<long long>(n_cc, 1) * 8);
-    std::vector<int64_t> foff((size_t)F + 1);
-    rc = lm_stream_read(s, rec.data(), foff.data(), nullptr, nullptr, nullptr, st);
-    if (rc) return rc;
-    tm.mark("counters + records D2H");
-    auto R = [&](long long c, int field) { return rec[(size_t)c * 8 + field]; };   // 0 cc_id 1 min_x 2 max_x 3 min_y 4 max_y 5 size 6 frame 7 assign
-    // the two fields every per-CC loop below needs, as dense arrays (one sequential pass over the records)
-    std::vector<int32_t> cc_frame((size_t)std::max<long long>(n_cc, 1)), cc_assign((size_t)std::max<long long>(n_cc, 1));
-    for (long long c = 0; c < n_cc; c++) { cc_frame[(size_t)c] = rec[(size_t)c * 8 + 6]; cc_assign[(size_t)c] = rec[(size_t)c * 8 + 7]; }
+    {   // pinned staging for this run: the assignments down, the tables up
+        const size_t want = (size_t)std::max<long long>(n_cc, 1) * 16 + ((size_t)F + 1) * 64 + ((size_t)4 << 20);
+        if (hipHostMalloc((void**)&g->pin, want) == hipSuccess) g->pin_cap = want;
+    }
+    // ---- what the host bookkeeping needs of the records: the unique every CC was assigned to and its frame (the frame
+    // follows from the per-frame offsets)
+    const size_t ncc1 = (size_t)std::max<long long>(n_cc, 1);
+    int32_t* h_assign = (int32_t*)lm_gpin(g, ncc1 * sizeof(int32_t));
+    long long* h_foff = (long long*)lm_gpin(g, ((size_t)F + 1) * sizeof(long long));
+    if (!h_assign || !h_foff) return LM_ERR_HIP;
+    if (n_cc > 0) LM_HIP(hipMemcpyAsync(h_assign, s->assign, (size_t)n_cc * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    LM_HIP(hipMemcpyAsync(h_foff, s->frame_cc_off, ((size_t)F + 1) * sizeof(long long), hipMemcpyDeviceToHost, st));
+    LM_HIP(hipStreamSynchronize(st));
+    tm.mark("counters + assignments D2H");
+    std::vector<int32_t> cc_frame(ncc1);
+    for (int f = 0; f < F; f++)
+        for (long long c = h_foff[f]; c < h_foff[f + 1]; c++) cc_frame[(size_t)c] = f;
+    const int32_t* cc_assign = h_assign;
 
     // ---- per-unique entry lists (CC order == ascending frame, the reference's append order)
     std::vector<int64_t> cnt((size_t)nU0 + 1, 0);
     for (long long c = 0; c < n_cc; c++) cnt[(size_t)cc_assign[(size_t)c] + 1]++;
     for (int u = 0; u < nU0; u++) cnt[(size_t)u + 1] += cnt[u];
-    std::vector<int32_t> lst((size_t)std::max<long long>(n_cc, 1));
+    std::vector<int32_t> lst(ncc1);
     {
         std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
         for (long long c = 0; c < n_cc; c++) lst[(size_t)pos[cc_assign[(size_t)c]]++] = (int32_t)c;
     }
     tm.mark("entry lists");
     // ---- split_stable_cc_by_gaps (:181-228)
-    g->assign = cc_assign;
+    g->assign.assign(cc_assign, cc_assign + n_cc);
     g->uniq_cc.resize(nU0);
     std::vector<std::pair<int64_t, int64_t>> seg((size_t)nU0);      // [begin, end) in lst of every unique
     for (int u = 0; u < nU0; u++) {
@@ -604,165 +1026,185 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         g->uniq_cc[u] = lst[(size_t)cnt[u]];    // every unique has at least its first-seen entry
     }
     g->n_split = 0;
-    for (int u = 0; u < nU0; u++) {
-        const int64_t b = cnt[u], e = cnt[(size_t)u + 1];
-        const int64_t n_local = e - b;
+    {
         std::vector<int64_t> cuts;              // starts of later runs
-        for (int64_t i = b + 1; i < e; i++)
-            if (cc_frame[(size_t)lst[(size_t)i]] - cc_frame[(size_t)lst[(size_t)i - 1]] > g->max_gap) cuts.push_back(i);
-        if (cuts.empty() || n_local < g->min_times) continue;
-        seg[u].second = cuts[0];
-        for (size_t ci = 0; ci < cuts.size(); ci++) {
-            const int64_t rb = cuts[ci], re = (ci + 1 < cuts.size()) ? cuts[ci + 1] : e;
-            const int new_u = (int)seg.size();
-            seg.push_back({rb, re});
-            g->uniq_cc.push_back(g->uniq_cc[u]);            // another reference to the original CC (:212)
-            for (int64_t i = rb; i < re; i++) g->assign[(size_t)lst[(size_t)i]] = new_u;
+        for (int u = 0; u < nU0; u++) {
+            const int64_t b = cnt[u], e = cnt[(size_t)u + 1];
+            const int64_t n_local = e - b;
+            cuts.clear();
+            for (int64_t i = b + 1; i < e; i++)
+                if (cc_frame[(size_t)lst[(size_t)i]] - cc_frame[(size_t)lst[(size_t)i - 1]] > g->max_gap) cuts.push_back(i);
+            if (cuts.empty() || n_local < g->min_times) continue;
+            seg[u].second = cuts[0];
+            for (size_t ci = 0; ci < cuts.size(); ci++) {
+                const int64_t rb = cuts[ci], re = (ci + 1 < cuts.size()) ? cuts[ci + 1] : e;
+                const int new_u = (int)seg.size();
+                seg.push_back({rb, re});
+                g->uniq_cc.push_back(g->uniq_cc[u]);            // another reference to the original CC (:212)
+                for (int64_t i = rb; i < re; i++) g->assign[(size_t)lst[(size_t)i]] = new_u;
+            }
+            g->n_split++;
         }
-        g->n_split++;
     }
     const int nU = (int)seg.size();
     g->ulist_off.assign((size_t)nU + 1, 0);
-    g->ulist_cc.clear();
-    g->ulist_cc.reserve((size_t)n_cc);
-    for (int u = 0; u < nU; u++) {
-        for (int64_t i = seg[u].first; i < seg[u].second; i++) g->ulist_cc.push_back(lst[(size_t)i]);
-        g->ulist_off[(size_t)u + 1] = (int64_t)g->ulist_cc.size();
+    g->ulist_cc.resize((size_t)n_cc);
+    {
+        size_t w = 0;
+        for (int u = 0; u < nU; u++) {
+            const size_t len = (size_t)(seg[u].second - seg[u].first);
+            if (len) memcpy(g->ulist_cc.data() + w, lst.data() + seg[u].first, len * sizeof(int32_t));
+            w += len;
+            g->ulist_off[(size_t)u + 1] = (int64_t)w;
+        }
+        g->ulist_cc.resize(w);
     }
-    auto first_frame = [&](int u) { return cc_frame[(size_t)g->ulist_cc[(size_t)g->ulist_off[u]]]; };
-    auto last_frame = [&](int u) { return cc_frame[(size_t)g->ulist_cc[(size_t)g->ulist_off[(size_t)u + 1] - 1]]; };
-    auto usize = [&](int u) { return R(g->uniq_cc[u], 5); };
-    auto ubox = [&](int u, int i) { return R(g->uniq_cc[u], 1 + i); };     // min_x max_x min_y max_y
-
+    std::vector<int32_t> ulist_frame(g->ulist_cc.size());
+    for (size_t e = 0; e < g->ulist_cc.size(); e++) ulist_frame[e] = cc_frame[(size_t)g->ulist_cc[e]];
+    auto first_frame = [&](int u) { return ulist_frame[(size_t)g->ulist_off[u]]; };
+    auto last_frame = [&](int u) { return ulist_frame[(size_t)g->ulist_off[(size_t)u + 1] - 1]; };
     tm.mark("split + CSR");
-    // ---- stable set (:230-236)
+
+    // ---- stable set (:230-236) and what the device needs to know about it
     g->stable.clear();
     for (int u = 0; u < nU; u++)
         if (g->ulist_off[(size_t)u + 1] - g->ulist_off[u] >= g->min_times) g->stable.push_back(u);
     const int nS = (int)g->stable.size();
-
-    // ---- overlapping stable CCs (:245-306): box self-join + pixel overlaps on the device
-    g->pair_a.clear(); g->pair_b.clear(); g->pair_match.clear();
-    if (nS > 1) {
-        std::vector<unsigned long long> hbox((size_t)nS);
-        std::vector<int32_t> hcc((size_t)nS);
-        for (int i = 0; i < nS; i++) {
-            const int u = g->stable[i];
-            hbox[i] = (unsigned long long)(unsigned short)ubox(u, 0) | ((unsigned long long)(unsigned short)ubox(u, 1) << 16) |
-                      ((unsigned long long)(unsigned short)ubox(u, 2) << 32) | ((unsigned long long)(unsigned short)ubox(u, 3) << 48);
-            hcc[i] = g->uniq_cc[u];
-        }
-        unsigned long long* d_box; int32_t* d_cc; int* d_np;
-        if (lm_upload(g, hbox, &d_box, st) || lm_upload(g, hcc, &d_cc, st)) return LM_ERR_HIP;
-        d_np = (int*)lm_galloc(g, 64);
-        if (!d_np) return LM_ERR_HIP;
-        int cap_pairs = 1 << 20;
-        int2* d_pairs = nullptr;
-        int np = 0;
-        for (;;) {
-            d_pairs = (int2*)lm_galloc(g, (size_t)cap_pairs * sizeof(int2));
-            if (!d_pairs) return LM_ERR_HIP;
-            LM_HIP(hipMemsetAsync(d_np, 0, sizeof(int), st));
-            const int gx = std::min((nS + 255) / 256, LM_HIP_EMULATED ? 2 : 64), gy = std::min((nS + LM_SJ_TILE - 1) / LM_SJ_TILE, LM_HIP_EMULATED ? 2 : 64);
-            hipLaunchKernelGGL(lm_k_selfjoin, dim3(gx, gy), dim3(256), 0, st, d_box, nS, d_np, d_pairs, cap_pairs);
-            LM_HIP(hipMemcpyAsync(&np, d_np, sizeof(int), hipMemcpyDeviceToHost, st));
-            LM_HIP(hipStreamSynchronize(st));
-            if (np <= cap_pairs) break;
-            cap_pairs = np + (np >> 3);     // grow and redo (the join is cheap; the small buffer stays in the arena)
-        }
-        if (np > 0) {
-            int32_t* d_match = (int32_t*)lm_galloc(g, (size_t)np * sizeof(int32_t));
-            if (!d_match) return LM_ERR_HIP;
-            hipLaunchKernelGGL(lm_k_pair_overlap, dim3(LM_HIP_EMULATED ? 2 : 1024), dim3(256), 0, st, s->cc, s->crop, d_cc, d_pairs, np, d_match);
-            std::vector<int2> hp((size_t)np);
-            std::vector<int32_t> hm((size_t)np);
-            LM_HIP(hipMemcpyAsync(hp.data(), d_pairs, (size_t)np * sizeof(int2), hipMemcpyDeviceToHost, st));
-            LM_HIP(hipMemcpyAsync(hm.data(), d_match, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            LM_HIP(hipStreamSynchronize(st));
-            std::vector<int32_t> order((size_t)np);
-            for (int i = 0; i < np; i++) order[i] = i;
-            std::sort(order.begin(), order.end(), [&](int x, int y) { return hp[x].x != hp[y].x ? hp[x].x < hp[y].x : hp[x].y < hp[y].y; });
-            g->pair_a.resize(np); g->pair_b.resize(np); g->pair_match.resize(np);
-            for (int i = 0; i < np; i++) {
-                const int o = order[i];
-                g->pair_a[i] = g->stable[hp[o].x]; g->pair_b[i] = g->stable[hp[o].y]; g->pair_match[i] = hm[o];
-            }
-        }
+    g->n_stable = nS;
+    std::vector<int32_t> s_cc((size_t)nS), s_first((size_t)nS), s_last((size_t)nS);
+    std::vector<int32_t> sidx_of_unique((size_t)nU, -1);
+    for (int i = 0; i < nS; i++) {
+        const int u = g->stable[i];
+        s_cc[i] = g->uniq_cc[u]; s_first[i] = first_frame(u); s_last[i] = last_frame(u);
+        sidx_of_unique[u] = i;
     }
-    tm.mark("self-join + overlaps (device)");
-    // per-unique neighbour lists, filled in sorted pair order (== the reference's iteration order)
-    struct Tov { int32_t other; double recall, precision; };
-    struct Aov { int32_t other, matched, size_other, size_self; };
-    const size_t npairs = g->pair_a.size();
-    std::vector<uint8_t> pkind(npairs, 0);              // 1: all-overlap only, 2: also inside the time window
-    std::vector<double> precall(npairs), pprec(npairs);
-    std::vector<int64_t> tov_cnt((size_t)nU + 1, 0), aov_cnt((size_t)nU + 1, 0);
+    int32_t *d_scc, *d_sfirst, *d_slast, *d_suid, *d_ssize;
+    unsigned long long* d_sbox;
+    if (lm_upload(g, s_cc, &d_scc, st) || lm_upload(g, s_first, &d_sfirst, st) || lm_upload(g, s_last, &d_slast, st) ||
+        lm_upload(g, g->stable, &d_suid, st))
+        return LM_ERR_HIP;
+    d_sbox = (unsigned long long*)lm_galloc(g, (size_t)std::max(nS, 1) * sizeof(unsigned long long));
+    d_ssize = (int32_t*)lm_galloc(g, (size_t)std::max(nS, 1) * sizeof(int32_t));
+    unsigned long long* d_tot = (unsigned long long*)lm_galloc(g, 8 * sizeof(unsigned long long));
+    if (!d_sbox || !d_ssize || !d_tot) return LM_ERR_HIP;
+    LM_HIP(hipMemsetAsync(d_tot, 0, 8 * sizeof(unsigned long long), st));
+    std::vector<unsigned long long> s_box;      // host copies for the group boxes
+    std::vector<int32_t> s_size;
     g->total_intersections = 0;
-    for (size_t i = 0; i < npairs; i++) {
-        const int a = g->pair_a[i], b = g->pair_b[i];
-        const int match = g->pair_match[i];
-        const double recall = (double)match / (double)usize(a);         // connected_component.py:239
-        const double precision = (double)match / (double)usize(b);      // :240
-        precall[i] = recall; pprec[i] = precision;
-        if (recall > 0.0 || precision > 0.0) {
-            pkind[i] = 1;
-            aov_cnt[(size_t)a + 1]++; aov_cnt[(size_t)b + 1]++;
-            if (last_frame(a) + g->t_window >= first_frame(b) && last_frame(b) >= first_frame(a) - g->t_window) {
-                pkind[i] = 2;
-                tov_cnt[(size_t)a + 1]++; tov_cnt[(size_t)b + 1]++;
-                g->total_intersections++;
+    std::vector<unsigned> str_off((size_t)nS + 1, 0);
+    std::vector<int32_t> str_j;
+    if (nS > 0) {
+        hipLaunchKernelGGL(lm_k_stable_gather, dim3(lm_gblocks(nS, 256, 1024)), dim3(256), 0, st, s->cc, d_scc, nS, d_sbox, d_ssize);
+        // ---- adjacency of the stable uniques (:245-306)
+        g->d_adj_off = (unsigned*)lm_galloc(g, ((size_t)nS + 1) * sizeof(unsigned));
+        if (!g->d_adj_off) return LM_ERR_HIP;
+        const unsigned row_blocks = lm_gblocks(nS, 4, 4096);       // one wave per row, four rows per workgroup
+        hipLaunchKernelGGL((lm_k_adj_rows<0>), dim3(row_blocks), dim3(256), 0, st, d_sbox, nS, g->d_adj_off, (int32_t*)nullptr, (int32_t*)nullptr);
+        hipLaunchKernelGGL(lm_k_scan_u32, dim3(1), dim3(1024), 0, st, g->d_adj_off, g->d_adj_off, nS, d_tot);
+        unsigned long long h_tot[8];
+        LM_HIP(hipMemcpyAsync(h_tot, d_tot, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        LM_HIP(hipStreamSynchronize(st));
+        if (h_tot[0] >= (1ull << 31)) { lm_set_error("lm_group_run: %llu overlapping stable pairs (limit 2^31)", h_tot[0]); return LM_ERR_CAPACITY; }
+        const long long ne = (long long)h_tot[0];
+        g->n_adj = ne;
+        const size_t ne1 = (size_t)std::max<long long>(ne, 1);
+        g->d_adj = (int32_t*)lm_galloc(g, ne1 * sizeof(int32_t));
+        g->d_arow = (int32_t*)lm_galloc(g, ne1 * sizeof(int32_t));
+        g->d_match = (int32_t*)lm_galloc(g, ne1 * sizeof(int32_t));
+        g->d_aov_off = (unsigned*)lm_galloc(g, ((size_t)nS + 1) * sizeof(unsigned));
+        g->d_tov_off = (unsigned*)lm_galloc(g, ((size_t)nS + 1) * sizeof(unsigned));
+        unsigned* d_str_off = (unsigned*)lm_galloc(g, ((size_t)nS + 1) * sizeof(unsigned));
+        if (!g->d_adj || !g->d_arow || !g->d_match || !g->d_aov_off || !g->d_tov_off || !d_str_off) return LM_ERR_HIP;
+        tm.mark("adjacency: count + scan", st, true);
+        hipLaunchKernelGGL((lm_k_adj_rows<1>), dim3(row_blocks), dim3(256), 0, st, d_sbox, nS, g->d_adj_off, g->d_adj, g->d_arow);
+        tm.mark("adjacency: fill", st, true);
+        if (ne > 0) {
+            hipLaunchKernelGGL(lm_k_adj_match, dim3(lm_gblocks(ne, 16, 8192)), dim3(256), 0, st, s->cc, s->crop, d_scc, g->d_adj, g->d_arow, ne, g->d_match);
+            tm.mark("adjacency: pixel overlaps", st, true);
+            hipLaunchKernelGGL(lm_k_adj_mirror, dim3(lm_gblocks(ne, 256, 8192)), dim3(256), 0, st, g->d_adj_off, g->d_adj, g->d_arow, ne, g->d_match);
+        }
+        LmAdjTab A;
+        A.off = g->d_adj_off; A.adj = g->d_adj; A.match = g->d_match; A.size = d_ssize; A.first = d_sfirst; A.last = d_slast; A.uid = d_suid;
+        A.n = nS; A.t_window = g->t_window; A.min_recall = g->min_recall;
+        LmAdjOut O;
+        memset(&O, 0, sizeof(O));
+        O.aov_off = g->d_aov_off; O.tov_off = g->d_tov_off; O.str_off = d_str_off; O.total_intersections = d_tot + 1;
+        hipLaunchKernelGGL((lm_k_adj_lists<0>), dim3(row_blocks), dim3(256), 0, st, A, O);
+        hipLaunchKernelGGL(lm_k_scan_u32, dim3(1), dim3(1024), 0, st, g->d_aov_off, g->d_aov_off, nS, d_tot + 2);
+        hipLaunchKernelGGL(lm_k_scan_u32, dim3(1), dim3(1024), 0, st, g->d_tov_off, g->d_tov_off, nS, d_tot + 3);
+        hipLaunchKernelGGL(lm_k_scan_u32, dim3(1), dim3(1024), 0, st, d_str_off, d_str_off, nS, d_tot + 4);
+        LM_HIP(hipMemcpyAsync(h_tot, d_tot, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        LM_HIP(hipStreamSynchronize(st));
+        g->total_intersections = (int64_t)h_tot[1];
+        g->n_aov = (long long)h_tot[2];
+        g->n_tov = (long long)h_tot[3];
+        const long long n_str = (long long)h_tot[4];
+        tm.mark("neighbour lists: kinds + counts");
+        const size_t na1 = (size_t)std::max<long long>(g->n_aov, 1), nt1 = (size_t)std::max<long long>(g->n_tov, 1);
+        g->d_aov_j = (int32_t*)lm_galloc(g, na1 * sizeof(int32_t));
+        g->d_aov_other = (int32_t*)lm_galloc(g, na1 * sizeof(int32_t));
+        g->d_aov_matched = (int32_t*)lm_galloc(g, na1 * sizeof(int32_t));
+        g->d_aov_size_other = (int32_t*)lm_galloc(g, na1 * sizeof(int32_t));
+        g->d_aov_size_self = (int32_t*)lm_galloc(g, na1 * sizeof(int32_t));
+        g->d_tov_other = (int32_t*)lm_galloc(g, nt1 * sizeof(int32_t));
+        g->d_tov_recall = (double*)lm_galloc(g, nt1 * sizeof(double));
+        g->d_tov_precision = (double*)lm_galloc(g, nt1 * sizeof(double));
+        int32_t* d_str_j = (int32_t*)lm_galloc(g, (size_t)std::max<long long>(n_str, 1) * sizeof(int32_t));
+        if (!g->d_aov_j || !g->d_aov_other || !g->d_aov_matched || !g->d_aov_size_other || !g->d_aov_size_self || !g->d_tov_other ||
+            !g->d_tov_recall || !g->d_tov_precision || !d_str_j)
+            return LM_ERR_HIP;
+        O.aov_j = g->d_aov_j; O.aov_other = g->d_aov_other; O.aov_matched = g->d_aov_matched; O.aov_size_other = g->d_aov_size_other;
+        O.aov_size_self = g->d_aov_size_self; O.tov_other = g->d_tov_other; O.tov_recall = g->d_tov_recall; O.tov_precision = g->d_tov_precision;
+        O.str_j = d_str_j;
+        hipLaunchKernelGGL((lm_k_adj_lists<1>), dim3(row_blocks), dim3(256), 0, st, A, O);
+        // what compute_groups follows, and the boxes / sizes of the stable uniques, to the host
+        unsigned* h_str_off = (unsigned*)lm_gpin(g, ((size_t)nS + 1) * sizeof(unsigned));
+        int32_t* h_str_j = (int32_t*)lm_gpin(g, (size_t)std::max<long long>(n_str, 1) * sizeof(int32_t));
+        unsigned long long* h_box = (unsigned long long*)lm_gpin(g, (size_t)nS * sizeof(unsigned long long));
+        int32_t* h_size = (int32_t*)lm_gpin(g, (size_t)nS * sizeof(int32_t));
+        if (!h_str_off || !h_str_j || !h_box || !h_size) return LM_ERR_HIP;
+        LM_HIP(hipMemcpyAsync(h_str_off, d_str_off, ((size_t)nS + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        if (n_str > 0) LM_HIP(hipMemcpyAsync(h_str_j, d_str_j, (size_t)n_str * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        LM_HIP(hipMemcpyAsync(h_box, d_sbox, (size_t)nS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        LM_HIP(hipMemcpyAsync(h_size, d_ssize, (size_t)nS * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        LM_HIP(hipStreamSynchronize(st));
+        str_off.assign(h_str_off, h_str_off + nS + 1);
+        str_j.assign(h_str_j, h_str_j + n_str);
+        s_box.assign(h_box, h_box + nS);
+        s_size.assign(h_size, h_size + nS);
+        tm.mark("neighbour lists: fill + strong edges D2H");
+        if (tm.on) fprintf(stderr, "[lm_group]   stable %d adjacency %lld aov %lld tov %lld strong %lld\n", nS, ne, g->n_aov, g->n_tov, n_str);
+
+        // ---- compute_groups (:308-413): sequential, order-dependent; works on stable indices
+        std::vector<std::vector<int32_t>> groups;
+        std::vector<int32_t> sg((size_t)nS, -1);
+        for (int a = 0; a < nS; a++) {
+            int gi;
+            if (sg[a] >= 0) gi = sg[a];
+            else { gi = (int)groups.size(); groups.push_back({a}); sg[a] = gi; }
+            for (unsigned e = str_off[a]; e < str_off[(size_t)a + 1]; e++) {
+                const int b = str_j[e];
+                if (sg[b] < 0) { sg[b] = gi; groups[gi].push_back(b); }
+                else if (sg[b] != gi) {
+                    const int og = sg[b];
+                    for (int m : groups[og]) { sg[m] = gi; groups[gi].push_back(m); }
+                    groups[og].clear();
+                }
             }
         }
-    }
-    for (int u = 0; u < nU; u++) { tov_cnt[(size_t)u + 1] += tov_cnt[u]; aov_cnt[(size_t)u + 1] += aov_cnt[u]; }
-    std::vector<Tov> tov_flat((size_t)tov_cnt[nU]);
-    std::vector<Aov> aov_flat((size_t)aov_cnt[nU]);
-    {
-        std::vector<int64_t> tp(tov_cnt.begin(), tov_cnt.end() - 1), ap(aov_cnt.begin(), aov_cnt.end() - 1);
-        for (size_t i = 0; i < npairs; i++) {
-            if (!pkind[i]) continue;
-            const int a = g->pair_a[i], b = g->pair_b[i];
-            const int sa = usize(a), sb = usize(b);
-            const int matched_pixels = (int)((double)sa * precall[i]);   // float64 round trip, can be match-1 (:294)
-            aov_flat[(size_t)ap[a]++] = {b, matched_pixels, sb, sa};
-            aov_flat[(size_t)ap[b]++] = {a, matched_pixels, sa, sb};
-            if (pkind[i] == 2) {
-                tov_flat[(size_t)tp[a]++] = {b, precall[i], pprec[i]};
-                tov_flat[(size_t)tp[b]++] = {a, pprec[i], precall[i]};
-            }
+        g->grp_off.assign(1, 0);
+        g->grp_members.clear();
+        g->gid_of_unique.assign((size_t)nU, -1);
+        for (auto& grp : groups) {
+            if (grp.empty()) continue;
+            const int ng = (int)g->grp_off.size() - 1;
+            for (int m : grp) { g->grp_members.push_back(g->stable[m]); g->gid_of_unique[g->stable[m]] = ng; }
+            g->grp_off.push_back((int64_t)g->grp_members.size());
         }
-    }
-    struct TovRange { const Tov *b, *e; const Tov* begin() const { return b; } const Tov* end() const { return e; } };
-    struct AovRange { const Aov *b, *e; const Aov* begin() const { return b; } const Aov* end() const { return e; } };
-    auto tov = [&](int u) { return TovRange{tov_flat.data() + tov_cnt[u], tov_flat.data() + tov_cnt[(size_t)u + 1]}; };
-    auto aov = [&](int u) { return AovRange{aov_flat.data() + aov_cnt[u], aov_flat.data() + aov_cnt[(size_t)u + 1]}; };
-    tm.mark("neighbour lists");
-    // ---- compute_groups (:308-413): sequential, order-dependent
-    std::vector<std::vector<int32_t>> groups;
-    std::vector<int32_t> gid((size_t)nU, -1);
-    for (int a : g->stable) {
-        int gi;
-        if (gid[a] >= 0) gi = gid[a];
-        else { gi = (int)groups.size(); groups.push_back({a}); gid[a] = gi; }
-        for (const Tov& t : tov(a)) {
-            if (t.recall < g->min_recall) continue;
-            const int b = t.other;
-            if (gid[b] < 0) { gid[b] = gi; groups[gi].push_back(b); }
-            else if (gid[b] != gi) {
-                const int og = gid[b];
-                for (int m : groups[og]) { gid[m] = gi; groups[gi].push_back(m); }
-                groups[og].clear();
-            }
-        }
-    }
-    g->grp_off.assign(1, 0);
-    g->grp_members.clear();
-    g->gid_of_unique.assign((size_t)nU, -1);
-    for (auto& grp : groups) {
-        if (grp.empty()) continue;
-        const int ng = (int)g->grp_off.size() - 1;
-        for (int m : grp) { g->grp_members.push_back(m); g->gid_of_unique[m] = ng; }
-        g->grp_off.push_back((int64_t)g->grp_members.size());
+    } else {
+        g->grp_off.assign(1, 0);
+        g->grp_members.clear();
+        g->gid_of_unique.assign((size_t)nU, -1);
     }
     const int nG = (int)g->grp_off.size() - 1;
     tm.mark("compute_groups");
@@ -770,19 +1212,22 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
     g->ages_off.assign(1, 0); g->ages.clear();
     std::vector<int32_t> g_from((size_t)nG), g_to((size_t)nG);      // live frame range [from, to) of every group
     std::vector<int64_t> fcnt((size_t)F + 2, 0);
-    for (int gi = 0; gi < nG; gi++) {
+    {
         std::vector<int32_t> a;
-        for (int64_t i = g->grp_off[gi]; i < g->grp_off[(size_t)gi + 1]; i++) {
-            const int u = g->grp_members[(size_t)i];
-            a.push_back(first_frame(u));
-            a.push_back(last_frame(u));
+        for (int gi = 0; gi < nG; gi++) {
+            a.clear();
+            for (int64_t i = g->grp_off[gi]; i < g->grp_off[(size_t)gi + 1]; i++) {
+                const int u = g->grp_members[(size_t)i];
+                a.push_back(first_frame(u));
+                a.push_back(last_frame(u));
+            }
+            std::sort(a.begin(), a.end());
+            a.erase(std::unique(a.begin(), a.end()), a.end());
+            for (int v : a) g->ages.push_back(v);
+            g->ages_off.push_back((int64_t)g->ages.size());
+            g_from[gi] = a.front(); g_to[gi] = std::max(a.front(), std::min(a.back() + 1, F));
+            if (g_to[gi] > g_from[gi]) { fcnt[(size_t)g_from[gi] + 1]++; fcnt[(size_t)g_to[gi] + 1]--; }
         }
-        std::sort(a.begin(), a.end());
-        a.erase(std::unique(a.begin(), a.end()), a.end());
-        for (int v : a) g->ages.push_back(v);
-        g->ages_off.push_back((int64_t)g->ages.size());
-        g_from[gi] = a.front(); g_to[gi] = std::max(a.front(), std::min(a.back() + 1, F));
-        if (g_to[gi] > g_from[gi]) { fcnt[(size_t)g_from[gi] + 1]++; fcnt[(size_t)g_to[gi] + 1]--; }
     }
     // per-frame lists in ascending group index: difference array -> counts -> offsets -> fill
     g->gpf_off.assign((size_t)F + 1, 0);
@@ -795,189 +1240,253 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
             for (int f = g_from[gi]; f < g_to[gi]; f++) g->gpf[(size_t)cur[f]++] = gi;
     }
     tm.mark("ages + groups_per_frame");
-    // ---- conflicts (:446-500); emitted grouped by g1 in first-insertion order of g2
-    {
-        struct Acc { int64_t matched = 0, unmatched = 0, area_union = 0; double inter = 0; };
-        std::vector<std::vector<std::pair<int32_t, Acc>>> conf((size_t)nG);
-        std::vector<std::unordered_map<int32_t, int32_t>> idx((size_t)nG);
-        auto add = [&](int x, int y, int64_t m, int64_t um, int64_t au, double ai) {
-            auto it = idx[x].find(y);
-            if (it == idx[x].end()) { idx[x][y] = (int32_t)conf[x].size(); conf[x].push_back({y, Acc()}); it = idx[x].find(y); }
-            Acc& a = conf[x][it->second].second;
-            a.matched += m; a.unmatched += um; a.area_union += au; a.inter += ai;
-        };
-        auto area = [&](int u) { return (int64_t)(ubox(u, 1) - ubox(u, 0) + 1) * (ubox(u, 3) - ubox(u, 2) + 1); };
-        for (int a : g->stable)
-            for (const Aov& t : aov(a)) {
-                const int b = t.other;
-                if (!(a < b)) continue;
-                const int64_t unmatched = (int64_t)t.size_self + t.size_other - (int64_t)t.matched * 2;
-                int64_t inter = 0;
-                if (ubox(a, 0) <= ubox(b, 1) && ubox(b, 0) <= ubox(a, 1) && ubox(a, 2) <= ubox(b, 3) && ubox(b, 2) <= ubox(a, 3))
-                    inter = (int64_t)(std::min(ubox(a, 1), ubox(b, 1)) - std::max(ubox(a, 0), ubox(b, 0)) + 1) *
-                            (std::min(ubox(a, 3), ubox(b, 3)) - std::max(ubox(a, 2), ubox(b, 2)) + 1);
-                const int64_t uni = area(a) + area(b) - inter;
-                const int ga = g->gid_of_unique[a], gb = g->gid_of_unique[b];
-                if (ga == gb) continue;
-                add(ga, gb, t.matched, unmatched, uni, (double)inter);
-                add(gb, ga, t.matched, unmatched, uni, (double)inter);
+    // ---- conflicts (:446-500): aggregated on the device per unordered group pair, ordered here.  The reference's dict of
+    // dicts is emitted grouped by g1, inner entries in first-insertion order.
+    g->conf_g1.clear(); g->conf_g2.clear(); g->conf_matched.clear(); g->conf_unmatched.clear(); g->conf_union.clear(); g->conf_inter.clear();
+    if (nS > 0 && g->n_aov > 0) {
+        std::vector<int32_t> sgid((size_t)nS);
+        for (int i = 0; i < nS; i++) sgid[i] = g->gid_of_unique[g->stable[i]];
+        int32_t* d_sgid;
+        if (lm_upload(g, sgid, &d_sgid, st)) return LM_ERR_HIP;
+        unsigned cap = 1024;
+        while ((long long)cap < std::min<long long>(g->n_aov, 1ll << 22)) cap <<= 1;
+        cap <<= 1;
+        LmConfRow* h_rows = nullptr;
+        unsigned n_rows = 0;
+        for (;;) {
+            LmConfTable T;
+            T.key = (unsigned long long*)lm_galloc(g, (size_t)cap * 6 * sizeof(unsigned long long));
+            unsigned* d_cnt = (unsigned*)lm_galloc(g, 256);
+            if (!T.key || !d_cnt) return LM_ERR_HIP;
+            T.matched = T.key + cap; T.unmatched = T.key + 2 * (size_t)cap; T.uni = T.key + 3 * (size_t)cap; T.inter = T.key + 4 * (size_t)cap;
+            T.first = T.key + 5 * (size_t)cap;
+            T.cap_mask = cap - 1;
+            T.overflow = (int*)(d_cnt + 1);
+            LM_HIP(hipMemsetAsync(T.key, 0xff, (size_t)cap * sizeof(unsigned long long), st));
+            LM_HIP(hipMemsetAsync(T.matched, 0, (size_t)cap * 4 * sizeof(unsigned long long), st));
+            LM_HIP(hipMemsetAsync(T.first, 0xff, (size_t)cap * sizeof(unsigned long long), st));
+            LM_HIP(hipMemsetAsync(d_cnt, 0, 256, st));
+            hipLaunchKernelGGL(lm_k_conflicts, dim3(lm_gblocks(nS, 4, 4096)), dim3(256), 0, st, g->d_aov_off, g->d_aov_j, g->d_aov_matched,
+                               g->d_aov_size_other, g->d_aov_size_self, d_sbox, d_sgid, nS, T);
+            LmConfRow* d_rows = (LmConfRow*)lm_galloc(g, (size_t)cap * sizeof(LmConfRow));
+            if (!d_rows) return LM_ERR_HIP;
+            hipLaunchKernelGGL(lm_k_conf_compact, dim3(lm_gblocks(cap, 256, 2048)), dim3(256), 0, st, T, cap, d_rows, d_cnt, cap);
+            unsigned h_cnt[2] = {0, 0};
+            LM_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
+            LM_HIP(hipStreamSynchronize(st));
+            if (h_cnt[1] || h_cnt[0] > cap / 2 + cap / 4) { cap <<= 1; continue; }      // too full: probe chains degrade; redo larger
+            n_rows = h_cnt[0];
+            if (n_rows) {
+                h_rows = (LmConfRow*)lm_gpin(g, (size_t)n_rows * sizeof(LmConfRow));
+                if (!h_rows) return LM_ERR_HIP;
+                LM_HIP(hipMemcpyAsync(h_rows, d_rows, (size_t)n_rows * sizeof(LmConfRow), hipMemcpyDeviceToHost, st));
+                LM_HIP(hipStreamSynchronize(st));
             }
-        g->conf_g1.clear(); g->conf_g2.clear(); g->conf_matched.clear(); g->conf_unmatched.clear(); g->conf_union.clear(); g->conf_inter.clear();
-        for (int x = 0; x < nG; x++)
-            for (auto& e : conf[x]) {
-                g->conf_g1.push_back(x); g->conf_g2.push_back(e.first); g->conf_matched.push_back(e.second.matched);
-                g->conf_unmatched.push_back(e.second.unmatched); g->conf_union.push_back(e.second.area_union); g->conf_inter.push_back(e.second.inter);
+            break;
+        }
+        // both directions of every pair, bucketed by g1 (counting sort), inner order = first touch
+        struct Ent { unsigned long long first; int32_t g2; uint32_t row; };
+        std::vector<int64_t> coff((size_t)nG + 1, 0);
+        for (unsigned i = 0; i < n_rows; i++) { coff[(size_t)(h_rows[i].key >> 32) + 1]++; coff[(size_t)(h_rows[i].key & 0xffffffffu) + 1]++; }
+        for (int x = 0; x < nG; x++) coff[(size_t)x + 1] += coff[x];
+        std::vector<Ent> ents((size_t)coff[nG]);
+        {
+            std::vector<int64_t> cur(coff.begin(), coff.end() - 1);
+            for (unsigned i = 0; i < n_rows; i++) {
+                const int32_t lo = (int32_t)(h_rows[i].key >> 32), hi = (int32_t)(h_rows[i].key & 0xffffffffu);
+                ents[(size_t)cur[lo]++] = {h_rows[i].first, hi, i};
+                ents[(size_t)cur[hi]++] = {h_rows[i].first, lo, i};
             }
+        }
+        const size_t ntot = ents.size();
+        g->conf_g1.resize(ntot); g->conf_g2.resize(ntot); g->conf_matched.resize(ntot); g->conf_unmatched.resize(ntot);
+        g->conf_union.resize(ntot); g->conf_inter.resize(ntot);
+        for (int x = 0; x < nG; x++) {
+            if (coff[(size_t)x + 1] - coff[x] > 1)
+                std::sort(ents.begin() + coff[x], ents.begin() + coff[(size_t)x + 1], [](const Ent& a, const Ent& b) { return a.first < b.first; });
+            for (int64_t i = coff[x]; i < coff[(size_t)x + 1]; i++) {
+                const Ent& e = ents[(size_t)i];
+                const LmConfRow& r = h_rows[e.row];
+                g->conf_g1[(size_t)i] = x; g->conf_g2[(size_t)i] = e.g2; g->conf_matched[(size_t)i] = (int64_t)r.matched;
+                g->conf_unmatched[(size_t)i] = (int64_t)r.unmatched; g->conf_union[(size_t)i] = (int64_t)r.uni;
+                g->conf_inter[(size_t)i] = (double)(int64_t)r.inter;
+            }
+        }
     }
     tm.mark("conflicts");
-    // flatten the neighbour lists
-    g->tov_off.assign(1, 0); g->tov_other.clear(); g->tov_recall.clear(); g->tov_precision.clear();
-    g->aov_off.assign(1, 0); g->aov_other.clear(); g->aov_matched.clear(); g->aov_size_other.clear(); g->aov_size_self.clear();
-    for (int u = 0; u < nU; u++) {
-        for (const Tov& t : tov(u)) { g->tov_other.push_back(t.other); g->tov_recall.push_back(t.recall); g->tov_precision.push_back(t.precision); }
-        g->tov_off.push_back((int64_t)g->tov_other.size());
-        for (const Aov& t : aov(u)) { g->aov_other.push_back(t.other); g->aov_matched.push_back(t.matched); g->aov_size_other.push_back(t.size_other); g->aov_size_self.push_back(t.size_self); }
-        g->aov_off.push_back((int64_t)g->aov_other.size());
-    }
-    tm.mark("flatten neighbour lists");
-    // ---- group images (:575-636)
-    std::vector<int32_t> ulist_frame(g->ulist_cc.size());
-    for (size_t e = 0; e < g->ulist_cc.size(); e++) ulist_frame[e] = cc_frame[(size_t)g->ulist_cc[e]];
-    tm.mark("  gimg: entry frames");
+    // ---- group images (:575-636): item = (group, age segment); boxes and offsets here, member / tile tables on the device
     g->bounds.assign((size_t)nG * 4, 0);
-    std::vector<LmGimgItem> items;
-    std::vector<LmGimgMember> members;
-    std::vector<LmGimgUnit> units;
     g->gimg_off.assign(1, 0);
     g->gbits_off.clear();
-    long long bit_words = 0;
     g->gimg_item_off.assign(1, 0);
-    // Groups are independent here: contiguous chunks of groups are tabulated by a few host threads into local tables
-    // (offsets relative to the chunk), then concatenated in group order.
-    struct Chunk {
-        std::vector<LmGimgItem> items; std::vector<LmGimgMember> members; std::vector<LmGimgUnit> units;
-        std::vector<int64_t> item_end;          // items of the chunk up to and including each group
-        long long img_bytes = 0, bit_words = 0;
-    };
-    const int n_chunks = std::max(1, std::min(LM_GROUP_THREADS, nG / 64));
-    std::vector<Chunk> chunks((size_t)n_chunks);
-    auto tabulate = [&](int ci) {
-        Chunk& ck = chunks[(size_t)ci];
-        std::vector<int32_t> seg_cnt;
-        const int g_lo = (int)((long long)nG * ci / n_chunks), g_hi = (int)((long long)nG * (ci + 1) / n_chunks);
-        for (int gi = g_lo; gi < g_hi; gi++) {
-            int x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
-            for (int64_t i = g->grp_off[gi]; i < g->grp_off[(size_t)gi + 1]; i++) {
-                const int u = g->grp_members[(size_t)i];
-                x0 = std::min(x0, (int)ubox(u, 0)); x1 = std::max(x1, (int)ubox(u, 1));
-                y0 = std::min(y0, (int)ubox(u, 2)); y1 = std::max(y1, (int)ubox(u, 3));
-            }
-            g->bounds[(size_t)gi * 4 + 0] = x0; g->bounds[(size_t)gi * 4 + 1] = x1; g->bounds[(size_t)gi * 4 + 2] = y0; g->bounds[(size_t)gi * 4 + 3] = y1;
-            const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-            // entries of every member inside every segment [ages[j], ages[j+1]] (both ends included, duplicates counted, :619):
-            // a unique's entries and the ages are ascending, so one two-pointer walk per member serves all segments
-            const int nm = (int)(g->grp_off[(size_t)gi + 1] - g->grp_off[gi]);
-            const int ns = (int)(g->ages_off[(size_t)gi + 1] - g->ages_off[gi]) - 1;
-            const int32_t* ag = g->ages.data() + g->ages_off[gi];
-            seg_cnt.assign((size_t)std::max(ns, 0) * nm, 0);
-            for (int mi = 0; mi < nm && ns > 0; mi++) {
-                const int u = g->grp_members[(size_t)g->grp_off[gi] + mi];
-                const int32_t* fe = ulist_frame.data() + g->ulist_off[(size_t)u + 1];
-                const int32_t *lo = ulist_frame.data() + g->ulist_off[u], *hi = lo;
-                for (int j = 0; j < ns; j++) {
-                    while (lo < fe && *lo < ag[j]) lo++;
-                    if (hi < lo) hi = lo;
-                    while (hi < fe && *hi <= ag[j + 1]) hi++;
-                    seg_cnt[(size_t)j * nm + mi] = (int32_t)(hi - lo);
-                }
-            }
-            for (int j = 0; j < ns; j++) {
-                LmGimgItem it;
-                it.x0 = x0; it.y0 = y0; it.w = w; it.h = h;
-                it.mem_off = (int32_t)ck.members.size();
-                for (int mi = 0; mi < nm; mi++) {
-                    const int count = seg_cnt[(size_t)j * nm + mi];
-                    if (count) ck.members.push_back({g->uniq_cc[g->grp_members[(size_t)g->grp_off[gi] + mi]], count});
-                }
-                it.mem_cnt = (int32_t)ck.members.size() - it.mem_off;
-                it.img_off = ck.img_bytes;
-                it.bits_off = ck.bit_words;
-                ck.img_bytes += (long long)w * h;
-                ck.bit_words += (long long)h * ((w + 31) >> 5);
-                const int item_idx = (int)ck.items.size();
-                ck.items.push_back(it);
-                for (int ty = 0; ty * LM_GT < h; ty++)
-                    for (int tx = 0; tx * LM_GT < w; tx++) ck.units.push_back({item_idx, (int16_t)tx, (int16_t)ty});
-            }
-            ck.item_end.push_back((int64_t)ck.items.size());
+    std::vector<LmGimgItem> items;
+    std::vector<int64_t> tile_off(1, 0);
+    std::vector<int32_t> slot_group(g->grp_members.size()), slot_cc(g->grp_members.size());
+    long long bit_words = 0;
+    for (int gi = 0; gi < nG; gi++) {
+        int x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
+        for (int64_t i = g->grp_off[gi]; i < g->grp_off[(size_t)gi + 1]; i++) {
+            const int u = g->grp_members[(size_t)i];
+            const unsigned long long b = s_box[(size_t)sidx_of_unique[u]];
+            x0 = std::min(x0, (int)(b & 0xffff)); x1 = std::max(x1, (int)((b >> 16) & 0xffff));
+            y0 = std::min(y0, (int)((b >> 32) & 0xffff)); y1 = std::max(y1, (int)(b >> 48));
+            slot_group[(size_t)i] = gi;
+            slot_cc[(size_t)i] = g->uniq_cc[u];
         }
-    };
-    tm.mark("  gimg: setup");
-    {
-        std::vector<std::thread> workers;
-        for (int ci = 1; ci < n_chunks; ci++) workers.emplace_back(tabulate, ci);
-        tabulate(0);
-        for (auto& t : workers) t.join();
-    }
-    tm.mark("  gimg: threads");
-    for (const Chunk& ck : chunks) {
-        const int64_t item0 = (int64_t)items.size();
-        const int32_t mem0 = (int32_t)members.size();
-        const long long img0 = g->gimg_off.back();
-        for (LmGimgItem it : ck.items) {
-            it.mem_off += mem0; it.img_off += img0; it.bits_off += bit_words;
-            g->gbits_off.push_back(it.bits_off);
-            g->gimg_off.push_back(it.img_off + (int64_t)it.w * it.h);
+        g->bounds[(size_t)gi * 4 + 0] = x0; g->bounds[(size_t)gi * 4 + 1] = x1; g->bounds[(size_t)gi * 4 + 2] = y0; g->bounds[(size_t)gi * 4 + 3] = y1;
+        const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+        const int ns = (int)(g->ages_off[(size_t)gi + 1] - g->ages_off[gi]) - 1;
+        const long long ntiles = (long long)((w + LM_GT - 1) / LM_GT) * ((h + LM_GT - 1) / LM_GT);
+        for (int j = 0; j < ns; j++) {
+            LmGimgItem it;
+            it.x0 = x0; it.y0 = y0; it.w = w; it.h = h;
+            it.img_off = g->gimg_off.back();
+            it.bits_off = bit_words;
+            g->gbits_off.push_back(bit_words);
+            g->gimg_off.push_back(it.img_off + (int64_t)w * h);
+            bit_words += (long long)h * ((w + 31) >> 5);
+            tile_off.push_back(tile_off.back() + ntiles);
             items.push_back(it);
         }
-        members.insert(members.end(), ck.members.begin(), ck.members.end());
-        for (LmGimgUnit un : ck.units) { un.item += (int32_t)item0; units.push_back(un); }
-        for (int64_t e : ck.item_end) g->gimg_item_off.push_back(item0 + e);
-        bit_words += ck.bit_words;
+        g->gimg_item_off.push_back((int64_t)items.size());
     }
-    if (tm.on) fprintf(stderr, "[lm_group]   groups %d items %zu members %zu units %zu chunks %d pairs %zu\n", nG, items.size(), members.size(), units.size(), n_chunks, g->pair_a.size());
-    tm.mark("  gimg: item tables");
-    const long long img_bytes = g->gimg_off.back();
-    g->d_images = (uint8_t*)lm_galloc(g, (size_t)std::max<long long>(img_bytes, 1));
+    const int n_items = (int)items.size();
+    const long long n_tiles = tile_off.back();
+    g->n_items = n_items;
+    tm.mark("  gimg: items (host)");
     g->d_gbits = (uint32_t*)lm_galloc(g, (size_t)std::max<long long>(bit_words, 1) * sizeof(uint32_t));
-    if (!g->d_images || !g->d_gbits) return LM_ERR_HIP;
-    if (!items.empty()) {
-        LmGimgItem* d_items; LmGimgMember* d_members; LmGimgUnit* d_units; int32_t* d_max;
-        if (lm_upload(g, items, &d_items, st) || lm_upload(g, members, &d_members, st) || lm_upload(g, units, &d_units, st)) return LM_ERR_HIP;
-        tm.mark("  gimg: uploads");
-        d_max = (int32_t*)lm_galloc(g, items.size() * sizeof(int32_t));
-        if (!d_max) return LM_ERR_HIP;
-        LM_HIP(hipMemsetAsync(d_max, 0, items.size() * sizeof(int32_t), st));
-        const int nb = (int)std::min<size_t>(units.size(), LM_HIP_EMULATED ? 2 : 4096);
-        hipLaunchKernelGGL(lm_k_gimg_max, dim3(nb), dim3(256), 0, st, d_items, d_units, (int)units.size(), d_members, s->cc, s->crop, d_max);
-        hipLaunchKernelGGL(lm_k_gimg_write, dim3(nb), dim3(256), 0, st, d_items, d_units, (int)units.size(), d_members, s->cc, s->crop,
-                           d_max, g->img_thr, g->d_images, g->d_gbits);
+    if (!g->d_gbits) return LM_ERR_HIP;
+    int64_t* d_gitem_first = nullptr;
+    int32_t *d_ages = nullptr;
+    if (n_items > 0) {
+        LmGimgTab T;
+        int32_t *d_slot_group, *d_slot_unique, *d_slot_cc, *d_ulist_frame, *d_bounds_g;
+        int64_t *d_ages_off64, *d_ulist_off, *d_tile_off;
+        std::vector<int64_t> gitem_first(g->gimg_item_off.begin(), g->gimg_item_off.end() - 1);
+        if (lm_upload(g, slot_group, &d_slot_group, st) || lm_upload(g, g->grp_members, &d_slot_unique, st) || lm_upload(g, slot_cc, &d_slot_cc, st) ||
+            lm_upload(g, g->ages, &d_ages, st) || lm_upload(g, g->ages_off, &d_ages_off64, st) || lm_upload(g, gitem_first, &d_gitem_first, st) ||
+            lm_upload(g, g->ulist_off, &d_ulist_off, st) || lm_upload(g, ulist_frame, &d_ulist_frame, st) || lm_upload(g, tile_off, &d_tile_off, st) ||
+            lm_upload(g, items, &g->d_items, st) || lm_upload(g, g->bounds, &d_bounds_g, st))
+            return LM_ERR_HIP;
+        T.slot_group = d_slot_group; T.slot_unique = d_slot_unique; T.slot_cc = d_slot_cc; T.n_slots = (int)g->grp_members.size();
+        T.ages = d_ages; T.ages_off = d_ages_off64; T.gitem_first = d_gitem_first; T.ulist_off = d_ulist_off; T.ulist_frame = d_ulist_frame;
+        T.tile_off = d_tile_off; T.bounds = d_bounds_g;
+        const size_t nt1 = (size_t)std::max<long long>(n_tiles, 1);
+        const int n_chunks = (int)((n_tiles + LM_SCAN_CHUNK - 1) / LM_SCAN_CHUNK);
+        unsigned* d_tile_cnt = (unsigned*)lm_galloc(g, (nt1 + 1) * sizeof(unsigned));
+        unsigned* d_tile_moff = (unsigned*)lm_galloc(g, (nt1 + 1) * sizeof(unsigned));
+        unsigned* d_chunk = (unsigned*)lm_galloc(g, ((size_t)n_chunks + 2) * sizeof(unsigned));
+        LmGimgUnit* d_units = (LmGimgUnit*)lm_galloc(g, nt1 * sizeof(LmGimgUnit));
+        int32_t* d_max = (int32_t*)lm_galloc(g, (size_t)n_items * sizeof(int32_t));
+        unsigned* d_nunits = (unsigned*)lm_galloc(g, 256);
+        if (!d_tile_cnt || !d_tile_moff || !d_chunk || !d_units || !d_max || !d_nunits) return LM_ERR_HIP;
+        LM_HIP(hipMemsetAsync(d_tile_cnt, 0, (nt1 + 1) * sizeof(unsigned), st));
+        LM_HIP(hipMemsetAsync(d_nunits, 0, 256, st));
+        LM_HIP(hipMemsetAsync(d_max, 0, (size_t)n_items * sizeof(int32_t), st));
+        LM_HIP(hipMemsetAsync(g->d_gbits, 0, (size_t)std::max<long long>(bit_words, 1) * sizeof(uint32_t), st));
+        const unsigned sb = lm_gblocks(T.n_slots, 256, 4096);
+        hipLaunchKernelGGL((lm_k_gimg_members<0>), dim3(sb), dim3(256), 0, st, T, d_tile_cnt, (const unsigned*)nullptr, (LmGimgMember*)nullptr, s->cc);
+        hipLaunchKernelGGL(lm_k_scan_chunks, dim3((unsigned)std::max(n_chunks, 1)), dim3(1024), 0, st, d_tile_cnt, d_tile_moff, n_tiles, d_chunk);
+        hipLaunchKernelGGL(lm_k_scan_u32, dim3(1), dim3(1024), 0, st, d_chunk, d_chunk, n_chunks, d_tot + 5);
+        hipLaunchKernelGGL(lm_k_scan_add, dim3(lm_gblocks(n_tiles + 1, 256, 4096)), dim3(256), 0, st, d_tile_moff, n_tiles, d_chunk, n_chunks);
+        unsigned long long h_nmem = 0;
+        LM_HIP(hipMemcpyAsync(&h_nmem, d_tot + 5, sizeof(h_nmem), hipMemcpyDeviceToHost, st));
+        LM_HIP(hipStreamSynchronize(st));
+        if (h_nmem >= (1ull << 32)) { lm_set_error("lm_group_run: %llu group-image tile members (limit 2^32)", h_nmem); return LM_ERR_CAPACITY; }
+        LmGimgMember* d_members = (LmGimgMember*)lm_galloc(g, (size_t)std::max<unsigned long long>(h_nmem, 1) * sizeof(LmGimgMember));
+        if (!d_members) return LM_ERR_HIP;
+        LM_HIP(hipMemsetAsync(d_tile_cnt, 0, (nt1 + 1) * sizeof(unsigned), st));
+        hipLaunchKernelGGL((lm_k_gimg_members<1>), dim3(sb), dim3(256), 0, st, T, d_tile_cnt, d_tile_moff, d_members, s->cc);
+        // a threshold <= 0 turns every pixel of every box on (0 / max >= thr): then every tile is visited
+        hipLaunchKernelGGL(lm_k_gimg_units, dim3(lm_gblocks(n_tiles, 256, 4096)), dim3(256), 0, st, d_tile_moff, n_tiles, d_tile_off, g->d_items, n_items,
+                           g->img_thr > 0.0 ? 0 : 1, d_units, d_nunits);
+        tm.mark("  gimg: member + tile tables (device)", st, true);
+        const unsigned nb = LM_HIP_EMULATED ? 2u : (unsigned)std::min<long long>(std::max<long long>(n_tiles, 1), 8192);
+        hipLaunchKernelGGL(lm_k_gimg_max, dim3(nb), dim3(256), 0, st, g->d_items, d_units, d_nunits, d_members, s->cc, s->crop, d_max);
+        hipLaunchKernelGGL(lm_k_gimg_write, dim3(nb), dim3(256), 0, st, g->d_items, d_units, d_nunits, d_members, s->cc, s->crop, d_max, g->img_thr,
+                           g->d_gbits);
         LM_HIP(hipGetLastError());
+        if (tm.on) {
+            unsigned nu_ = 0;
+            (void)hipMemcpyAsync(&nu_, d_nunits, 4, hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            fprintf(stderr, "[lm_group]   groups %d items %d tile members %llu tiles %lld visited %u conflicts %zu\n", nG, n_items, h_nmem, n_tiles, nu_,
+                    g->conf_g1.size());
+        }
+        tm.mark("  gimg: max + write", st, true);
     }
-    tm.mark("group images (host tables + device)");
     // ---- render tables for frames_from_groups (:638-681): one item per (frame, live group), built on the device
     if (reconstruct_tables) {
         std::vector<long long> fio(g->gpf_off.begin(), g->gpf_off.end());
         std::vector<int32_t> ages_off32(g->ages_off.begin(), g->ages_off.end());
-        std::vector<int64_t> gitem_first(g->gimg_item_off.begin(), g->gimg_item_off.end() - 1);
-        int32_t *d_gpf, *d_ages, *d_ages_off, *d_bounds;
-        int64_t *d_gitem_first, *d_gbits_off;
+        int32_t *d_gpf, *d_ages_off, *d_bounds;
+        int64_t* d_gbits_off;
         const size_t n_ritems = g->gpf.size();
         g->d_render_items = (LmRenderItem*)lm_galloc(g, std::max<size_t>(n_ritems, 1) * sizeof(LmRenderItem));
         if (!g->d_render_items) return LM_ERR_HIP;
         if (lm_upload(g, fio, &g->d_frame_item_off, st)) return LM_ERR_HIP;
         if (n_ritems) {
-            if (lm_upload(g, g->gpf, &d_gpf, st) || lm_upload(g, g->ages, &d_ages, st) || lm_upload(g, ages_off32, &d_ages_off, st) ||
-                lm_upload(g, g->bounds, &d_bounds, st) || lm_upload(g, gitem_first, &d_gitem_first, st) ||
+            if (lm_upload(g, g->gpf, &d_gpf, st) || lm_upload(g, ages_off32, &d_ages_off, st) || lm_upload(g, g->bounds, &d_bounds, st) ||
                 lm_upload(g, g->gbits_off, &d_gbits_off, st))
                 return LM_ERR_HIP;
             hipLaunchKernelGGL(lm_k_render_items, dim3((unsigned)((n_ritems + 255) / 256)), dim3(256), 0, st, g->d_frame_item_off, F, d_gpf,
                                d_ages, d_ages_off, d_bounds, d_gitem_first, d_gbits_off, g->d_render_items);
         }
-        LM_HIP(hipStreamSynchronize(st));      // the uploaded vectors are locals: the async copies must finish before they go away
     }
+    LM_HIP(hipGetLastError());
     LM_HIP(hipStreamSynchronize(st));
     tm.mark("render tables + final sync");
+    return LM_OK;
+}
+
+// PAIR_* / TOV_* / AOV_* arrays of lm_group_array: copied down and re-indexed by unique on first request
+static int lm_group_materialize_pairs(LmGroups* g)
+{
+    if (g->have_pairs) return LM_OK;
+    std::vector<int32_t> adj, arow, match;
+    hipStream_t st = nullptr;
+    if (g->n_adj > 0 && (lm_download(g, g->d_adj, (size_t)g->n_adj, adj, st) || lm_download(g, g->d_arow, (size_t)g->n_adj, arow, st) ||
+                         lm_download(g, g->d_match, (size_t)g->n_adj, match, st)))
+        return LM_ERR_HIP;
+    g->pair_a.clear(); g->pair_b.clear(); g->pair_match.clear();
+    for (long long e = 0; e < g->n_adj; e++)
+        if (arow[(size_t)e] < adj[(size_t)e]) {       // rows ascending, partners ascending: already sorted by (a, b)
+            g->pair_a.push_back(g->stable[arow[(size_t)e]]); g->pair_b.push_back(g->stable[adj[(size_t)e]]); g->pair_match.push_back(match[(size_t)e]);
+        }
+    g->have_pairs = true;
+    return LM_OK;
+}
+
+static int lm_group_materialize_neighbours(LmGroups* g)
+{
+    if (g->have_nbr) return LM_OK;
+    hipStream_t st = nullptr;
+    const size_t nU = g->uniq_cc.size();
+    const int nS = g->n_stable;
+    std::vector<unsigned> aoff, toff;
+    g->tov_off.assign(nU + 1, 0); g->aov_off.assign(nU + 1, 0);
+    if (nS > 0) {
+        if (lm_download(g, g->d_aov_off, (size_t)nS + 1, aoff, st) || lm_download(g, g->d_tov_off, (size_t)nS + 1, toff, st)) return LM_ERR_HIP;
+        if (lm_download(g, g->d_aov_other, (size_t)g->n_aov, g->aov_other, st) || lm_download(g, g->d_aov_matched, (size_t)g->n_aov, g->aov_matched, st) ||
+            lm_download(g, g->d_aov_size_other, (size_t)g->n_aov, g->aov_size_other, st) ||
+            lm_download(g, g->d_aov_size_self, (size_t)g->n_aov, g->aov_size_self, st) || lm_download(g, g->d_tov_other, (size_t)g->n_tov, g->tov_other, st) ||
+            lm_download(g, g->d_tov_recall, (size_t)g->n_tov, g->tov_recall, st) || lm_download(g, g->d_tov_precision, (size_t)g->n_tov, g->tov_precision, st))
+            return LM_ERR_HIP;
+        // rows of the device tables are the stable uniques in ascending unique index: the flat arrays are already in
+        // per-unique order, only the offsets have to be spread over all uniques
+        int si = 0;
+        for (size_t u = 0; u < nU; u++) {
+            if (si < nS && g->stable[si] == (int32_t)u) {
+                g->aov_off[u + 1] = g->aov_off[u] + (int64_t)(aoff[(size_t)si + 1] - aoff[si]);
+                g->tov_off[u + 1] = g->tov_off[u] + (int64_t)(toff[(size_t)si + 1] - toff[si]);
+                si++;
+            } else {
+                g->aov_off[u + 1] = g->aov_off[u];
+                g->tov_off[u + 1] = g->tov_off[u];
+            }
+        }
+    }
+    g->have_nbr = true;
     return LM_OK;
 }
 
@@ -1125,6 +1634,8 @@ extern "C" int lm_group_array(LmGroups* g, int which, const void** ptr, int64_t*
     if (!g || !ptr || !count) { lm_set_error("lm_group_array: bad arguments"); return LM_ERR_ARG; }
 #define LM_GA(id, vec) case id: *ptr = (vec).data(); *count = (int64_t)(vec).size(); return LM_OK;
     static thread_local int64_t scalars[8];
+    if (which >= LM_G_PAIR_A && which <= LM_G_PAIR_MATCH && lm_group_materialize_pairs(g)) return LM_ERR_HIP;
+    if (which >= LM_G_TOV_OFF && which <= LM_G_AOV_SIZE_SELF && lm_group_materialize_neighbours(g)) return LM_ERR_HIP;
     switch (which) {
         LM_GA(LM_G_UNIQ_CC, g->uniq_cc) LM_GA(LM_G_ULIST_OFF, g->ulist_off) LM_GA(LM_G_ULIST_CC, g->ulist_cc) LM_GA(LM_G_ASSIGN, g->assign)
         LM_GA(LM_G_STABLE, g->stable) LM_GA(LM_G_PAIR_A, g->pair_a) LM_GA(LM_G_PAIR_B, g->pair_b) LM_GA(LM_G_PAIR_MATCH, g->pair_match)
@@ -1137,10 +1648,18 @@ extern "C" int lm_group_array(LmGroups* g, int which, const void** ptr, int64_t*
         LM_GA(LM_G_CONF_UNMATCHED, g->conf_unmatched) LM_GA(LM_G_CONF_UNION, g->conf_union) LM_GA(LM_G_CONF_INTER, g->conf_inter)
         LM_GA(LM_G_BOUNDS, g->bounds) LM_GA(LM_G_GIMG_OFF, g->gimg_off) LM_GA(LM_G_GIMG_ITEM_OFF, g->gimg_item_off)
         case LM_G_GIMG: {
+            // the reference's uint8 segment images (compute_group_images :630), expanded from the bit rows on demand
             if (g->gimg_host.size() != (size_t)g->gimg_off.back()) {
                 g->gimg_host.resize((size_t)g->gimg_off.back());
-                if (!g->gimg_host.empty())
-                    LM_HIP(hipMemcpy(g->gimg_host.data(), g->d_images, g->gimg_host.size(), hipMemcpyDeviceToHost));
+                if (!g->gimg_host.empty()) {
+                    uint8_t* d_img = nullptr;
+                    LM_HIP(hipMalloc((void**)&d_img, g->gimg_host.size()));
+                    hipLaunchKernelGGL(lm_k_gimg_expand, dim3(LM_HIP_EMULATED ? 1 : 8, (unsigned)std::min(g->n_items, LM_HIP_EMULATED ? 2 : 4096)), dim3(256), 0,
+                                       (hipStream_t) nullptr, g->d_items, g->n_items, g->d_gbits, d_img);
+                    const hipError_t e = hipMemcpy(g->gimg_host.data(), d_img, g->gimg_host.size(), hipMemcpyDeviceToHost);
+                    (void)hipFree(d_img);
+                    LM_HIP(e);
+                }
             }
             *ptr = g->gimg_host.data(); *count = (int64_t)g->gimg_host.size();
             return LM_OK;

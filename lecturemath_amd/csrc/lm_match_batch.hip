@@ -37,6 +37,7 @@
 #define LM_MB_TTAB (1 << 18)     // twin table slots; batches with more than LM_MB_TTAB / 2 CCs skip twin detection
 #define LM_MB_CHUNK 4096        // source boxes filtered per round (LDS survivors list)
 #define LM_MB_MAX_FRAMES 64     // frames per batch (per-frame tables of the replay kernel live in LDS)
+#define LM_MB_BIGPAIR 2048       // words of a box intersection above which a pair is evaluated by a whole workgroup
 #ifndef LM_MB_CH
 #define LM_MB_CH 2048           // non-twin CCs of one frame resolved per LDS pass
 #endif
@@ -76,6 +77,9 @@ struct LmMatchBatch {
     unsigned long long* ttab;   // [LM_MB_TTAB] twin table: key32 << 32 | smallest batch-relative cc index with that key
     uint32_t* tkey;             // [cap_cc] per global cc: key32 of (box, size, crop); later: non-twins before this CC (lm_k_mb_nt)
     uint8_t* twin;              // [cap_cc] per global cc: 1 = exact twin of an earlier CC of the batch
+    uint32_t* big[2];           // [cap_big] pairs whose pixel intersection is left to a whole workgroup (lm_k_mb_eval_big)
+    unsigned* n_big;            // [2] their number (zeroed by lm_k_mb_twin_insert / lm_k_mb_nt)
+    uint32_t cap_big;
     uint32_t cap_pairs;
     int cap_tiles;
 };
@@ -144,6 +148,7 @@ __global__ void __launch_bounds__(1024) lm_k_mb_nt(const long long* __restrict__
     __shared__ int s_head[6];
     if (cnt->error) return;
     if ((int)blockIdx.x == B) {
+        if (threadIdx.x < 2) mb.n_big[threadIdx.x] = 0;        // filled by lm_k_mb_eval
         lm_mb_prologue(frame_cc_off, f0, B, active, active_cc, active_box, active_last, cnt, mb, max_gap);
         return;
     }
@@ -369,13 +374,27 @@ __global__ void __launch_bounds__(256) lm_k_mb_eval(const LmCcRec* __restrict__ 
         LmCcRec rec, urec;
         uint2 pr = make_uint2(0u, 0u);
         long long ci = 0;
+        bool possible = false, big = false;
+        LmIsect is;
         if (live) {
             pr = mb.pairs[SRC][p];
             const int ui = mb.pair_u[SRC][p];
             ci = (long long)mb.nt_list[pr.x];
             rec = cc[ci];
             urec = cc[ui];
-            const LmIsect is = lm_isect(rec, urec);
+            is = lm_isect(rec, urec);
+            // the common pixels cannot outnumber the smaller CC: most box neighbours of a large component are glyph-sized and
+            // fail the thresholds on the sizes alone
+            possible = lm_accept(rec.size < urec.size ? rec.size : urec.size, rec.size, urec.size, min_recall, min_precision);
+            big = possible && is.nwc * (is.y1 - is.y0 + 1) > LM_MB_BIGPAIR;
+        }
+        // a large intersection goes to the list of lm_k_mb_eval_big (a whole workgroup per pair) when there is room
+        unsigned slot = 0xffffffffu;
+        if (big && sub == 0) slot = atomicAdd(&mb.n_big[SRC], 1u);
+        slot = (unsigned)__shfl((int)slot, 0, 8);
+        const bool deferred = big && slot < mb.cap_big;
+        if (deferred && sub == 0) mb.big[SRC][slot] = p;
+        if (live && possible && !deferred) {
             // lane `sub` takes rows sub, sub + 8, ... of the intersection (no integer divisions)
             for (int y = is.y0 + sub; y <= is.y1; y += 8) {
                 const unsigned long long ra = rec.crop_off + (unsigned long long)((y - rec.min_y) * is.anw + (is.wc0 - is.awx0));
@@ -385,7 +404,7 @@ __global__ void __launch_bounds__(256) lm_k_mb_eval(const LmCcRec* __restrict__ 
         }
 #pragma unroll
         for (int d = 4; d >= 1; d >>= 1) m += __shfl_xor(m, d, 8);
-        if (live && sub == 0 && lm_accept(m, rec.size, urec.size, min_recall, min_precision)) {
+        if (live && possible && !deferred && sub == 0 && lm_accept(m, rec.size, urec.size, min_recall, min_precision)) {
             mb.pairs[SRC][p].x = pr.x | 0x80000000u;
             // alive at rec.frame even if the unique is never matched again: c cannot become a new unique
             if (SRC == 0 && lm_mb_alive(rec.frame, active_last[pr.y], max_gap)) mb.sidx[ci] = -1;
@@ -393,93 +412,176 @@ __global__ void __launch_bounds__(256) lm_k_mb_eval(const LmCcRec* __restrict__ 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// T: exact twins.  8 lanes per CC.
-// ------------------------------------------------------------------------------------------------
-LM_DEV unsigned lm_mix32(unsigned h) { h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16; return h; }
+// the pairs lm_k_mb_eval set aside: one workgroup per pair, a thread per word of the box intersection
+template <int SRC>
+__global__ void __launch_bounds__(256) lm_k_mb_eval_big(const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
+                                                        const int32_t* __restrict__ active_last, LmCounters* __restrict__ cnt, LmMatchBatch mb,
+                                                        double min_recall, double min_precision, int max_gap)
+{
+    __shared__ int s_sum;
+    if (cnt->error) return;
+    const unsigned n = mb.n_big[SRC] < mb.cap_big ? mb.n_big[SRC] : mb.cap_big;
+    for (unsigned b = blockIdx.x; b < n; b += gridDim.x) {
+        const unsigned p = mb.big[SRC][b];
+        const uint2 pr = mb.pairs[SRC][p];
+        const long long ci = (long long)mb.nt_list[pr.x];
+        const LmCcRec rec = cc[ci], urec = cc[mb.pair_u[SRC][p]];
+        const LmIsect is = lm_isect(rec, urec);
+        if (threadIdx.x == 0) s_sum = 0;
+        __syncthreads();
+        int m = lm_overlap_words(rec, urec, is, crop, (int)threadIdx.x, 256);
+        m = lm_wave_sum(m);
+        if (lm_lane() == 0 && m) atomicAdd(&s_sum, m);
+        __syncthreads();
+        if (threadIdx.x == 0 && lm_accept(s_sum, rec.size, urec.size, min_recall, min_precision)) {
+            mb.pairs[SRC][p].x = pr.x | 0x80000000u;
+            if (SRC == 0 && lm_mb_alive(rec.frame, active_last[pr.y], max_gap)) mb.sidx[ci] = -1;
+        }
+        __syncthreads();
+    }
+}
 
-__global__ void __launch_bounds__(256) lm_k_mb_twin_insert(const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
+// ------------------------------------------------------------------------------------------------
+// T: exact twins.  The hash of a CC's crop comes with its record (lm_k_emit / lm_k_crop_hash leave it in chash[]); candidates
+// are verified word by word with the work spread over the crop WORDS of the batch (a lecture's large components have crops of
+// 10^4..10^5 words: a few lanes per CC would leave the comparison to a handful of waves).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) lm_k_mb_twin_insert(const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ chash,
                                                            const long long* __restrict__ frame_cc_off, int f0, int B,
                                                            LmCounters* __restrict__ cnt, LmMatchBatch mb)
 {
     if (cnt->error) return;
     const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
     const long long n = C1 - C0;
-    if (blockIdx.x == 0 && threadIdx.x < LM_MB_MAX_FRAMES) mb.nt_cnt[threadIdx.x] = 0;      // counted by lm_k_mb_twin_find
+    if (blockIdx.x == 0 && threadIdx.x < LM_MB_MAX_FRAMES) mb.nt_cnt[threadIdx.x] = 0;      // counted by lm_k_mb_twin_final
     if (n * 2 > LM_MB_TTAB) return;
-    const int sub = (int)(threadIdx.x & 7);
-    const long long grp = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3, ngrp = ((long long)gridDim.x * 256) >> 3;
-    const long long rounds = (n + ngrp - 1) / ngrp;     // whole waves stay in the loop for the shuffles
-    for (long long it = 0; it < rounds; it++) {
-        const long long i = it * ngrp + grp;
-        const bool live = i < n;
-        unsigned h = 0;
-        LmCcRec r;
-        if (live) {
-            r = cc[C0 + i];
-            const int nw = (r.max_x >> 5) - (r.min_x >> 5) + 1, total = nw * (r.max_y - r.min_y + 1);
-            for (int k = sub; k < total; k += 8) h += lm_mix32(crop[r.crop_off + k] + 0x9e3779b9u * (unsigned)k);
-        }
-#pragma unroll
-        for (int d = 4; d >= 1; d >>= 1) h += (unsigned)__shfl_xor((int)h, d, 8);
-        if (live && sub == 0) {
-            const unsigned long long box = lm_pack_box(r);
-            unsigned key = lm_mix32(h ^ lm_mix32((unsigned)box) ^ lm_mix32((unsigned)(box >> 32) + 0x85ebca6bu) ^ lm_mix32((unsigned)r.size + 0xc2b2ae35u));
-            if (key == 0xffffffffu) key = 0;
-            mb.tkey[C0 + i] = key;
-            const unsigned long long val = ((unsigned long long)key << 32) | (unsigned long long)(unsigned)i;
-            for (unsigned probe = 0; probe < LM_MB_TTAB; probe++) {
-                const unsigned slot = (key + probe) & (LM_MB_TTAB - 1);
-                const unsigned long long old = atomicCAS(&mb.ttab[slot], ~0ull, val);
-                if (old == ~0ull) break;
-                if ((unsigned)(old >> 32) == key) { atomicMin(&mb.ttab[slot], val); break; }
-            }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const LmCcRec r = cc[C0 + i];
+        const unsigned h = chash[C0 + i];
+        const unsigned long long box = lm_pack_box(r);
+        unsigned key = lm_mix32(h ^ lm_mix32((unsigned)box) ^ lm_mix32((unsigned)(box >> 32) + 0x85ebca6bu) ^ lm_mix32((unsigned)r.size + 0xc2b2ae35u));
+        if (key == 0xffffffffu) key = 0;
+        mb.tkey[C0 + i] = key;
+        const unsigned long long val = ((unsigned long long)key << 32) | (unsigned long long)(unsigned)i;
+        for (unsigned probe = 0; probe < LM_MB_TTAB; probe++) {
+            const unsigned slot = (key + probe) & (LM_MB_TTAB - 1);
+            const unsigned long long old = atomicCAS(&mb.ttab[slot], ~0ull, val);
+            if (old == ~0ull) break;
+            if ((unsigned)(old >> 32) == key) { atomicMin(&mb.ttab[slot], val); break; }
         }
     }
 }
 
-__global__ void __launch_bounds__(256) lm_k_mb_twin_find(const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
-                                                         const long long* __restrict__ frame_cc_off, int f0, int B,
-                                                         LmCounters* __restrict__ cnt, LmMatchBatch mb, int max_gap)
+// candidate root of every CC: the smallest CC of the batch with the same key, if it has the same box and size and lies at most
+// max_gap frames earlier.  twin[] = 1 for the candidates; lm_k_mb_twin_cmp clears it where the crops differ.
+__global__ void __launch_bounds__(256) lm_k_mb_twin_probe(const LmCcRec* __restrict__ cc, const long long* __restrict__ frame_cc_off, int f0, int B,
+                                                          LmCounters* __restrict__ cnt, LmMatchBatch mb, int max_gap)
 {
     if (cnt->error) return;
     const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
     const long long n = C1 - C0;
     const bool enabled = n * 2 <= LM_MB_TTAB;
-    const int sub = (int)(threadIdx.x & 7);
-    const long long grp = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3, ngrp = ((long long)gridDim.x * 256) >> 3;
-    const long long rounds = (n + ngrp - 1) / ngrp;
-    for (long long it = 0; it < rounds; it++) {
-        const long long i = it * ngrp + grp;
-        const bool live = i < n;
-        int diff = 1;       // 0 after a complete, equal comparison
-        long long root_keep = -1;
-        if (live && enabled) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        long long root = -1;
+        if (enabled) {
             const unsigned key = mb.tkey[C0 + i];
-            long long root = -1;
             for (unsigned probe = 0; probe < LM_MB_TTAB; probe++) {
                 const unsigned long long e = mb.ttab[(key + probe) & (LM_MB_TTAB - 1)];
                 if (e == ~0ull) break;
                 if ((unsigned)(e >> 32) == key) { root = (long long)(unsigned)e; break; }
             }
-            root_keep = root;
             if (root >= 0 && root < i) {
                 const LmCcRec r = cc[C0 + i], q = cc[C0 + root];
-                if (r.size == q.size && r.min_x == q.min_x && r.max_x == q.max_x && r.min_y == q.min_y && r.max_y == q.max_y &&
-                    q.frame < r.frame && r.frame - q.frame <= max_gap) {
-                    const int nw = (r.max_x >> 5) - (r.min_x >> 5) + 1, total = nw * (r.max_y - r.min_y + 1);
-                    diff = 0;
-                    for (int k = sub; k < total; k += 8) diff |= (crop[r.crop_off + k] != crop[q.crop_off + k]) ? 1 : 0;
-                }
+                if (!(r.size == q.size && r.min_x == q.min_x && r.max_x == q.max_x && r.min_y == q.min_y && r.max_y == q.max_y &&
+                      q.frame < r.frame && r.frame - q.frame <= max_gap))
+                    root = -1;
+            } else {
+                root = -1;
             }
         }
-#pragma unroll
-        for (int d = 4; d >= 1; d >>= 1) diff |= __shfl_xor(diff, d, 8);
-        if (live && sub == 0) {
-            mb.twin[C0 + i] = diff ? 0 : 1;
-            mb.troot[C0 + i] = diff ? -1 : (int32_t)(C0 + root_keep);
-            if (diff) atomicAdd(&mb.nt_cnt[cc[C0 + i].frame - f0], 1);
+        mb.twin[C0 + i] = root >= 0 ? 1 : 0;
+        mb.troot[C0 + i] = root >= 0 ? (int32_t)(C0 + root) : -1;
+    }
+}
+
+// index (relative to C0) of the record whose crop holds word w; the records' crop offsets ascend with the record index.
+// `start` = a record at or before the one wanted.
+LM_DEV long long lm_cc_of_word(const LmCcRec* __restrict__ cc, long long C0, long long n, unsigned long long w, long long start)
+{
+    long long k = start;
+    while (k + 1 < n && cc[C0 + k + 1].crop_off <= w) k++;
+    return k;
+}
+
+LM_DEV long long lm_cc_of_word_search(const LmCcRec* __restrict__ cc, long long C0, long long n, unsigned long long w)
+{
+    long long lo = 0, hi = n;               // largest k with crop_off <= w
+    while (hi - lo > 1) {
+        const long long mid = (lo + hi) >> 1;
+        if (cc[C0 + mid].crop_off <= w) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// one lane per crop word of the batch: a candidate whose word differs from its root's is not a twin
+__global__ void __launch_bounds__(256) lm_k_mb_twin_cmp(const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
+                                                        const long long* __restrict__ frame_cc_off, int f0, int B,
+                                                        LmCounters* __restrict__ cnt, LmMatchBatch mb)
+{
+    if (cnt->error) return;
+    const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
+    const long long n = C1 - C0;
+    if (n <= 0 || n * 2 > LM_MB_TTAB) return;
+    const unsigned long long W0 = cc[C0].crop_off;
+    const unsigned long long W1 = (C1 < cnt->n_cc) ? cc[C1].crop_off : cnt->n_words;
+    const int lane = lm_lane();
+    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    for (unsigned long long w0 = W0 + wave * 64ull; w0 < W1; w0 += nwaves * 64ull) {
+        const long long k0 = lm_cc_of_word_search(cc, C0, n, w0);
+        const unsigned long long w = w0 + (unsigned long long)lane;
+        if (w >= W1) continue;
+        const long long k = lm_cc_of_word(cc, C0, n, w, k0);
+        const int32_t root = mb.troot[C0 + k];
+        if (root < 0) continue;
+        if (crop[w] != crop[cc[root].crop_off + (w - cc[C0 + k].crop_off)]) mb.twin[C0 + k] = 0;
+    }
+}
+
+__global__ void __launch_bounds__(256) lm_k_mb_twin_final(const LmCcRec* __restrict__ cc, const long long* __restrict__ frame_cc_off, int f0, int B,
+                                                          LmCounters* __restrict__ cnt, LmMatchBatch mb)
+{
+    if (cnt->error) return;
+    const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
+    for (long long i = C0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < C1; i += (long long)gridDim.x * blockDim.x) {
+        if (mb.twin[i]) continue;
+        mb.troot[i] = -1;
+        atomicAdd(&mb.nt_cnt[cc[i].frame - f0], 1);
+    }
+}
+
+// crop hashes of records that did not come through lm_k_emit (lm_stream_import / lm_stream_append_packed): chash[c0 .. c0 + n)
+// must be zero on entry
+__global__ void __launch_bounds__(256) lm_k_crop_hash(const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop, long long c0, long long n,
+                                                      unsigned long long W1, uint32_t* __restrict__ chash)
+{
+    if (n <= 0) return;
+    const unsigned long long W0 = cc[c0].crop_off;
+    const int lane = lm_lane();
+    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    for (unsigned long long w0 = W0 + wave * 64ull; w0 < W1; w0 += nwaves * 64ull) {
+        const long long k0 = lm_cc_of_word_search(cc, c0, n, w0);
+        const unsigned long long w = w0 + (unsigned long long)lane;
+        const bool live = w < W1;
+        long long k = k0;
+        unsigned contrib = 0;
+        if (live) {
+            k = lm_cc_of_word(cc, c0, n, w, k0);
+            contrib = lm_mix32(crop[w] + 0x9e3779b9u * (unsigned)(w - cc[c0 + k].crop_off));
         }
+        const bool same = live && k == k0;
+        const unsigned wsum = lm_wave_sum(same ? contrib : 0u);
+        if (lane == 0 && live) atomicAdd(&chash[c0 + k0], wsum);
+        if (live && !same) atomicAdd(&chash[c0 + k], contrib);
     }
 }
 

@@ -51,8 +51,14 @@ __global__ void __launch_bounds__(1024) lm_k_batch_offsets(const int32_t* __rest
     }
 }
 
+LM_DEV unsigned lm_mix32(unsigned h) { h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16; return h; }
+
 // ------------------------------------------------------------------------------------------------
-// E2: emit kept-CC records and their bit crops. One wave per kept CC; grid.y = frame in batch.
+// E2: emit kept-CC records and their bit crops; grid.y = frame in batch.
+// Work is distributed over the CROP WORDS of the frame, not over its CCs: after an hour of lecture most of the ink belongs to
+// a few large components (crops of 10^4..10^5 words) next to hundreds of glyph-sized ones, and a wave per CC left the GPU to
+// one wave.  A wave takes 64 consecutive words of the frame's crop space; lane 0's word is located in the ascending
+// kept_cropoff[] by binary search, the other lanes walk forward from there (a CC has at least a few words).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) lm_k_emit(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
                                                  const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
@@ -60,44 +66,60 @@ __global__ void __launch_bounds__(256) lm_k_emit(const uint64_t* __restrict__ bi
                                                  const int32_t* __restrict__ st_max_y, const int32_t* __restrict__ st_min_x,
                                                  const int32_t* __restrict__ st_max_x, const int32_t* __restrict__ st_count,
                                                  const int32_t* __restrict__ kept_label, const uint32_t* __restrict__ kept_cropoff,
-                                                 const int32_t* __restrict__ frame_kept, const long long* __restrict__ batch_cc_base,
+                                                 const int32_t* __restrict__ frame_kept, const uint32_t* __restrict__ frame_cropwords,
+                                                 const long long* __restrict__ batch_cc_base,
                                                  const unsigned long long* __restrict__ batch_word_base, LmCcRec* __restrict__ cc,
-                                                 uint32_t* __restrict__ crop, int first_frame, int WW, int H, int cap)
+                                                 uint32_t* __restrict__ crop, uint32_t* __restrict__ chash, int first_frame, int WW, int H, int cap)
 {
     const int b = blockIdx.y;
     const long long cc_base = batch_cc_base[b];
     if (cc_base < 0) return;    // capacity error raised by lm_k_batch_offsets
     const long long off = (long long)b * cap;
     const int nk = frame_kept[b];
-    const int lane = lm_lane();
-    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+    const unsigned nwords = frame_cropwords[b];
+    const unsigned long long wbase = batch_word_base[b];
     const int32_t* fin = final_label + off;
-    for (int k = wave; k < nk; k += nwaves) {
+    const uint32_t* coffs = kept_cropoff + off;
+    // ---- records: one thread per kept CC
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nk; k += gridDim.x * blockDim.x) {
         const int l0 = kept_label[off + k];
-        const int mnx = st_min_x[off + l0], mxx = st_max_x[off + l0], mny = st_min_y[off + l0], mxy = st_max_y[off + l0];
-        const unsigned long long coff = batch_word_base[b] + kept_cropoff[off + k];
-        if (lane == 0) {
-            LmCcRec r;
-            r.cc_id = l0;
-            r.size = st_count[off + l0];
-            r.min_x = (int16_t)mnx; r.max_x = (int16_t)mxx; r.min_y = (int16_t)mny; r.max_y = (int16_t)mxy;
-            r.crop_off = coff;
-            r.frame = first_frame + b;
-            r.pad = 0;
-            cc[cc_base + k] = r;
+        LmCcRec r;
+        r.cc_id = l0;
+        r.size = st_count[off + l0];
+        r.min_x = (int16_t)st_min_x[off + l0]; r.max_x = (int16_t)st_max_x[off + l0];
+        r.min_y = (int16_t)st_min_y[off + l0]; r.max_y = (int16_t)st_max_y[off + l0];
+        r.crop_off = wbase + coffs[k];
+        r.frame = first_frame + b;
+        r.pad = 0;
+        cc[cc_base + k] = r;
+    }
+    // ---- crops: one lane per crop word
+    const int lane = lm_lane();
+    const unsigned wave = (unsigned)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (unsigned)((gridDim.x * blockDim.x) >> 6);
+    for (unsigned w0 = wave * 64u; w0 < nwords; w0 += nwaves * 64u) {
+        int lo = 0, hi = nk;                // largest k with coffs[k] <= w0 (coffs[0] == 0)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (coffs[mid] <= w0) lo = mid; else hi = mid;
         }
-        const int wx0 = mnx >> 5;
-        const int nw = (mxx >> 5) - wx0 + 1;
-        const int total = nw * (mxy - mny + 1);
-        for (int idx = lane; idx < total; idx += 64) {
-            int r = idx / nw, j = idx - r * nw;
-            int wx = wx0 + j;
-            long long row = (long long)b * H + mny + r;
-            long long rw = row * WW + (wx >> 1);
-            int half = wx & 1;
+        const unsigned w = w0 + (unsigned)lane;
+        const bool live = w < nwords;
+        unsigned contrib = 0;
+        int k = lo;
+        if (live) {
+            while (k + 1 < nk && coffs[k + 1] <= w) k++;
+            const int l0 = kept_label[off + k];
+            const int mnx = st_min_x[off + l0], mxx = st_max_x[off + l0], mny = st_min_y[off + l0];
+            const int wx0 = mnx >> 5;
+            const int nw = (mxx >> 5) - wx0 + 1;
+            const int idx = (int)(w - coffs[k]);
+            const int r = idx / nw, j = idx - r * nw;
+            const int wx = wx0 + j;
+            const long long row = (long long)b * H + mny + r;
+            const long long rw = row * WW + (wx >> 1);
+            const int half = wx & 1;
             unsigned b32 = (unsigned)(bits[rw] >> (32 * half));
-            int x_lo = wx * 32;
+            const int x_lo = wx * 32;
             // clip to the box in x
             unsigned m = 0xffffffffu;
             if (mnx > x_lo) m &= 0xffffffffu << (mnx - x_lo);
@@ -109,18 +131,25 @@ __global__ void __launch_bounds__(256) lm_k_emit(const uint64_t* __restrict__ bi
                 const int idbase = (int)rowoff[row] + (int)prefix[rw] - 1;
                 unsigned rem = b32;
                 while (rem) {
-                    int lo = __ffs((int)rem) - 1;
-                    unsigned t = ~(rem >> lo);
+                    const int lo2 = __ffs((int)rem) - 1;
+                    const unsigned t = ~(rem >> lo2);
                     int len = t ? (__ffs((int)t) - 1) : 32;
-                    if (len > 32 - lo) len = 32 - lo;
-                    unsigned piece = ((len >= 32) ? 0xffffffffu : ((1u << len) - 1u)) << lo;
-                    int id = idbase + __popcll(s & lm_lowmask_incl(half * 32 + lo));
+                    if (len > 32 - lo2) len = 32 - lo2;
+                    const unsigned piece = ((len >= 32) ? 0xffffffffu : ((1u << len) - 1u)) << lo2;
+                    const int id = idbase + __popcll(s & lm_lowmask_incl(half * 32 + lo2));
                     if (fin[id] == l0 + 1) out |= piece;
                     rem &= ~piece;
                 }
             }
-            crop[coff + idx] = out;
+            crop[wbase + w] = out;
+            contrib = lm_mix32(out + 0x9e3779b9u * (unsigned)idx);
         }
+        // crop hash for the twin detection: the lanes that share lane 0's CC (nearly all of a large component's waves) add up
+        // in the wave, the others add on their own
+        const bool same = live && k == lo;
+        const unsigned wsum = lm_wave_sum(same ? contrib : 0u);
+        if (lane == 0 && live) atomicAdd(&chash[cc_base + lo], wsum);
+        if (live && !same) atomicAdd(&chash[cc_base + k], contrib);
     }
 }
 

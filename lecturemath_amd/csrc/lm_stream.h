@@ -41,6 +41,7 @@ struct LmStream {
     int32_t* assign;
     long long* frame_cc_off;    // [cap_frames + 1]
     uint32_t* crop;
+    uint32_t* chash;            // [cap_cc] sum over the crop words of mix32(word + 0x9e3779b9 * index), left by lm_k_emit (twin detection key)
     // active list, parallel arrays in ascending unique index
     int32_t* active;            // unique index
     int32_t* active_cc;         // global cc index of the unique's first-seen CC

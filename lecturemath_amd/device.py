@@ -28,7 +28,11 @@ class Backend:
     def empty(self, shape, dtype):
         if self.device:
             return self.torch.empty(shape, dtype=getattr(self.torch, self._T[dtype]), device="cuda")
-        return np.empty(shape, dtype=dtype)
+        # emulated build: 64-byte aligned like device allocations (packed record blocks hold 32-byte aligned structs)
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        raw = np.empty(nbytes + 64, np.uint8)
+        off = (-raw.ctypes.data) % 64
+        return raw[off:off + nbytes].view(dtype).reshape(shape)
 
     def from_host(self, a):
         a = np.ascontiguousarray(a)
@@ -198,6 +202,18 @@ class FrameStream:
     def match(self, n_frames):
         """Sequential temporal matching over the next n_frames unmatched frames."""
         self.lib.check(self.lib.lm_stream_match(self.handle, int(n_frames), self.be.stream()))
+
+    def pack(self, first_frame, n_frames):
+        """Records + crops of frames [first_frame, first_frame + n_frames) as one flat device uint8 buffer (lm_stream_pack)."""
+        nb = ctypes.c_int64(0)
+        self.lib.check(self.lib.lm_stream_pack_size(self.handle, int(first_frame), int(n_frames), ctypes.addressof(nb), self.be.stream()))
+        buf = self.be.empty((max(int(nb.value), 32),), np.uint8)
+        self.lib.check(self.lib.lm_stream_pack(self.handle, int(first_frame), int(n_frames), _lib.ptr(buf), int(nb.value), self.be.stream()))
+        return buf
+
+    def append_packed(self, buf):
+        """Append a packed block (device uint8 buffer from pack(), possibly received from another rank) behind the last frame."""
+        self.lib.check(self.lib.lm_stream_append_packed(self.handle, _lib.ptr(buf), int(buf.shape[0]), self.be.stream()))
 
     def counters(self):
         k = np.zeros(7, np.int64)

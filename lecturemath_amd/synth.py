@@ -68,6 +68,28 @@ def whiteboard_rgb(h=1080, w=1920, n_glyphs=1500, seed=20211):
     return img.astype(np.uint8), mask
 
 
+def whiteboard_stream(n_frames, h=1080, w=1920, glyphs_start=400, glyphs_per_frame=12, seed=20212):
+    """Yield n_frames RGB uint8 frames of ONE evolving whiteboard (fixed background noise / illumination ramp, ink strokes
+    accumulating over time) for the RGB -> FCN -> ... end-to-end measurements: consecutive frames share most of their
+    content, like sampled lecture video."""
+    rng = np.random.default_rng(seed)
+    ramp = np.linspace(-10.0, 10.0, w, dtype=np.float32)[None, :, None]
+    board = np.clip(235.0 + rng.normal(0.0, 3.0, (h, w, 3)).astype(np.float32) + ramp, 0, 255).astype(np.uint8)
+    total = glyphs_start + glyphs_per_frame * n_frames
+    glyphs = _random_glyphs(rng, total, h, w)
+    ink = rng.integers(20, 81, total)
+    mask = np.zeros((h, w), np.uint8)
+    done = 0
+    for t in range(n_frames):
+        upto = glyphs_start + glyphs_per_frame * (t + 1)
+        for g, v in zip(glyphs[done:upto], ink[done:upto]):
+            _draw_glyph(mask, *[int(x) for x in g], value=int(v))
+        done = upto
+        frame = board.copy()
+        frame[mask > 0] = mask[mask > 0][:, None]
+        yield frame
+
+
 def binary_stream(n_frames, h=1080, w=1920, seed=20213, glyphs_per_add=40, add_every=2, erase_every=250,
                   jitter_p=0.02, jitter_frac=0.05, transient=True, occluder=False, max_ext=28):
     """Yield n_frames uint8 {0,255} frames (255 = ink), a persistent board evolving in time."""

@@ -56,7 +56,7 @@ struct Fiber;
 extern Fiber* g_cur;
 struct ThreadCtx { dim3 tid, bid, bdim, gdim; };
 extern ThreadCtx g_ctx;
-void launch(const std::function<void()>& body, dim3 grid, dim3 block);
+void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t shmem);
 void syncthreads();
 // wave rendezvous: every live lane of the calling lane's wave deposits `v`; returns the 64 deposited
 // values (dead lanes: 0) and the mask of participating lanes.
@@ -71,7 +71,7 @@ int lane_id();
 #define warpSize 64
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    hipemu::launch([&]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block))
+    hipemu::launch([&]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block), (size_t)(shmem))
 
 static inline void __syncthreads() { hipemu::syncthreads(); }
 static inline void __threadfence() {}

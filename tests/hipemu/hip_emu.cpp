@@ -5,7 +5,22 @@
 
 #include <vector>
 
-alignas(16) char lm_emu_dynsmem[160 * 1024];
+// Dynamic LDS of the running launch: allocated per launch at EXACTLY the size the launch asked for (so that an index past
+// the kernel's allocation is a heap overflow AddressSanitizer reports) and filled with 0xFF before every block (fp32 / f16
+// NaN patterns, -1 as an integer: a kernel that consumes LDS it never wrote, e.g. stale data of the previous workgroup,
+// poisons its result instead of passing by accident).
+char* lm_emu_dynsmem = nullptr;
+static size_t g_dynsmem_bytes = 0;
+
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HIPEMU_ASAN 1
+#include <sanitizer/common_interface_defs.h>
+#endif
+#endif
+#ifndef HIPEMU_ASAN
+#define HIPEMU_ASAN 0
+#endif
 
 namespace hipemu {
 
@@ -27,6 +42,7 @@ struct Wave {
     unsigned long long gen = 0;   // completed collectives
 };
 
+static const size_t kStack = 256 * 1024;
 Fiber* g_cur = nullptr;
 ThreadCtx g_ctx;
 
@@ -37,8 +53,34 @@ static const std::function<void()>* g_body = nullptr;
 static int g_block_arrived = 0;
 static unsigned long long g_block_gen = 0;
 static int g_live = 0;
-static const size_t kStack = 256 * 1024;
 
+#if HIPEMU_ASAN
+// AddressSanitizer must be told about every stack switch (ucontext fibers), or it reports false stack overflows
+static const void* g_sched_stack = nullptr;
+static size_t g_sched_stack_size = 0;
+static void to_sched(bool dying)
+{
+    void* fake = nullptr;
+    __sanitizer_start_switch_fiber(dying ? nullptr : &fake, g_sched_stack, g_sched_stack_size);
+    swapcontext(&g_cur->ctx, &g_sched);
+    __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+}
+static void to_fiber(Fiber& f)
+{
+    void* fake = nullptr;
+    __sanitizer_start_switch_fiber(&fake, f.stack, kStack);
+    swapcontext(&g_sched, &f.ctx);
+    __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+}
+static void fiber_main()
+{
+    __sanitizer_finish_switch_fiber(nullptr, &g_sched_stack, &g_sched_stack_size);
+    (*g_body)();
+    g_cur->state = DONE;
+    to_sched(true);
+}
+static void yield_to_sched() { to_sched(false); }
+#else
 static void fiber_main()
 {
     (*g_body)();
@@ -47,6 +89,8 @@ static void fiber_main()
 }
 
 static void yield_to_sched() { swapcontext(&g_cur->ctx, &g_sched); }
+static void to_fiber(Fiber& f) { swapcontext(&g_sched, &f.ctx); }
+#endif
 
 int lane_id() { return g_cur->linear & 63; }
 
@@ -90,10 +134,16 @@ const unsigned long long* wave_gather(unsigned long long v, unsigned long long* 
     return wv.vals[slot];
 }
 
-void launch(const std::function<void()>& body, dim3 grid, dim3 block)
+void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t shmem)
 {
     int nthreads = (int)(block.x * block.y * block.z);
     if (nthreads <= 0 || grid.x * grid.y * grid.z == 0) return;
+    if (shmem > 160 * 1024) { fprintf(stderr, "hipemu: launch asks for %zu bytes of dynamic LDS (> 160 KB)\n", shmem); abort(); }
+    char* const outer_smem = lm_emu_dynsmem;          // launches do not nest, but keep the state tidy
+    const size_t outer_bytes = g_dynsmem_bytes;
+    lm_emu_dynsmem = nullptr;
+    if (shmem && posix_memalign((void**)&lm_emu_dynsmem, 64, shmem) != 0) abort();
+    g_dynsmem_bytes = shmem;
     g_body = &body;
     if ((int)g_fibers.size() < nthreads) {
         size_t old = g_fibers.size();
@@ -106,6 +156,7 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block)
     for (unsigned by = 0; by < grid.y; by++)
     for (unsigned bx = 0; bx < grid.x; bx++) {
         for (auto& w : g_waves) { w.arrived = 0; w.gen = 0; }
+        if (shmem) memset(lm_emu_dynsmem, 0xff, shmem);
         g_block_arrived = 0;
         g_block_gen = 0;
         g_live = nthreads;
@@ -147,7 +198,7 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block)
                 g_ctx.bid = dim3(bx, by, bz);
                 g_ctx.bdim = block;
                 g_ctx.gdim = grid;
-                swapcontext(&g_sched, &f.ctx);
+                to_fiber(f);
                 progressed = true;
                 if (f.state == DONE) g_live--;
             }
@@ -163,6 +214,9 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block)
     }
     g_ctx = saved;
     g_cur = nullptr;
+    free(lm_emu_dynsmem);
+    lm_emu_dynsmem = outer_smem;
+    g_dynsmem_bytes = outer_bytes;
 }
 
 }  // namespace hipemu

@@ -102,6 +102,40 @@ def check_stream_oracle(lib, frames, max_gap, max_batch=5, thresholds=(0.85, 0.8
     return r
 
 
+def blob_stream(n_frames=14, h=160, w=800, seed=17):
+    """What an hour of lecture looks like to step 02: one large component (a mesh of strokes over most of the frame, its crop
+    several thousand words) that grows a little every other frame -- so consecutive versions are twins half of the time and
+    near-identical large non-twins otherwise -- among glyph-sized CCs lying inside its box, some of them blinking.  Exercises
+    the word-parallel paths: lm_k_emit's crop words, lm_k_mb_twin_cmp, the size prune and lm_k_mb_eval_big."""
+    rng = np.random.default_rng(seed)
+    mesh = np.zeros((h, w), np.uint8)
+    mesh[10:h - 10:12, 8:w - 8] = 255              # long horizontal strokes ...
+    mesh[10:h - 10, 8:w - 8:40] = 255              # ... tied together by vertical ones: ONE component
+    dots = [(int(rng.integers(14, h - 18)), int(rng.integers(12, w - 20))) for _ in range(60)]
+    frames = []
+    for t in range(n_frames):
+        img = mesh.copy()
+        grow = 3 * (t // 2)                         # a spur that gets longer every other frame
+        img[h // 2 + 3:h // 2 + 3 + 2, 20:20 + 4 + grow] = 255
+        img[h // 2 + 1:h // 2 + 5, 20:22] = 255     # attached to a horizontal stroke
+        for i, (y, x) in enumerate(dots):
+            if (i + t) % 7 == 0:
+                continue
+            y0 = y - (y - 10) % 12 + 3              # between two strokes: a separate glyph-sized CC
+            img[y0:y0 + 6, x - (x - 8) % 40 + 4:x - (x - 8) % 40 + 10] = 255
+        frames.append(img)
+    return frames
+
+
+def check_stream_large_components(lib, **kw):
+    frames = blob_stream(**kw)
+    r = check_stream_oracle(lib, frames, max_gap=4, max_batch=5, max_ccs=1 << 14, max_crop_words=1 << 20)
+    big = max(int(rec[4]) for rec in r["unique_recs"])
+    assert big > 5000, big                          # the mesh: thousands of pixels, crop of thousands of words
+    check_stream_oracle(lib, frames, max_gap=4, max_batch=5, records_then_match=True, max_ccs=1 << 14, max_crop_words=1 << 20)
+    return r
+
+
 def check_stream_threshold_edges(lib):
     """Thresholds the twin shortcut must respect: exactly 1.0 (only identical crops match: everything rides on twins) and
     above 1.0 (nothing ever matches, twin detection is off: every CC of every frame is a new unique)."""

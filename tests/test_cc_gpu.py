@@ -44,6 +44,12 @@ def test_stream_frames_with_thousands_of_ccs(hip_lib, oracle_built):
     assert len(r["cc_idx_per_frame"][0]) > 3000
 
 
+def test_stream_large_components(hip_lib, oracle_built):
+    """Large components (crops of 10^3..10^4 words) among glyph-sized ones, as in the later part of a lecture: lm_k_emit by crop
+    words, lm_k_mb_twin_cmp, the size prune of lm_k_mb_eval and lm_k_mb_eval_big vs the oracle, both matching paths."""
+    lm_checks.check_stream_large_components(hip_lib, n_frames=40, h=400, w=1600)
+
+
 def test_stream_churn_and_empty_frames(hip_lib, oracle_built):
     """A stream where nearly every CC is a new unique (>16k in-batch sources and >16k active positions in ONE 40-frame
     matching batch: the replay kernel's global-memory fallbacks) and every seventh frame is empty; both matching paths."""

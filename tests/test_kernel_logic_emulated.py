@@ -89,6 +89,12 @@ def test_grouping_crowded_tiles_vs_oracle(emu_lib, oracle_built):
     assert len(r["cc_groups"]) > 200
 
 
+def test_stream_large_components(emu_lib, oracle_built):
+    """A component whose crop has thousands of words next to glyph-sized ones: crop emission, twin comparison and pair
+    evaluation distribute their work over crop words, not CCs."""
+    lm_checks.check_stream_large_components(emu_lib, n_frames=8)
+
+
 def test_stream_threshold_edges(emu_lib, oracle_built):
     lm_checks.check_stream_threshold_edges(emu_lib)
 

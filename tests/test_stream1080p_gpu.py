@@ -1,0 +1,103 @@
+"""BASELINE.json configs[2] at its stated size: ONE synthetic 1080p stream (synth.binary_stream, seed 20213) of 1,000 and of
+10,000 frames through threshold -> labelling -> records -> matching (state carried over the whole stream) -> step 03 ->
+reconstruction, through the C ABI on the GPU.
+
+  * first 1,000 frames: step-02 state bit for bit against the oracle (records, crops of the uniques, unique_cc_frames,
+    cc_idx_per_frame, tempo_count, active list), and every step 02/03 digest -- including the sha256 chain over all 1,000
+    reconstructed frames -- against the digests THE REFERENCE produced on the same stream in the build container
+    (tests/golden/g9_stream1080p_digests.json, tests/golden/make_golden_stream1080p.py);
+  * all 10,000 frames: the same digests (reconstructed frames through their per-frame byte sums) against the reference's
+    ("first 1,000 frames + checksums").
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import lm_checks
+from lecturemath_amd import device, digests, synth
+
+pytestmark = pytest.mark.gpu
+
+H, W, SEED = 1080, 1920, 20213
+GOLD = json.load(open(os.path.join(lm_checks.GOLD, "g9_stream1080p_digests.json")))
+DIGEST_KEYS = ("unique_cc_frames", "cc_idx_per_frame", "cc_groups", "group_ages", "groups_per_frame", "group_boundaries")
+
+
+def run_stream(lib, n_frames, batch=64):
+    """The stream through the device path exactly as bench.py drives it: logits -> threshold+invert per batch -> push."""
+    import torch
+    fs = device.FrameStream(W, H, n_frames, 0.85, 0.85, 85, 20, max_batch=batch, max_ccs=n_frames * 4096, max_crop_words=n_frames * (1 << 17), lib=lib)
+    labels = torch.empty((batch, H, W), dtype=torch.int32, device="cuda")
+    buf = []
+
+    def flush():
+        if buf:
+            mask = torch.from_numpy(np.stack(buf)).cuda()
+            logits = torch.where(mask > 0, -4.0, 4.0) + (torch.rand(mask.shape, device="cuda") - 0.5)     # ink <=> negative logit
+            binary = fs.labeler.threshold_invert(logits)
+            assert bool((binary == mask).all())
+            fs.push(binary, labels[:len(buf)])
+            buf.clear()
+
+    for f in synth.binary_stream(n_frames, H, W, seed=SEED):
+        buf.append(f)
+        if len(buf) == batch:
+            flush()
+    flush()
+    return fs
+
+
+def device_digests(fs, gr, n_frames, with_frames, batch=64):
+    d = digests.from_device(fs, gr)
+    chain, sums = digests.FrameChain(), []
+    for f0 in range(0, n_frames, batch):
+        n = min(batch, n_frames - f0)
+        clean = gr.render(f0, n)
+        sums.append(device.frame_sums(clean, fs.lib))
+        if with_frames:
+            chain.update(clean.cpu().numpy())
+    d["clean_frame_sums"] = digests.sums_digest(np.concatenate(sums))
+    if with_frames:
+        d["clean_binary"] = chain.hexdigest()
+    return d
+
+
+def check_against_reference(fs, n_frames, with_frames):
+    ref = GOLD[str(n_frames)]
+    k = fs.counters()
+    assert (k["n_cc"], k["n_unique"], k["tempo_count"]) == (ref["n_cc"], ref["n_unique_step02"], ref["tempo_count"])
+    gr = device.Grouping(fs, max_gap=85, min_times=3, t_window=5, min_recall=0.5, img_threshold=0.5, reconstruct=True)
+    try:
+        sc = gr.array("scalars")
+        assert (int(sc[0]), int(sc[1]), int(sc[2]), int(sc[3])) == (ref["n_split"], ref["total_intersections"], ref["n_groups"], ref["n_unique"])
+        assert len(gr.array("stable")) == ref["n_stable"]
+        d = device_digests(fs, gr, n_frames, with_frames)
+        for key in DIGEST_KEYS + ("clean_frame_sums",) + (("clean_binary",) if with_frames else ()):
+            assert d[key] == ref[key], key
+    finally:
+        gr.close()
+
+
+def test_first_1000_frames_vs_oracle_and_reference(hip_lib, oracle_built):
+    n = 1000
+    fs = run_stream(hip_lib, n)
+    try:
+        st = oracle_built.Stability(W, H, 0.85, 0.85, 85)
+        for f in synth.binary_stream(n, H, W, seed=SEED):
+            st.add_frame(f)
+        lm_checks.state_equal_oracle(fs.result(), st.result())
+        check_against_reference(fs, n, with_frames=True)
+    finally:
+        fs.close()
+
+
+@pytest.mark.skipif("10000" not in GOLD, reason="reference digests of the 10,000-frame stream not generated yet")
+def test_full_10000_frames_vs_reference_digests(hip_lib):
+    n = 10000
+    fs = run_stream(hip_lib, n)
+    try:
+        check_against_reference(fs, n, with_frames=False)
+    finally:
+        fs.close()
