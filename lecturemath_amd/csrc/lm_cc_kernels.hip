@@ -648,13 +648,15 @@ __global__ void __launch_bounds__(256) lm_k_stats(const uint64_t* __restrict__ b
                     slot = (slot + 1) & (LM_ST_SLOTS - 1);
                 }
                 if (placed) {
+                    // a large component owns most pieces of a tile: the box only moves for the few pieces on its rim, so look
+                    // before the atomic (a stale value only costs an atomic that changes nothing)
                     atomicAdd(&s_cnt[slot], len);
                     if (is_start) {
-                        atomicMin(&s_mnx[slot], w * 64 + lo);
-                        atomicMin(&s_mny[slot], y);
-                        atomicMax(&s_mxy[slot], y);
+                        if (w * 64 + lo < s_mnx[slot]) atomicMin(&s_mnx[slot], w * 64 + lo);
+                        if (y < s_mny[slot]) atomicMin(&s_mny[slot], y);
+                        if (y > s_mxy[slot]) atomicMax(&s_mxy[slot], y);
                     }
-                    if (ends) atomicMax(&s_mxx[slot], w * 64 + hi);
+                    if (ends && w * 64 + hi > s_mxx[slot]) atomicMax(&s_mxx[slot], w * 64 + hi);
                 } else {      // table full (very dense tile): straight to L2
                     const long long cc = foff + lab - 1;
                     atomicAdd(&st_count[cc], len);
@@ -675,10 +677,12 @@ __global__ void __launch_bounds__(256) lm_k_stats(const uint64_t* __restrict__ b
         if (!lab) continue;
         const long long cc = foff + lab - 1;
         atomicAdd(&st_count[cc], s_cnt[i]);
-        if (s_mnx[i] != 0x7fffffff) atomicMin(&st_min_x[cc], s_mnx[i]);
-        if (s_mny[i] != 0x7fffffff) atomicMin(&st_min_y[cc], s_mny[i]);
-        if (s_mxy[i] >= 0) atomicMax(&st_max_y[cc], s_mxy[i]);
-        if (s_mxx[i] >= 0) atomicMax(&st_max_x[cc], s_mxx[i]);
+        // same here: hundreds of tiles report the same large label, nearly all of them from inside its box (the plain loads
+        // may be stale -- values only move one way, so that only costs an atomic that changes nothing)
+        if (s_mnx[i] != 0x7fffffff && s_mnx[i] < st_min_x[cc]) atomicMin(&st_min_x[cc], s_mnx[i]);
+        if (s_mny[i] != 0x7fffffff && s_mny[i] < st_min_y[cc]) atomicMin(&st_min_y[cc], s_mny[i]);
+        if (s_mxy[i] >= 0 && s_mxy[i] > st_max_y[cc]) atomicMax(&st_max_y[cc], s_mxy[i]);
+        if (s_mxx[i] >= 0 && s_mxx[i] > st_max_x[cc]) atomicMax(&st_max_x[cc], s_mxx[i]);
     }
 }
 

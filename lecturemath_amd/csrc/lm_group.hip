@@ -183,19 +183,24 @@ __global__ void __launch_bounds__(256) lm_k_gimg_write(const LmGimgItem* __restr
         const LmGimgItem it = items[un.item];
         lm_gimg_accumulate(it, un, members, cc, crop, s_mask);
         const double mx = (double)item_max[un.item];
+        // (double)v / mx >= thr is monotone in v: one exact integer bound per tile instead of a float64 division per pixel
+        int vmin = (int)(thr * mx);
+        if (vmin < 0) vmin = 0;
+        while (vmin > 0 && (double)(vmin - 1) / mx >= thr) vmin--;
+        while ((double)vmin / mx < thr) vmin++;
         const int tw = (it.w - un.tx * LM_GT < LM_GT) ? it.w - un.tx * LM_GT : LM_GT;
         const int th = (it.h - un.ty * LM_GT < LM_GT) ? it.h - un.ty * LM_GT : LM_GT;
         // a 64-px tile row is two whole words of the item's row
         const int bw = (it.w + 31) >> 5;
-        for (int i = threadIdx.x; i < th * 2; i += blockDim.x) {
-            const int yy = i >> 1, hf = i & 1;
-            if (un.tx * 2 + hf >= bw) continue;
-            unsigned word = 0;
-            for (int b = 0; b < 32; b++) {
-                const int xx = hf * 32 + b;
-                if (xx < tw && (double)s_mask[yy * LM_GT + xx] / mx >= thr) word |= 1u << b;
+        // a lane per pixel of a tile row (conflict-free LDS reads), the ballot is the row's two words
+        {
+            const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6), lane = lm_lane();
+            for (int yy = wave; yy < LM_GT; yy += nwaves) {         // every wave runs all its trips: ballots need whole waves
+                const bool on = yy < th && lane < tw && s_mask[yy * LM_GT + lane] >= vmin;
+                const unsigned long long m = __ballot(on);
+                if (yy < th && lane < 2 && un.tx * 2 + lane < bw)
+                    bits[it.bits_off + (long long)(un.ty * LM_GT + yy) * bw + un.tx * 2 + lane] = (unsigned)(m >> (32 * lane));
             }
-            bits[it.bits_off + (long long)(un.ty * LM_GT + yy) * bw + un.tx * 2 + hf] = word;
         }
         __syncthreads();
     }
@@ -716,7 +721,11 @@ template <int MODE>
 __global__ void __launch_bounds__(256) lm_k_gimg_members(const LmGimgTab T, unsigned* __restrict__ tile_cnt, const unsigned* __restrict__ tile_moff,
                                                          LmGimgMember* __restrict__ members, const LmCcRec* __restrict__ cc)
 {
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < T.n_slots; s += gridDim.x * blockDim.x) {
+    // one wave per (group, member) slot, its lanes take the segments: a member that stays for thousands of frames spans
+    // hundreds of segments
+    const int lane = lm_lane();
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+    for (int s = wave; s < T.n_slots; s += nwaves) {
         const int g = T.slot_group[s], u = T.slot_unique[s];
         const int32_t* ag = T.ages + T.ages_off[g];
         const int na = (int)(T.ages_off[g + 1] - T.ages_off[g]), ns = na - 1;
@@ -738,7 +747,7 @@ __global__ void __launch_bounds__(256) lm_k_gimg_members(const LmGimgTab T, unsi
         const int ntx = (gw + LM_GT - 1) / LM_GT;
         const int tx0 = (r.min_x - gx0) / LM_GT, tx1 = (r.max_x - gx0) / LM_GT, ty0 = (r.min_y - gy0) / LM_GT, ty1 = (r.max_y - gy0) / LM_GT;
         const long long item0 = T.gitem_first[g];
-        for (int j = j_lo; j <= j_hi; j++) {
+        for (int j = j_lo + lane; j <= j_hi; j += 64) {
             int a = 0, b = n;                       // first entry >= ag[j]
             while (a < b) { const int mid = (a + b) >> 1; if (fe[mid] < ag[j]) a = mid + 1; else b = mid; }
             const int e_lo = a;
@@ -1384,7 +1393,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         LM_HIP(hipMemsetAsync(d_nunits, 0, 256, st));
         LM_HIP(hipMemsetAsync(d_max, 0, (size_t)n_items * sizeof(int32_t), st));
         LM_HIP(hipMemsetAsync(g->d_gbits, 0, (size_t)std::max<long long>(bit_words, 1) * sizeof(uint32_t), st));
-        const unsigned sb = lm_gblocks(T.n_slots, 256, 4096);
+        const unsigned sb = lm_gblocks(T.n_slots, 4, 16384);      // a wave per slot
         hipLaunchKernelGGL((lm_k_gimg_members<0>), dim3(sb), dim3(256), 0, st, T, d_tile_cnt, (const unsigned*)nullptr, (LmGimgMember*)nullptr, s->cc);
         hipLaunchKernelGGL(lm_k_scan_chunks, dim3((unsigned)std::max(n_chunks, 1)), dim3(1024), 0, st, d_tile_cnt, d_tile_moff, n_tiles, d_chunk);
         hipLaunchKernelGGL(lm_k_scan_u32, dim3(1), dim3(1024), 0, st, d_chunk, d_chunk, n_chunks, d_tot + 5);
