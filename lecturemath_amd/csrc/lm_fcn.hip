@@ -18,10 +18,20 @@
 // Per chunk a block stages in LDS the (16+KH-1) x (16+KW-1) x CK input patch (pixel stride CK+4 floats: the
 // 16 B A-fragment reads of 16 neighbouring pixels then fall on distinct banks) and the chunk's weights for ALL
 // taps, pre-packed on the host in fragment order [tap][kstep][nblock][lane][4].
-#include <mutex>
 #include "lm_common.h"
 
 #include <vector>
+
+// Kernels marked LM_NO_PACKED_F32 are compiled without the packed fp32 VALU instructions (v_pk_fma_f32 ...).  The one-channel
+// head kernels below, vectorised by the compiler into v_pk_fma_f32 chains fed straight from ds_read_b128 results, returned
+// sporadic wrong values in lanes 48-63 (the low register of the packed pair) whenever workgroups of ANOTHER kernel shared
+// their CUs -- two forward passes in flight -- and never alone; the same source built with scalar v_fmac_f32 is bit-stable
+// under the same overlap (tools/fcn_overlap_repro.py).
+#if LM_HIP_EMULATED || defined(LM_FCN_HEAD_VARIANT)
+#define LM_NO_PACKED_F32
+#else
+#define LM_NO_PACKED_F32 __attribute__((target("no-packed-fp32-ops")))
+#endif
 
 #define LM_ACT_NONE 0
 #define LM_ACT_GELU 1
@@ -46,6 +56,7 @@ struct LmConvArgs {
     int act;
     int tmode, dy, dx, OH, OW;          // transposed mode: input (y, x) -> output (2y+dy, 2x+dx) of an OH x OW grid
     int tg;                             // f16x3 kernel: taps whose weights are staged together (divides K*K)
+    int terms;                          // fp16-split kernels: products per operand pair (3, 2 or 1; see lm_k_conv_mfma_h)
 };
 
 template <int CK, int NT>
@@ -266,7 +277,9 @@ constexpr int lm_cv_tg(int K, int NT)
 }
 
 // KS: kernel side known at compile time (1, 3, 7), or 0 = taken from the arguments (worst-case prefetch arrays)
-template <int NT, int KS, int TG = 0>     // TG: taps per weight group, 0 = lm_cv_tg(KS, NT)
+// TERMS: products per pair of operands.  3 = hi.hi + hi.lo + lo.hi (the "f16x3" format above, ~22 bits per operand);
+// 2 = hi.hi + lo.hi (activations split, weights rounded to f16); 1 = hi.hi (both operands rounded to f16).
+template <int NT, int KS, int TG = 0, int TERMS = 3>     // TG: taps per weight group, 0 = lm_cv_tg(KS, NT)
 __global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1) lm_k_conv_mfma_h(const LmConvArgs a)      // two waves per SIMD whenever the accumulators allow
 {
     LM_DYN_SMEM(smem);
@@ -327,13 +340,13 @@ __global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1) lm_k_conv_mfma_h(const
                 for (int m = 0; m < 2; m++) {
                     const char* pp = s_patch + (prow + m * 2 + kh) * RB + (pcol + kw) * PB + half * 16;
                     ah[m] = *(const lm_h8*)pp;
-                    al[m] = *(const lm_h8*)(pp + 32);
+                    if (TERMS >= 2) al[m] = *(const lm_h8*)(pp + 32);
                 }
 #pragma unroll
                 for (int n = 0; n < NT; n++) {
                     const char* wp = s_w + ((long long)(tt * NT + n) * 128 + lane) * 16;
                     bh[n] = *(const lm_h8*)wp;
-                    bl[n] = *(const lm_h8*)(wp + 64 * 16);
+                    if (TERMS >= 3) bl[n] = *(const lm_h8*)(wp + 64 * 16);
                 }
                 // the three products of one accumulator are a dependent chain: issue them term by term across the 2 * NT
                 // accumulators so that neighbouring MFMAs are independent
@@ -341,14 +354,18 @@ __global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1) lm_k_conv_mfma_h(const
                 for (int m = 0; m < 2; m++)
 #pragma unroll
                     for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA_F16(ah[m], bh[n], acc[m][n]);
+                if (TERMS >= 3) {
 #pragma unroll
-                for (int m = 0; m < 2; m++)
+                    for (int m = 0; m < 2; m++)
 #pragma unroll
-                    for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA_F16(ah[m], bl[n], acc[m][n]);
+                        for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA_F16(ah[m], bl[n], acc[m][n]);
+                }
+                if (TERMS >= 2) {
 #pragma unroll
-                for (int m = 0; m < 2; m++)
+                    for (int m = 0; m < 2; m++)
 #pragma unroll
-                    for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA_F16(al[m], bh[n], acc[m][n]);
+                        for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA_F16(al[m], bh[n], acc[m][n]);
+                }
             }
             buf ^= 1;
         }
@@ -376,6 +393,7 @@ __global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1) lm_k_conv_mfma_h(const
 // 2x2 stride-2 transposed convolution (fp16-split operands): the four (dy, dx) sub-convolutions are 1x1 GEMMs over the SAME
 // input pixels, so one workgroup stages a 16x16-px patch chunk once, reads its A fragments once and feeds four accumulator
 // sets (weights packed like a conv with 4 taps, tap = dy * 2 + dx).  One n-block (32 output channels) per workgroup.
+template <int TERMS>
 __global__ void __launch_bounds__(256, 2) lm_k_convT_mfma_h(const LmConvArgs a)
 {
     LM_DYN_SMEM(smem);
@@ -426,10 +444,14 @@ __global__ void __launch_bounds__(256, 2) lm_k_convT_mfma_h(const LmConvArgs a)
             const lm_h8 bh = *(const lm_h8*)wp, bl = *(const lm_h8*)(wp + 64 * 16);
 #pragma unroll
             for (int m = 0; m < 2; m++) acc[t][m] = LM_MFMA_F16(ah[m], bh, acc[t][m]);
+            if (TERMS >= 3) {
 #pragma unroll
-            for (int m = 0; m < 2; m++) acc[t][m] = LM_MFMA_F16(ah[m], bl, acc[t][m]);
+                for (int m = 0; m < 2; m++) acc[t][m] = LM_MFMA_F16(ah[m], bl, acc[t][m]);
+            }
+            if (TERMS >= 2) {
 #pragma unroll
-            for (int m = 0; m < 2; m++) acc[t][m] = LM_MFMA_F16(al[m], bh, acc[t][m]);
+                for (int m = 0; m < 2; m++) acc[t][m] = LM_MFMA_F16(al[m], bh, acc[t][m]);
+            }
         }
         buf ^= 1;
     }
@@ -504,7 +526,7 @@ __global__ void __launch_bounds__(256) lm_k_prepare(const uint8_t* __restrict__ 
 // COUT == 1 (text mask, output logit): weights [chunk][tap][8], every thread computes TWO pixels 16 columns apart so one
 // weight read serves 8 FMAs.  COUT == 4 (3-channel reconstruction): weights [chunk][tap][8][4].
 template <int COUT>
-__global__ void __launch_bounds__(256) lm_k_conv_small(const float* __restrict__ in, int ips, int C, int H, int W,
+__global__ void LM_NO_PACKED_F32 __launch_bounds__(256) lm_k_conv_small(const float* __restrict__ in, int ips, int C, int H, int W,
                                                        const float* __restrict__ wts, const float* __restrict__ bias, int K, int Cout,
                                                        int act, float* __restrict__ out, int ops)
 {
@@ -584,21 +606,26 @@ __global__ void __launch_bounds__(256) lm_k_conv_small(const float* __restrict__
 LM_DEV int lm_c1_q(int K) { return (LM_C1_TW + K - 1 + 3) >> 2; }
 LM_DEV int lm_c1_row_floats(int K) { return (4 * lm_c1_q(K) * 12 + 63) & ~63; }
 
-__global__ void __launch_bounds__(256) lm_k_conv_c1(const float* __restrict__ in, int ips, int C, int H, int W,
-                                                    const float* __restrict__ wts, const float* __restrict__ bias, int K, int act,
-                                                    float* __restrict__ out, int ops)
+// KS: kernel side known at compile time (7: the shipped configuration), or 0 = taken from the argument.  With the side known
+// the ten window reads of a kernel row are unconditional and issued back to back; with a run-time side every read beyond the
+// third is guarded and waits for its own result.
+template <int KS>
+__global__ void LM_NO_PACKED_F32 __launch_bounds__(256) lm_k_conv_c1(const float* __restrict__ in, int ips, int C, int H, int W,
+                                                                     const float* __restrict__ wts, const float* __restrict__ bias, int Karg, int act,
+                                                                     float* __restrict__ out, int ops)
 {
     LM_DYN_SMEM(smem);
+    const int K = KS ? KS : Karg;
     const int pad = (K - 1) >> 1, taps = K * K, PW = LM_C1_TW + K - 1, PH = 16 + K - 1;
     const int Q = lm_c1_q(K), RF = lm_c1_row_floats(K);
     float* s_patch = (float*)smem;                          // [PH][RF]
-    float* s_w = s_patch + PH * RF;                         // [tap][8]
     const int tiles_x = (W + LM_C1_TW - 1) / LM_C1_TW;
     const int ty0 = (blockIdx.x / tiles_x) << 4, tx0 = (blockIdx.x % tiles_x) * LM_C1_TW;
     const int ly = (int)(threadIdx.x >> 4), lx = (int)(threadIdx.x & 15);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     // the next chunk's patch is fetched into registers while the current chunk is being convolved
-    constexpr int MAXI = 13;                                // ceil(22 * 70 * 2 / 256) patch items per thread (7x7)
+    constexpr int MAXI = KS ? ((16 + KS - 1) * (LM_C1_TW + KS - 1) * 2 + 255) / 256 : 13;      // 13 = ceil(22 * 70 * 2 / 256) patch items per thread (7x7)
+    constexpr int NWIN = KS ? KS + 3 : 10;                  // window pixels 4*lx .. 4*lx + K + 2
     const int items = PH * PW * 2;
     float4 pr[MAXI];
     auto fetch = [&](int c0) {
@@ -628,21 +655,21 @@ __global__ void __launch_bounds__(256) lm_k_conv_c1(const float* __restrict__ in
             }
         }
         const float* wsrc = wts + (long long)(c0 >> 3) * taps * 8;
-        for (int i = threadIdx.x; i < taps * 2; i += blockDim.x) *(float4*)(s_w + i * 4) = *(const float4*)(wsrc + (long long)i * 4);
         lm_lds_barrier();
         if (c0 + 8 < C) fetch(c0 + 8);
         for (int kh = 0; kh < K; kh++) {
             const float* prow = s_patch + (ly + kh) * RF;
 #pragma unroll
             for (int hq = 0; hq < 2; hq++) {                // channels 0-3, 4-7 of the chunk
-                float4 win[10];                             // window pixels 4*lx .. 4*lx + K + 2 (K <= 7)
+                float4 win[NWIN];
 #pragma unroll
-                for (int s2 = 0; s2 < 10; s2++)
-                    win[s2] = (s2 < K + 3) ? *(const float4*)(prow + ((s2 & 3) * Q + lx + (s2 >> 2)) * 12 + hq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int s2 = 0; s2 < NWIN; s2++)
+                    win[s2] = (KS || s2 < K + 3) ? *(const float4*)(prow + ((s2 & 3) * Q + lx + (s2 >> 2)) * 12 + hq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int kw = 0; kw < 7; kw++) {
+                for (int kw = 0; kw < (KS ? KS : 7); kw++) {
                     if (kw >= K) break;
-                    const float4 wv = *(const float4*)(s_w + (kh * K + kw) * 8 + hq * 4);
+                    // the weights are the same for every lane: read through the scalar cache into SGPRs (no LDS traffic, no VGPRs)
+                    const float4 wv = *(const float4*)(wsrc + (kh * K + kw) * 8 + hq * 4);
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const float4 u = win[j + kw];
@@ -822,7 +849,7 @@ static size_t lm_conv_smem_h(int K, int NT)
     return (size_t)P * (((size_t)P * 80 + 255) & ~(size_t)255) + 2 * (size_t)lm_conv_tg_h(K, NT) * NT * 2048;   // rows padded to 256 B, weights double-buffered
 }
 
-template <int NT, int KS, int TG = 0> static int lm_launch_conv_hk(const LmConvArgs& a, hipStream_t st)
+template <int NT, int KS, int TG, int TERMS> static int lm_launch_conv_hkt(const LmConvArgs& a, hipStream_t st)
 {
     const int tg = TG ? TG : lm_conv_tg_h(a.K, NT);
     const int P = 16 + a.K - 1;
@@ -830,16 +857,23 @@ template <int NT, int KS, int TG = 0> static int lm_launch_conv_hk(const LmConvA
 #if !LM_HIP_EMULATED
     static size_t configured = 0;
     if (smem > configured) {
-        LM_HIP(hipFuncSetAttribute((const void*)lm_k_conv_mfma_h<NT, KS, TG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        LM_HIP(hipFuncSetAttribute((const void*)lm_k_conv_mfma_h<NT, KS, TG, TERMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         configured = smem;
     }
 #endif
     const int tiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
     LmConvArgs b = a;
     b.tg = tg;
-    hipLaunchKernelGGL((lm_k_conv_mfma_h<NT, KS, TG>), dim3(tiles, (a.nblocks + NT - 1) / NT), dim3(256), smem, st, b);
+    hipLaunchKernelGGL((lm_k_conv_mfma_h<NT, KS, TG, TERMS>), dim3(tiles, (a.nblocks + NT - 1) / NT), dim3(256), smem, st, b);
     LM_HIP(hipGetLastError());
     return LM_OK;
+}
+
+template <int NT, int KS, int TG = 0> static int lm_launch_conv_hk(const LmConvArgs& a, hipStream_t st)
+{
+    if (a.terms == 1) return lm_launch_conv_hkt<NT, KS, TG, 1>(a, st);
+    if (a.terms == 2) return lm_launch_conv_hkt<NT, KS, TG, 2>(a, st);
+    return lm_launch_conv_hkt<NT, KS, TG, 3>(a, st);
 }
 
 template <int NT> static int lm_launch_conv_h(const LmConvArgs& a, hipStream_t st)
@@ -858,9 +892,13 @@ template <int NT> static int lm_launch_conv_h(const LmConvArgs& a, hipStream_t s
     }
 }
 
-static int lm_launch_conv(const LmConvArgs& a, int ck, hipStream_t st)
+static inline int lm_terms_of_ck(int ck) { return ck == -1 ? 1 : (ck == -2 ? 2 : 3); }
+
+static int lm_launch_conv(const LmConvArgs& a0, int ck, hipStream_t st)
 {
-    if (ck == 0) {          // fp16-split packing
+    LmConvArgs a = a0;
+    if (ck <= 0) {          // fp16-split packing (ck 0: three products per operand pair, -2: two, -1: one)
+        a.terms = lm_terms_of_ck(ck);
         // two n-blocks per wave when the channel blocks divide evenly and the grid still has >= 1.5 workgroups per CU (four
         // would need 128 accumulator registers: one wave per SIMD, measured slower)
         const int tiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
@@ -903,18 +941,22 @@ static int lm_convT_layer(LmFcn* f, int layer, const float* in, int cin, int H, 
     if (!l.w) { lm_set_error("lm_fcn_forward: layer %d has no weights", layer); return LM_ERR_STATE; }
     const int nblocks = (l.cout + 31) / 32;
     // floats per (dy, dx) weight set: fp32 packing [chunk][ks][nblock][64][4]; f16x3 packing [chunk][nblock][2][64] x 16 B
-    const long long per_set = l.ck ? (long long)(cin / l.ck) * (l.ck / 8) * nblocks * 256 : (long long)((cin + 15) / 16) * nblocks * 512;
-    if (l.ck == 0) {        // fp16-split: one launch, the four (dy, dx) weight sets are the four taps of the packing
+    const long long per_set = l.ck > 0 ? (long long)(cin / l.ck) * (l.ck / 8) * nblocks * 256 : (long long)((cin + 15) / 16) * nblocks * 512;
+    if (l.ck <= 0) {        // fp16-split: one launch, the four (dy, dx) weight sets are the four taps of the packing
         LmConvArgs a;
         memset(&a, 0, sizeof(a));
         a.in0 = in; a.c0 = cin; a.ps0 = cin; a.H = H; a.W = W;
         a.wpk = l.w; a.bias = l.bias; a.out = out; a.ops = l.cout; a.ooff = 0; a.Cout = l.cout; a.nblocks = nblocks;
         a.K = 1; a.act = LM_ACT_GELU; a.tmode = 1; a.OH = OH; a.OW = OW;
         const size_t smem = (size_t)16 * ((16 * 80 + 255) & ~255) + 2 * 4 * 2048;
-        hipLaunchKernelGGL(lm_k_convT_mfma_h, dim3(((W + 15) / 16) * ((H + 15) / 16), nblocks), dim3(256), smem, st, a);
+        const dim3 grid(((W + 15) / 16) * ((H + 15) / 16), nblocks);
+        const int terms = lm_terms_of_ck(l.ck);
+        if (terms == 1) hipLaunchKernelGGL(lm_k_convT_mfma_h<1>, grid, dim3(256), smem, st, a);
+        else if (terms == 2) hipLaunchKernelGGL(lm_k_convT_mfma_h<2>, grid, dim3(256), smem, st, a);
+        else hipLaunchKernelGGL(lm_k_convT_mfma_h<3>, grid, dim3(256), smem, st, a);
         LM_HIP(hipGetLastError());
     }
-    for (int d = 0; d < 4 && l.ck != 0; d++) {
+    for (int d = 0; d < 4 && l.ck > 0; d++) {
         LmConvArgs a;
         memset(&a, 0, sizeof(a));
         a.in0 = in; a.c0 = cin; a.ps0 = cin; a.H = H; a.W = W;
@@ -955,16 +997,18 @@ static int lm_small_layer(LmFcn* f, int layer, const float* in, int ips, int C, 
     if (!l.w) { lm_set_error("lm_fcn_forward: layer %d has no weights", layer); return LM_ERR_STATE; }
     if (l.cout == 1 && l.k <= 7) {
         const int PH = 16 + l.k - 1, Q = (LM_C1_TW + l.k - 1 + 3) >> 2, RF = (4 * Q * 12 + 63) & ~63;
-        const size_t smem = ((size_t)PH * RF + (size_t)l.k * l.k * 8) * sizeof(float);
+        const size_t smem = (size_t)PH * RF * sizeof(float);
+        const int tiles = ((W + LM_C1_TW - 1) / LM_C1_TW) * ((H + 15) / 16);
 #if !LM_HIP_EMULATED
-        static size_t configured = 0;
-        if (smem > configured) {
-            LM_HIP(hipFuncSetAttribute((const void*)lm_k_conv_c1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            configured = smem;
+        static size_t configured[2] = {0, 0};
+        if (smem > configured[l.k == 7]) {
+            if (l.k == 7) LM_HIP(hipFuncSetAttribute((const void*)lm_k_conv_c1<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            else LM_HIP(hipFuncSetAttribute((const void*)lm_k_conv_c1<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            configured[l.k == 7] = smem;
         }
 #endif
-        const int tiles = ((W + LM_C1_TW - 1) / LM_C1_TW) * ((H + 15) / 16);
-        hipLaunchKernelGGL(lm_k_conv_c1, dim3(tiles), dim3(256), smem, st, in, ips, C, H, W, l.w, l.bias, l.k, act, out, ops);
+        if (l.k == 7) hipLaunchKernelGGL(lm_k_conv_c1<7>, dim3(tiles), dim3(256), smem, st, in, ips, C, H, W, l.w, l.bias, l.k, act, out, ops);
+        else hipLaunchKernelGGL(lm_k_conv_c1<0>, dim3(tiles), dim3(256), smem, st, in, ips, C, H, W, l.w, l.bias, l.k, act, out, ops);
         LM_HIP(hipGetLastError());
         return LM_OK;
     }
@@ -1033,30 +1077,11 @@ static int lm_fcn_forward_impl(LmFcn* f, const uint8_t* d_rgb, int h, int w, flo
     return LM_OK;
 }
 
-// Forward passes are chained on the device even when they are issued on different HIP streams (or by different engines): two of
-// them running concurrently were measured to disturb each other (sporadic 1e-3 .. 2e-2 errors in the one-channel heads, none
-// with a single pass in flight or next to other kernels; DESIGN.md 7, open issue), so a pass waits for the event the previous
-// one recorded.
-static std::mutex g_fcn_mutex;
-#if !LM_HIP_EMULATED
-static hipEvent_t g_fcn_done = nullptr;
-static hipStream_t g_fcn_last_stream = nullptr;
-#endif
-
+// Forward passes issued on different HIP streams (or by different engines) may overlap on the device: every engine owns its
+// activation buffers, and the kernels hold no state between launches.  (Round 1 chained them behind an event because two
+// passes in flight disturbed each other's one-channel heads; the cause was the packed-fp32 code of those kernels, see
+// LM_NO_PACKED_F32 above, tools/fcn_overlap_repro.py and tests/test_cc_gpu.py::test_fcn_two_engines_on_two_streams.)
 extern "C" int lm_fcn_forward(LmFcn* f, const uint8_t* d_rgb, int h, int w, float* d_out, float* d_text, float* d_rec, void* stream)
 {
-    std::lock_guard<std::mutex> lock(g_fcn_mutex);
-#if !LM_HIP_EMULATED
-    hipStream_t st = (hipStream_t)stream;
-    if (!g_fcn_done) LM_HIP(hipEventCreateWithFlags(&g_fcn_done, hipEventDisableTiming));
-    else if (st != g_fcn_last_stream) LM_HIP(hipStreamWaitEvent(st, g_fcn_done, 0));
-#endif
-    const int rc = lm_fcn_forward_impl(f, d_rgb, h, w, d_out, d_text, d_rec, stream);
-#if !LM_HIP_EMULATED
-    if (rc == LM_OK) {
-        LM_HIP(hipEventRecord(g_fcn_done, st));
-        g_fcn_last_stream = st;
-    }
-#endif
-    return rc;
+    return lm_fcn_forward_impl(f, d_rgb, h, w, d_out, d_text, d_rec, stream);
 }

@@ -96,8 +96,9 @@ class FcnEngine:
 
     def __init__(self, widths, pixel_kernel, kernel, max_h, max_w, lib=None, precision="f16x3"):
         """precision: "f16x3" (default; fp16-split operands, three f16 MFMAs per product, fp32 accumulate, ~1e-6 relative
-        error at 5x the fp32 MFMA rate) or "fp32" (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains)."""
-        assert precision in ("f16x3", "fp32")
+        error at 5x the fp32 MFMA rate), "f16x2" (activations split, weights rounded to f16: two MFMAs), "f16" (both operands
+        rounded to f16: one MFMA) or "fp32" (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains)."""
+        assert precision in ("f16x3", "f16x2", "f16", "fp32")
         self.precision = precision
         self.lib = lib or _lib.load()
         self.be = Backend(self.lib)
@@ -141,12 +142,13 @@ class FcnEngine:
         def ck_for(*chans):
             return 16 if all(c % 16 == 0 for c in chans) else 8
 
-        h = self.precision == "f16x3"
+        h = self.precision != "fp32"
+        hck = {"f16x3": 0, "f16x2": -2, "f16": -1}.get(self.precision, 0)       # lm_fcn.hip: products per operand pair
 
         def mfma(w, cin_map, cin_padded):
             """(packed weights, ck): ck = 0 selects the fp16-split kernel"""
             if h:
-                return pack_mfma_h(w, cin_map, sum(cin_padded) if isinstance(cin_padded, tuple) else cin_padded), 0
+                return pack_mfma_h(w, cin_map, sum(cin_padded) if isinstance(cin_padded, tuple) else cin_padded), hck
             ck = ck_for(cin_padded) if not isinstance(cin_padded, tuple) else ck_for(*cin_padded)
             return pack_mfma(w, ck, cin_map, cin_padded if not isinstance(cin_padded, tuple) else sum(cin_padded)), ck
 
@@ -168,7 +170,7 @@ class FcnEngine:
             bt = _np(sd["transposed_conv_%d.bias" % lvl]).astype(np.float32)
             wt, bt = fold_bn(wt, bt, sd, "upsample_block_%d.0" % lvl, 1)
             if h:       # one launch: the four (dy, dx) sets are the four "taps" of the packing (lm_k_convT_mfma_h)
-                self._set(L_UPT + i, pack_mfma_h(np.ascontiguousarray(wt.transpose(1, 0, 2, 3)), range(tin), tin), bias_pad(bt), tin, u, 1, 0)
+                self._set(L_UPT + i, pack_mfma_h(np.ascontiguousarray(wt.transpose(1, 0, 2, 3)), range(tin), tin), bias_pad(bt), tin, u, 1, hck)
             else:
                 sets = [mfma(np.ascontiguousarray(wt[:, :, dy, dx].T)[:, :, None, None], range(tin), tin) for dy in (0, 1) for dx in (0, 1)]
                 self._set(L_UPT + i, np.concatenate([p for p, _ in sets]), bias_pad(bt), tin, u, 1, sets[0][1])
@@ -182,10 +184,10 @@ class FcnEngine:
         w, b = conv_bn("conv_reconstruct")
         self._set(L_REC, pack_small(w, range(3, 3 + c1), s0), np.pad(b, (0, 4 - len(b))), s0, 3, self.kk, 0)
         w, b = conv_bn("conv_pixels_1")
-        wpk, ck = (pack_mfma_h(w, range(3 + c1), s0), 0) if h else (pack_mfma(w, 8, range(3 + c1), s0), 8)
+        wpk, ck = (pack_mfma_h(w, range(3 + c1), s0), hck) if h else (pack_mfma(w, 8, range(3 + c1), s0), 8)
         self._set(L_PX1, wpk, bias_pad(b), s0, pm1, self.pk, ck)
         w, b = conv_bn("conv_pixels_2")
-        wpk, ck = (pack_mfma_h(w, range(3 + pm1), s1), 0) if h else (pack_mfma(w, 8, range(3 + pm1), s1), 8)
+        wpk, ck = (pack_mfma_h(w, range(3 + pm1), s1), hck) if h else (pack_mfma(w, 8, range(3 + pm1), s1), 8)
         self._set(L_PX2, wpk, bias_pad(b), s1, pm2, self.pk, ck)
         w, b = conv_bn("conv_out")
         self._set(L_OUT, pack_small(w, range(3 + pm2), s2), np.pad(b, (0, 4 - len(b))), s2, 1, self.pk, 0)

@@ -198,32 +198,58 @@ def test_fcn_shipped_config_vs_oracle(hip_lib, precision):
     eng.close()
 
 
-def test_fcn_two_engines_on_two_streams(hip_lib):
-    """Two engines fed from two HIP streams at 1080p give the single-stream logits bit for bit: the library chains forward
-    passes on the device (two passes actually overlapping were measured to disturb each other's one-channel heads)."""
+@pytest.fixture(scope="module")
+def fcn_1080p_oracle():
+    """Shipped widths, one 1920x1080 frame through the torch fp32 oracle (all host cores; once per test module)."""
     import torch
-    from lecturemath_amd import _lib, fcn
     from oracle import fcn as ofcn
-    h, w = 1080, 1920
     sd = ofcn.random_state_dict(ofcn.SHIPPED_WIDTHS, pixel_kernel=7, seed=0)
+    rgb, _ = synth.whiteboard_rgb(1080, 1920, 1500, seed=20211)
+    torch.set_num_threads(os.cpu_count())
+    with torch.no_grad():
+        o, t, r = ofcn.forward(sd, ofcn.prepare_image(rgb))
+    return sd, rgb, o[0, 0].numpy(), t[0, 0].numpy(), r[0].numpy()
+
+
+@pytest.mark.parametrize("precision,tol", [("f16x3", 1e-4), ("fp32", 1e-4), ("f16x2", 1e-3), ("f16", 1e-3)])
+def test_fcn_shipped_config_1080p_vs_oracle(hip_lib, fcn_1080p_oracle, precision, tol):
+    """BASELINE configs[1] at its size: the shipped network on one 1920x1080 frame against the oracle.  The bar is 1e-3 on the
+    logits (north_star); the default format (f16x3) and fp32 are held to 1e-4, the cheaper operand formats to the bar itself."""
+    from lecturemath_amd import fcn
+    sd, rgb, o, t, r = fcn_1080p_oracle
+    eng = fcn.FcnEngine(synth.FCN_SHIPPED_WIDTHS, 7, 3, 1080, 1920, hip_lib, precision=precision)
+    eng.load_state_dict(sd)
+    out, text, rec = (x.cpu().numpy() for x in eng.forward(rgb))
+    eng.close()
+    assert np.abs(out - o).max() <= tol and np.abs(text - t).max() <= tol and np.abs(rec - r).max() <= tol
+
+
+def test_fcn_two_engines_on_two_streams(hip_lib, fcn_1080p_oracle):
+    """Two engines fed from two HIP streams at 1080p, their forward passes really overlapping on the device (nothing in the
+    library serialises them), give the single-pass logits -- themselves within 1e-4 of the oracle -- bit for bit, pass after
+    pass.  Round 1 saw sporadic 1e-3..2e-2 errors in the one-channel heads here (packed-fp32 code)."""
+    import torch
+    from lecturemath_amd import fcn
+    sd, rgb, o, t, r = fcn_1080p_oracle
+    h, w = 1080, 1920
     engines = []
     for _ in range(2):
-        e = fcn.FcnEngine(ofcn.SHIPPED_WIDTHS, 7, 3, h, w, hip_lib, precision="f16x3")
+        e = fcn.FcnEngine(synth.FCN_SHIPPED_WIDTHS, 7, 3, h, w, hip_lib, precision="f16x3")
         e.load_state_dict(sd)
         engines.append(e)
-    rgb, _ = synth.whiteboard_rgb(h, w, 1500, seed=20211)
     d = torch.from_numpy(rgb).cuda()
-    gold = [t.clone() for t in engines[0].forward(d)]
+    gold = [x.clone() for x in engines[0].forward(d)]
+    assert float(np.abs(gold[0].cpu().numpy() - o).max()) <= 1e-4 and float(np.abs(gold[1].cpu().numpy() - t).max()) <= 1e-4
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     torch.cuda.synchronize()
-    for _ in range(4):
+    for _ in range(10):
         res = []
         for e, st in zip(engines, streams):
             with torch.cuda.stream(st):
                 res.append(e.forward(d))
         torch.cuda.synchronize()
-        for r in res:
-            for a, b in zip(gold, r):
+        for rr in res:
+            for a, b in zip(gold, rr):
                 assert bool((a == b).all())
     for e in engines:
         e.close()

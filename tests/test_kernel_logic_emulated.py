@@ -114,3 +114,28 @@ def test_grouping_golden_short_gap(emu_lib):
 @pytest.mark.parametrize("precision", ["f16x3", "fp32"])
 def test_fcn_golden_tiny(emu_lib, precision):
     assert lm_checks.check_fcn_golden(emu_lib, "k7_70x94", precision=precision) < 1e-4
+
+
+def test_emulated_library_under_asan_ubsan(oracle_built):
+    """The product's HIP sources built for the CPU with -fsanitize=address,undefined (tests/hipemu `make asan`) and run in a
+    child interpreter with the ASan runtime preloaded: the FCN forward pass (f16x3; every dynamic-LDS kernel of lm_fcn.hip),
+    a stream with large components and step 03.  The emulator allocates the dynamic LDS of every launch at exactly the size
+    the launch asked for and fills it with NaN patterns before every block, so an LDS index past a kernel's allocation aborts
+    the child and LDS that is consumed without having been written poisons the compared results."""
+    import subprocess
+    import sys
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu")
+    subprocess.check_call(["make", "-s", "-C", d, "asan"])
+    rt = subprocess.check_output(["make", "-s", "-C", d, "asan-runtime"]).decode().strip()
+    child = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from lecturemath_amd import _lib\nimport lm_checks\n"
+        "lib = _lib.load(%r)\n"
+        "assert lm_checks.check_fcn_golden(lib, 'k7_70x94', tol=1e-4, precision='f16x3') < 1e-4\n"
+        "lm_checks.check_stream_large_components(lib, n_frames=6)\n"
+        "lm_checks.check_grouping_golden(lib, 'short_gap_jitter')\n"
+        "print('sanitized run ok')\n" % (os.path.dirname(os.path.dirname(d)), os.path.dirname(d), os.path.join(d, "liblecturemath_emu_asan.so")))
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:detect_stack_use_after_return=0",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "sanitized run ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
