@@ -9,6 +9,28 @@ import time
 import numpy as np
 
 
+def deletion_signal(group_ages, st3D, add_threshold):
+    """The signal method 3 segments (:44-99): every group adds its box area (as a fraction of the frame) at the frame it
+    appears and at the frame it disappears; the deletions are accumulated over time, restarting from zero at every frame whose
+    additions exceed add_threshold.  float64 throughout; np.add.at and np.cumsum add in index order, i.e. in the order the
+    reference's loops do, so the sums round identically."""
+    n = len(st3D.frame_indices)
+    groups = list(group_ages)                      # dict order = group index order
+    first = np.fromiter((group_ages[g][0] for g in groups), dtype=np.int64, count=len(groups))
+    last = np.fromiter((group_ages[g][-1] for g in groups), dtype=np.int64, count=len(groups))
+    boxes = np.array([st3D.cc_group_boundaries[g] for g in groups], dtype=np.int64).reshape(-1, 4)       # min_x, max_x, min_y, max_y
+    area = ((boxes[:, 1] - boxes[:, 0] + 1) * (boxes[:, 3] - boxes[:, 2] + 1)) / (st3D.width * st3D.height)
+    added, deleted = np.zeros(n), np.zeros(n)
+    np.add.at(added, first, area)
+    np.add.at(deleted, last, area)
+    signal = np.empty(n)
+    restarts = np.flatnonzero(added > add_threshold)
+    bounds = np.unique(np.concatenate([[0], restarts, [n]]))
+    for a, b in zip(bounds[:-1], bounds[1:]):       # a running sum per stretch between restarts
+        signal[a:b] = np.cumsum(deleted[a:b])
+    return signal
+
+
 def process_input(process, input_data):
     from AccessMath.data.space_time_struct import SpaceTimeStruct
     from AccessMath.preprocessing.content.video_segmenter import VideoSegmenter
@@ -26,23 +48,8 @@ def process_input(process, input_data):
     add_threshold = process.configuration.get_float("VIDEO_SEGMENTATION_DEL_EVENT_ADD_THRESHOLD", 10)
     min_segment_length = process.configuration.get_int("VIDEO_SEGMENTATION_DEL_EVENT_MIN_LENGTH", 15)
     threshold = process.configuration.get_float("VIDEO_SEGMENTATION_DEL_EVENT_THRESHOLD", 0.25)
-    n = len(st3D.frame_indices)
-    add_values = np.zeros(n)
-    del_values = np.zeros(n)
-    for group_idx in group_ages:
-        first, last = group_ages[group_idx][0], group_ages[group_idx][-1]
-        g_min_x, g_max_x, g_min_y, g_max_y = st3D.cc_group_boundaries[group_idx]
-        area = (g_max_x - g_min_x + 1) * (g_max_y - g_min_y + 1)
-        area /= (st3D.width * st3D.height)          # normalised by the frame size (float64)
-        add_values[first] += area
-        del_values[last] += area
-    accumulated_delete = 0.0
-    cumulative_delete = np.zeros(n)
-    for idx in range(n):
-        if add_values[idx] > add_threshold:
-            accumulated_delete = 0.0
-        accumulated_delete += del_values[idx]
-        cumulative_delete[idx] = accumulated_delete
+    cumulative_delete = deletion_signal(group_ages, st3D, add_threshold)
+    n = len(cumulative_delete)
     intervals = VideoSegmenter.split_video_from_group_deletes(cumulative_delete, 0, n - 1, min_segment_length, threshold)
     print(intervals)
     print([(st3D.frame_indices[start_f], st3D.frame_indices[end_f]) for start_f, end_f in intervals])

@@ -104,6 +104,38 @@ def check_step_04(name, step03_outputs, clean=None):
         assert [float(v) for v in sums] == [float(v) for v in g["sums"]]
 
 
+def check_step_05_ties(lib, cases=None):
+    """Step 05 on the tie-heavy synthetic structures of G8b (hundreds of groups per segment, many starting at the same frame and
+    overlapping in chains): the groups the reference draws -- decided by its tie-break inside conflict sets -- keyframes and CC
+    time lists, for two segmentations per case."""
+    import json
+    use_library(lib)
+    from AccessMath.data.space_time_struct import SpaceTimeStruct
+    from AccessMath.preprocessing.content.keyframe_extractor import KeyframeExtractor
+    g = np.load(os.path.join(lm_checks.GOLD, "g8b_step05_ties.npz"))
+    for c in (range(int(g["n_cases"])) if cases is None else cases):
+        meta = json.loads(bytes(g["meta_%d" % c]).decode())
+        ng, off = meta["n_groups"], g["ages_off_%d" % c]
+        ages = {k: [int(v) for v in g["ages_%d" % c][off[k]:off[k + 1]]] for k in range(ng)}
+        bounds = {k: tuple(int(v) for v in g["bounds_%d" % c][k]) for k in range(ng)}
+        bits = np.unpackbits(g["images_%d" % c])
+        images, pos = {}, 0
+        for k in range(ng):
+            w, h = bounds[k][1] - bounds[k][0] + 1, bounds[k][3] - bounds[k][2] + 1
+            images[k] = []
+            for _ in range(len(ages[k]) - 1):
+                images[k].append((bits[pos:pos + w * h].reshape(h, w) * 255).astype(np.uint8))
+                pos += w * h
+        n = meta["n"]
+        st3d = SpaceTimeStruct([1000.0 * i for i in range(n)], list(range(n)), meta["h"], meta["w"], ages, images, bounds)
+        for k, segs in enumerate(meta["segs"]):
+            keyframes, cc_times = KeyframeExtractor.GenerateFromST3DForIntervals(st3d, [tuple(sg) for sg in segs], False)
+            kf = np.stack(keyframes)
+            assert (np.packbits(kf[..., 0] == 255, axis=2) == g["keyframes_%d_%d" % (c, k)]).all(), (c, k)
+            flat = np.asarray([(sidx, *t) for sidx, lst in enumerate(cc_times) for t in lst], np.float64).reshape(-1, 6)
+            assert flat.shape == g["times_%d_%d" % (c, k)].shape and (flat == g["times_%d_%d" % (c, k)]).all(), (c, k)
+
+
 def check_step_05(lib, name):
     """Step 05 core (KeyframeExtractor.GenerateFromST3DForIntervals) on the reference's own step-03 outputs (G4 fixture) vs
     the reference's keyframes and CC times (G8), three segmentations; plus the entry point's interval arithmetic."""

@@ -110,5 +110,9 @@ def test_step_05_short_gap(emu_lib):
     dropin_checks.check_step_05(emu_lib, "short_gap_jitter")
 
 
+def test_step_05_tie_heavy_structures(emu_lib):
+    dropin_checks.check_step_05_ties(emu_lib, cases=(0, 1))
+
+
 def test_pipeline_short_gap(emu_lib):
     dropin_checks.check_pipeline(emu_lib, "short_gap_jitter")
