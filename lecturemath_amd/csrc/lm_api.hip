@@ -389,19 +389,22 @@ extern "C" int CC_AgeBoundaries(int* labels, float* ages, int width, int height,
     const size_t px = (size_t)width * height;
     if (!c || lm_stage(c, px)) return 0;
     const int n = count_labels;
-    int32_t* d_out = nullptr;     // 6 arrays of n
-    if (hipMalloc((void**)&d_out, (size_t)n * 7 * sizeof(int32_t)) != hipSuccess) { lm_set_error("CC_AgeBoundaries: hipMalloc failed"); return 0; }
+    int32_t* d_out = nullptr;     // 9 arrays of n
+    if (hipMalloc((void**)&d_out, (size_t)n * 9 * sizeof(int32_t)) != hipSuccess) { lm_set_error("CC_AgeBoundaries: hipMalloc failed"); return 0; }
     int32_t *mny = d_out, *mxy = d_out + n, *mnx = d_out + 2 * (size_t)n, *mxx = d_out + 3 * (size_t)n, *cnt = d_out + 4 * (size_t)n,
-            *ageb = d_out + 5 * (size_t)n;
+            *ageb = d_out + 5 * (size_t)n, *last_px = d_out + 7 * (size_t)n, *last_neg = d_out + 8 * (size_t)n;
     float* agef = (float*)(d_out + 6 * (size_t)n);
     bool ok = hipMemcpy(c->stage_i32, labels, px * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
     if (ok && ages) ok = hipMemcpy(c->stage_f32, ages, px * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
     if (ok) {
-        hipLaunchKernelGGL(lm_k_ab_init, dim3(lm_blocks(n, 256)), dim3(256), 0, (hipStream_t)0, mny, mxy, mnx, mxx, cnt, ageb,
+        const float* d_ages = ages ? c->stage_f32 : (const float*)nullptr;
+        hipLaunchKernelGGL(lm_k_ab_init, dim3(lm_blocks(n, 256)), dim3(256), 0, (hipStream_t)0, mny, mxy, mnx, mxx, cnt, ageb, last_px, last_neg,
                            width, height, n);
-        hipLaunchKernelGGL(lm_k_ab_scan, dim3(lm_blocks((long long)px, 256)), dim3(256), 0, (hipStream_t)0, c->stage_i32,
-                           ages ? c->stage_f32 : (const float*)nullptr, width, height, n, mny, mxy, mnx, mxx, cnt, ageb);
-        hipLaunchKernelGGL(lm_k_ab_finish, dim3(lm_blocks(n, 256)), dim3(256), 0, (hipStream_t)0, ageb, agef, n);
+        hipLaunchKernelGGL(lm_k_ab_scan, dim3(lm_blocks((long long)px, 256)), dim3(256), 0, (hipStream_t)0, c->stage_i32, d_ages, width, height, n,
+                           mny, mxy, mnx, mxx, cnt, last_px, last_neg);
+        hipLaunchKernelGGL(lm_k_ab_age, dim3(lm_blocks((long long)px, 256)), dim3(256), 0, (hipStream_t)0, c->stage_i32, d_ages, width, height, n,
+                           last_neg, ageb);
+        hipLaunchKernelGGL(lm_k_ab_finish, dim3(lm_blocks(n, 256)), dim3(256), 0, (hipStream_t)0, ageb, last_px, last_neg, d_ages, agef, n);
         const size_t nb = (size_t)n * sizeof(int32_t);
         ok = hipMemcpy(out_mins_y, mny, nb, hipMemcpyDeviceToHost) == hipSuccess &&
              hipMemcpy(out_maxs_y, mxy, nb, hipMemcpyDeviceToHost) == hipSuccess &&

@@ -689,21 +689,27 @@ __global__ void __launch_bounds__(256) lm_k_stats(const uint64_t* __restrict__ b
 // ------------------------------------------------------------------------------------------------
 // K7b: CC_AgeBoundaries from an arbitrary int32 label image (+ fp32 ages): the literal drop-in
 // entry point (labels may come from elsewhere, e.g. is_labeled=True callers, labeler.py:127-130).
-// One thread per pixel quad; out arrays pre-initialised by lm_k_ab_init.
-// Age semantics: exact for non-negative ages (the reference's sentinel is -1; the hot path passes zeros).
+// Age semantics (accessmath_lib.c:405-407, a sequential raster scan with -1 as "nothing yet"):
+//     if (age_out < 0 || age[px] < age_out) age_out = age[px];
+// so a NEGATIVE age makes the next pixel of the label overwrite it whatever its value.  In closed form, with j the last
+// pixel of the label (raster order) whose age is negative: the result is that pixel's age if it is the label's last pixel,
+// otherwise the minimum over the pixels after j (all of them >= 0); without negative ages, the plain minimum.  Two passes:
+// lm_k_ab_scan finds, per label, the raster index of its last pixel and of its last negative-age pixel, lm_k_ab_age takes the
+// minimum (bit patterns of non-negative floats order like ints) over the pixels behind the latter.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) lm_k_ab_init(int32_t* mny, int32_t* mxy, int32_t* mnx, int32_t* mxx, int32_t* cnt,
-                                                    int32_t* age_bits, int W, int H, int n)
+                                                    int32_t* age_bits, int32_t* last_px, int32_t* last_neg, int W, int H, int n)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         mny[i] = H; mxy[i] = 0; mnx[i] = W; mxx[i] = 0; cnt[i] = 0;
-        age_bits[i] = 0x7fffffff;   // "no pixel seen"; float bit patterns of ages >= 0 order like ints
+        age_bits[i] = 0x7fffffff;   // "no pixel seen"
+        last_px[i] = -1; last_neg[i] = -1;
     }
 }
 
 __global__ void __launch_bounds__(256) lm_k_ab_scan(const int32_t* __restrict__ labels, const float* __restrict__ ages,
                                                     int W, int H, int n, int32_t* mny, int32_t* mxy, int32_t* mnx,
-                                                    int32_t* mxx, int32_t* cnt, int32_t* age_bits)
+                                                    int32_t* mxx, int32_t* cnt, int32_t* last_px, int32_t* last_neg)
 {
     long long total = (long long)W * H;
     long long stride = (long long)gridDim.x * blockDim.x;
@@ -717,19 +723,38 @@ __global__ void __launch_bounds__(256) lm_k_ab_scan(const int32_t* __restrict__ 
         atomicMin(&mnx[k], x);
         atomicMax(&mxx[k], x);
         atomicAdd(&cnt[k], 1);
-        float a = ages ? ages[i] : 0.0f;
-        int ab;
-        memcpy(&ab, &a, 4);
-        if (a >= 0.0f) atomicMin(&age_bits[k], ab);
+        if (ages) {
+            atomicMax(&last_px[k], (int)i);
+            if (ages[i] < 0.0f) atomicMax(&last_neg[k], (int)i);
+        }
     }
 }
 
-__global__ void __launch_bounds__(256) lm_k_ab_finish(const int32_t* age_bits, float* out_age, int n)
+__global__ void __launch_bounds__(256) lm_k_ab_age(const int32_t* __restrict__ labels, const float* __restrict__ ages, int W, int H, int n,
+                                                   const int32_t* __restrict__ last_neg, int32_t* age_bits)
+{
+    long long total = (long long)W * H;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int l = labels[i];
+        if (l <= 0 || l > n) continue;
+        const int k = l - 1;
+        const float a = ages ? ages[i] : 0.0f;
+        if ((int)i <= last_neg[k] || !(a >= 0.0f)) continue;
+        int ab;
+        memcpy(&ab, &a, 4);
+        atomicMin(&age_bits[k], ab & 0x7fffffff);       // -0.0f counts as 0.0f
+    }
+}
+
+__global__ void __launch_bounds__(256) lm_k_ab_finish(const int32_t* age_bits, const int32_t* last_px, const int32_t* last_neg,
+                                                      const float* __restrict__ ages, float* out_age, int n)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         int ab = age_bits[i];
         float a = -1.0f;
-        if (ab != 0x7fffffff) memcpy(&a, &ab, 4);
+        if (ages && last_neg[i] >= 0 && last_neg[i] == last_px[i]) a = ages[last_neg[i]];     // the label ends on a negative age
+        else if (ab != 0x7fffffff) memcpy(&a, &ab, 4);
         out_age[i] = a;
     }
 }

@@ -303,6 +303,109 @@ def check_fcn_class(lib, name="k7_70x94"):
     assert ((dec == 255 - g["binary"]) | edge).all()
 
 
+def check_step01_entry_points(lib, tmp_dir, name="k7_70x94", n_frames=3):
+    """The step-01 script's callbacks as the harness calls them (pre_ST3D_v3.0_01_binarize.py:20-55: get_worker builds the
+    network from the configuration and a state_dict written with torch.save, the sampler feeds worker.handleFrame, get_results
+    hands back (frame_times, frame_indices, compressed_frames)) and the one-image tool test_FCN_binarizer.py (:13-59) through
+    its main() with the reference's argv -- both against the reference's binarization of the G5 fixture."""
+    use_library(lib)
+    import importlib.util
+    import types
+    import PIL.Image
+    import torch
+    from AM_CommonTools.configuration.configuration import Configuration
+    from lecturemath_amd import fcn, png
+    g = np.load(os.path.join(lm_checks.GOLD, "g5_fcn_%s.npz" % name))
+    tmp_dir = str(tmp_dir)
+    os.makedirs(os.path.join(tmp_dir, "models"), exist_ok=True)
+    torch.save({k[3:]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith("sd.")}, os.path.join(tmp_dir, "models", "net.dat"))
+    conf_path = os.path.join(tmp_dir, "lecture.conf")
+    with open(conf_path, "w") as f:
+        f.write("# written by tests/dropin_checks.py\nOUTPUT_PATH = %s\nBINARIZATION_FCN_LECTURENET_DIR = models\n"
+                "BINARIZATION_FCN_LECTURENET_FILENAME = net.dat\nFCN_BINARIZER_NET_PIXEL_KERNEL_SIZE = %d\n" % (tmp_dir, int(g["pk"])))
+        for (key, _), v in zip(fcn.WIDTH_KEYS, g["widths"]):
+            f.write("%s = %d\n" % (key, int(v)))
+
+    def script(fname):
+        spec = importlib.util.spec_from_file_location("lm_entry_" + fname.replace(".", "_"), os.path.join(DROPIN, fname))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    edge = np.abs(g["out"][0, 0] - 0.01569) < 2e-3        # pixels whose logit sits within the fp32 tolerance of the decision edge
+    # ---- step 01
+    s01 = script("pre_ST3D_v3.0_01_binarize.py")
+    process = types.SimpleNamespace(configuration=Configuration.from_file(conf_path), params={})
+    worker = s01.get_worker(process)
+    h, w = g["rgb"].shape[:2]
+    worker.initialize(w, h)
+    bgr = np.ascontiguousarray(g["rgb"][:, :, ::-1])
+    for k in range(n_frames):
+        worker.handleFrame(bgr, None, 0, 1000.0 * (k + 1), 1000.0 * (k + 1), 30 * (k + 1))
+    worker.finalize()
+    times, indices, compressed = s01.get_results(worker)
+    assert times == [1000.0 * (k + 1) for k in range(n_frames)] and indices == [30 * (k + 1) for k in range(n_frames)]
+    assert len(compressed) == n_frames and not hasattr(worker, "lecture_net")
+    for c in compressed:
+        assert ((png.decode_gray8(c) == 255 - g["binary"]) | edge).all()
+    # ---- test_FCN_binarizer.py
+    PIL.Image.fromarray(g["rgb"]).save(os.path.join(tmp_dir, "in.png"))
+    tool = script("test_FCN_binarizer.py")
+    argv = sys.argv
+    try:
+        sys.argv = ["test_FCN_binarizer.py", conf_path, os.path.join(tmp_dir, "models", "net.dat"), os.path.join(tmp_dir, "in.png"),
+                    os.path.join(tmp_dir, "out")]
+        tool.main()
+    finally:
+        sys.argv = argv
+    binary = np.asarray(PIL.Image.open(os.path.join(tmp_dir, "out_BIN.png")))
+    text = np.asarray(PIL.Image.open(os.path.join(tmp_dir, "out_text.png")))
+    bg = np.asarray(PIL.Image.open(os.path.join(tmp_dir, "out_bg.png")).convert("RGB"))
+    assert ((binary == g["binary"]) | edge).all()
+    assert ((text == g["text_mask"]) | (np.abs(g["text"][0, 0] - 0.01569) < 2e-3)).all()
+    assert np.abs(bg[:, :, ::-1].astype(np.int32) - g["rec_img"].astype(np.int32)).max() <= 1       # the tool writes RGB, rec_img is BGR
+
+
+def check_rebuilt_binary_images(lib, name="short_gap_jitter"):
+    """CCStabilityEstimator.rebuilt_binary_images (cc_stability_estimator.py:166-179; dead work in the reference's step 03, kept
+    for callers): every kept CC painted back gives the input frame minus the CCs below MIN_CC_PIXELS."""
+    use_library(lib)
+    from AccessMath.preprocessing.content.cc_stability_estimator import CCStabilityEstimator
+    from oracle import cc as occ
+    g, spec, frames = lm_checks.load_stream(name)
+    est = CCStabilityEstimator(spec["w"], spec["h"], 0.85, 0.85, spec["gap2"], False)
+    for f in frames[:12]:
+        est.add_frame(f, True)
+    est.finish_processing()
+    rebuilt = est.rebuilt_binary_images()
+    assert len(rebuilt) == 12
+    for f, r in zip(frames, rebuilt):
+        labels, n = occ.label4(f)
+        rec, crops = occ.extract(labels, n)
+        exp = np.zeros_like(f)
+        for (cc_id, x0, x1, y0, y1, size), crop in zip(rec, crops):
+            exp[y0:y1 + 1, x0:x1 + 1] |= crop
+        assert r.dtype == np.uint8 and (r == exp).all()
+
+
+def check_overlap_golden(lib):
+    """G2: ConnectedComponent.getOverlapFMeasure of the drop-in class (AND + count on the crops) vs the reference's recall /
+    precision, bit for bit as float64, for 200 CC pairs incl. disjoint ones (connected_component.py:202-250)."""
+    use_library(lib)
+    from AM_CommonTools.data.connected_component import ConnectedComponent
+    g = np.load(os.path.join(lm_checks.GOLD, "g2_overlap.npz"))
+    oa = ob = 0
+    for k, bx in enumerate(g["boxes"]):
+        ax0, ax1, ay0, ay1, asz, bx0, bx1, by0, by1, bsz = (int(v) for v in bx)
+        ah, aw, bh, bw = ay1 - ay0 + 1, ax1 - ax0 + 1, by1 - by0 + 1, bx1 - bx0 + 1
+        a = ConnectedComponent(0, ax0, ax1, ay0, ay1, asz, g["crops_a"][oa:oa + ah * aw].reshape(ah, aw))
+        b = ConnectedComponent(1, bx0, bx1, by0, by1, bsz, g["crops_b"][ob:ob + bh * bw].reshape(bh, bw))
+        oa += ah * aw
+        ob += bh * bw
+        r, p = a.getOverlapFMeasure(b, False, False)
+        assert np.float64(r).view(np.int64) == g["recall"][k].view(np.int64) and np.float64(p).view(np.int64) == g["precision"][k].view(np.int64), k
+
+
 def check_fcn_4k_resize_branch(lib):
     """binarize() on a 3840x2160 frame (> 2.5 MP, FCN_lecturenet.py:435-437,481-494): PIL LANCZOS halving, FCN at 1080p,
     NEAREST x2 back -- against the oracle's torch forward on the same halved image.  Tiny network (the branch is about

@@ -116,3 +116,16 @@ def test_step_05_tie_heavy_structures(emu_lib):
 
 def test_pipeline_short_gap(emu_lib):
     dropin_checks.check_pipeline(emu_lib, "short_gap_jitter")
+
+
+def test_step01_entry_points(emu_lib, tmp_path):
+    """pre_ST3D_v3.0_01_binarize.py get_worker / get_results with a torch.save'd state_dict, and test_FCN_binarizer.py main()."""
+    dropin_checks.check_step01_entry_points(emu_lib, tmp_path, n_frames=1)
+
+
+def test_rebuilt_binary_images(emu_lib, oracle_built):
+    dropin_checks.check_rebuilt_binary_images(emu_lib)
+
+
+def test_overlap_golden_g2(emu_lib):
+    dropin_checks.check_overlap_golden(emu_lib)

@@ -56,6 +56,14 @@ def test_drop_in_cc_age_boundaries(emu_lib, oracle_built):
     exp = oracle_built.age_boundaries(labels, ages, n)
     for a, b in zip(outs + [oa], exp):
         assert (a == b).all()
+    # signed ages: the reference's sequential "-1 = nothing yet" rule (accessmath_lib.c:405-407) lets a negative age be
+    # overwritten by whatever pixel follows; labels ending on a negative age keep it
+    for seed in (4, 5):
+        ages = np.random.default_rng(seed).normal(0.2, 1.0, img.shape).astype(np.float32)
+        oa = np.zeros(n, np.float32)
+        emu_lib.CC_AgeBoundaries(labels.ctypes.data, ages.ctypes.data, img.shape[1], img.shape[0], n, *[o.ctypes.data for o in outs], oa.ctypes.data)
+        exp_age = oracle_built.age_boundaries(labels, ages, n)[5]
+        assert (exp_age < 0).any() and (exp_age >= 0).any() and (oa == exp_age).all()
 
 
 def test_label_host(emu_lib, oracle_built):
