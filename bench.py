@@ -280,7 +280,7 @@ def main():
     # error is raised by the library, never silent)
     cap_frames = F if rank == 0 else max(n_mine, 1)
     max_ccs = cap_frames * 4096
-    max_words = cap_frames * (1 << 17)
+    max_words = cap_frames * max(1 << 17, (W * H) // 16)
 
     depth = max(1, a.depth) if world == 1 else 1
     prio = os.environ.get("LM_BENCH_PRIO", "front")

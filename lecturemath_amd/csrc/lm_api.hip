@@ -148,8 +148,10 @@ extern "C" LmCtx* lm_ctx_create(int width, int height, int max_batch)
     c->g.W = width;
     c->g.H = height;
     c->g.WW = (width + 63) / 64;
-    c->nbands = (height + LM_BAND_ROWS - 1) / LM_BAND_ROWS;
-    c->slot = ((LM_BAND_ROWS * ((width + 1) / 2)) + 63) & ~63;       // worst-case runs of one band, multiple of 64
+    c->band_rows = (c->g.WW > 32) ? 16 : LM_BAND_ROWS_MAX;
+    if (const char* e = getenv("LM_BAND_ROWS")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32) c->band_rows = v; }      // tuning experiments
+    c->nbands = (height + c->band_rows - 1) / c->band_rows;
+    c->slot = ((c->band_rows * ((width + 1) / 2)) + 63) & ~63;       // worst-case runs of one band, multiple of 64
     c->g.cap = c->nbands * c->slot;
     c->max_batch = max_batch;
     (void)hipGetDevice(&c->device);
@@ -257,7 +259,7 @@ extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, i
     if (lm_profile_mark(c, st, true, n_frames)) return LM_ERR_HIP;
     const int nbands = c->nbands, slot = c->slot;
     const int capw = g.cap / 64;
-    const size_t band_smem = (size_t)LM_BAND_ROWS * g.WW * 18 + LM_BAND_LDS * 4 + (65 + 64) * 4 + 64;
+    const size_t band_smem = (size_t)c->band_rows * g.WW * 18 + LM_BAND_LDS * 4 + (65 + 64) * 4 + 64;
 #if !LM_HIP_EMULATED
     static size_t band_smem_configured = 0;
     if (band_smem > band_smem_configured) {
@@ -267,9 +269,9 @@ extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, i
 #endif
     const unsigned long long magic_cpr = ((1ull << 40) / (unsigned)(g.WW * 4)) + 1, magic_ww = ((1ull << 40) / (unsigned)g.WW) + 1;
     hipLaunchKernelGGL(lm_k_band, dim3(nbands, n_frames), dim3(512), band_smem, st, d_binary, c->bits, c->starts, c->prefix, c->rowoff,
-                       c->band_runs, c->parent, c->band_fallback, g.W, g.H, g.WW, slot, g.cap, lm_debug_band_phases(), magic_cpr, magic_ww);
+                       c->band_runs, c->parent, c->band_fallback, g.W, g.H, g.WW, slot, g.cap, lm_debug_band_phases(), magic_cpr, magic_ww, c->band_rows);
     hipLaunchKernelGGL(lm_k_seam_union, dim3(nbands, n_frames), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff,
-                       c->band_fallback, c->parent, g.WW, g.H, g.cap);
+                       c->band_fallback, c->parent, g.WW, g.H, g.cap, c->band_rows);
     hipLaunchKernelGGL(lm_k_flatten_flag, dim3(nbands, n_frames), dim3(256), 0, st, c->parent, c->band_runs, c->rootbits, c->wordprefix,
                        c->band_roots, slot, g.cap, capw);
     hipLaunchKernelGGL(lm_k_apply_labels, dim3(nbands, n_frames), dim3(256), 0, st, c->parent, c->band_runs, c->rootbits, c->wordprefix,

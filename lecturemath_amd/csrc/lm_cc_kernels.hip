@@ -147,12 +147,16 @@ LM_DEV unsigned lm_nz_nibble(unsigned d)
 
 // ------------------------------------------------------------------------------------------------
 // K4: union-find over runs, two levels.
-//   K4a  lm_k_band: one workgroup per band of LM_BAND_ROWS rows packs the band, scans its rows and keeps the band's
+//   K4a  lm_k_band: one workgroup per band of LmCtx::band_rows rows packs the band, scans its rows and keeps the band's
 //        forest in LDS (ds atomics); the flattened band-local roots are written out as global parents.
 //   K4b  seam rows between bands: the few remaining contacts, with device-scope atomics in L2.
 // Root of a set = its smallest run id, so roots are the runs holding each component's first pixel.
 // ------------------------------------------------------------------------------------------------
-#define LM_BAND_ROWS 32
+// Rows per band (run time, LmCtx::band_rows): the band's bit rows, run starts and prefixes (18 B per 64-px word) and a forest of
+// LM_BAND_LDS runs live in LDS.  Two tunings: 32 rows up to 2048 px wide (1080p: WW = 30, 34 KB per workgroup, ~4 per CU);
+// 16 rows above (4K: WW = 60, 33 KB; with 32 rows a dense 4K band has more than LM_BAND_LDS runs and falls back to L2
+// unions: 617 vs 334 us per 16 dense 4K frames, profiles/r02_label_band_rows.txt).
+#define LM_BAND_ROWS_MAX 32
 #define LM_BAND_LDS 4096
 
 LM_DEV int lm_find(const int32_t* parent, int x)
@@ -214,16 +218,16 @@ __global__ void __launch_bounds__(512) lm_k_band(const uint8_t* __restrict__ img
                                                  uint16_t* __restrict__ prefix, uint32_t* __restrict__ rowoff,
                                                  int32_t* __restrict__ band_runs, int32_t* __restrict__ parent,
                                                  uint8_t* __restrict__ band_fallback, int W, int H, int WW, int slot, int cap, int phases,
-                                                 unsigned long long magic_cpr, unsigned long long magic_ww)
+                                                 unsigned long long magic_cpr, unsigned long long magic_ww, int brows)
 {
     LM_DYN_SMEM(smem);
     const int b = blockIdx.y, band = blockIdx.x, nbands = gridDim.x;
-    const int y0 = band * LM_BAND_ROWS;
-    const int nrows = (y0 + LM_BAND_ROWS < H) ? LM_BAND_ROWS : H - y0;
+    const int y0 = band * brows;
+    const int nrows = (y0 + brows < H) ? brows : H - y0;
     const long long row0 = (long long)b * H + y0;
     unsigned long long* s_bits = (unsigned long long*)smem;                   // [64][WW]
-    unsigned long long* s_starts = s_bits + LM_BAND_ROWS * WW;                // [64][WW]
-    int32_t* s_par = (int32_t*)(s_starts + LM_BAND_ROWS * WW);                // [LM_BAND_LDS]
+    unsigned long long* s_starts = s_bits + brows * WW;                // [64][WW]
+    int32_t* s_par = (int32_t*)(s_starts + brows * WW);                // [LM_BAND_LDS]
     unsigned* s_rowoff = (unsigned*)(s_par + LM_BAND_LDS);                    // [65]
     unsigned* s_rowcnt = s_rowoff + 65;                                       // [64]
     uint16_t* s_prefix = (uint16_t*)(s_rowcnt + 64);                          // [64][WW]
@@ -356,11 +360,11 @@ __global__ void __launch_bounds__(512) lm_k_band(const uint8_t* __restrict__ img
 __global__ void __launch_bounds__(256) lm_k_seam_union(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
                                                        const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
                                                        const uint8_t* __restrict__ band_fallback, int32_t* __restrict__ parent,
-                                                       int WW, int H, int cap)
+                                                       int WW, int H, int cap, int brows)
 {
     const int b = blockIdx.y, band = blockIdx.x;
-    const int y0 = band * LM_BAND_ROWS;
-    const int y1 = (y0 + LM_BAND_ROWS < H) ? y0 + LM_BAND_ROWS : H;
+    const int y0 = band * brows;
+    const int y1 = (y0 + brows < H) ? y0 + brows : H;
     const long long row0 = (long long)b * H + y0;
     int32_t* par = parent + (long long)b * cap;
     // contacts of the band's first row with the last row of the band above: enumerated into LDS first (bit tricks only),

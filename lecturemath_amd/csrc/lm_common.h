@@ -62,7 +62,8 @@ struct LmCtx {
     uint32_t* band_base;     // [B][nbands] labels (roots) in the bands above
     uint32_t* band_roots;    // [B][nbands] roots per band
     uint8_t* band_fallback;  // [B][nbands] 1 = forest too large for LDS, unions done in L2
-    int nbands, slot;        // bands of LM_BAND_ROWS rows; slot = id space per band (worst-case runs, multiple of 64)
+    int nbands, slot;        // bands of band_rows rows; slot = id space per band (worst-case runs, multiple of 64)
+    int band_rows;           // 32 up to 2048 px wide, 16 above (lm_cc_kernels.hip)
     int32_t* parent;         // [B][cap]
     int32_t* final_label;    // [B][cap]
     int32_t* n_labels;       // [B]

@@ -406,10 +406,11 @@ def check_overlap_golden(lib):
         assert np.float64(r).view(np.int64) == g["recall"][k].view(np.int64) and np.float64(p).view(np.int64) == g["precision"][k].view(np.int64), k
 
 
-def check_fcn_4k_resize_branch(lib):
+def check_fcn_4k_resize_branch(lib, shipped=False):
     """binarize() on a 3840x2160 frame (> 2.5 MP, FCN_lecturenet.py:435-437,481-494): PIL LANCZOS halving, FCN at 1080p,
-    NEAREST x2 back -- against the oracle's torch forward on the same halved image.  Tiny network (the branch is about
-    the resize plumbing); pixels whose logit is within the fp32 tolerance of the threshold edge are exempt."""
+    NEAREST x2 back -- against the oracle's torch forward on the same halved image.  Tiny network by default (the branch is
+    about the resize plumbing), the shipped widths with shipped=True; pixels whose logit is within the fp32 tolerance of the
+    threshold edge are exempt."""
     use_library(lib)
     import PIL.Image
     import torch
@@ -417,9 +418,11 @@ def check_fcn_4k_resize_branch(lib):
     from AccessMath.lecturenet_v1.FCN_lecturenet import FCN_LectureNet
     from lecturemath_amd import fcn, synth
     from oracle import fcn as ofcn
-    widths = (8,) * 18
-    sd = ofcn.random_state_dict(widths, pixel_kernel=3, seed=5)
-    conf = Configuration({key: "8" for key, _ in fcn.WIDTH_KEYS})
+    widths = ofcn.SHIPPED_WIDTHS if shipped else (8,) * 18
+    sd = ofcn.random_state_dict(widths, pixel_kernel=7 if shipped else 3, seed=5)
+    conf = Configuration({key: str(v) for (key, _), v in zip(fcn.WIDTH_KEYS, widths)})
+    if shipped:
+        conf.set("FCN_BINARIZER_NET_PIXEL_KERNEL_SIZE", "7")
     net = FCN_LectureNet.CreateFromConfig(conf, 3, False)
     net.load_state_dict(sd)
     rgb, _ = synth.whiteboard_rgb(2160, 3840, n_glyphs=3000, seed=9)

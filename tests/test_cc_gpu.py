@@ -115,6 +115,17 @@ def test_full_size_properties_4k(hip_lib):
     lab.close()
 
 
+def test_4k_stream_and_grouping_vs_oracle(hip_lib, oracle_built):
+    """BASELINE configs[4] size (3840x2160, WW = 60 words per row): a 24-frame stream through labelling, statistics, records,
+    crops and temporal matching vs the oracle, and step 03 (groups, ages, group images, every reconstructed frame) of its first
+    12 frames vs the oracle's grouping."""
+    frames = list(synth.binary_stream(24, 2160, 3840, seed=20215, glyphs_per_add=160, erase_every=9, jitter_p=0.2, max_ext=56))
+    r = lm_checks.check_stream_oracle(hip_lib, frames, max_gap=85, max_batch=8, max_ccs=1 << 18, max_crop_words=1 << 25)
+    assert len(r["unique_recs"]) > 1000
+    g = lm_checks.check_grouping_oracle(hip_lib, frames[:12], max_batch=6)
+    assert len(g["cc_groups"]) > 100
+
+
 def test_drop_in_cc_age_boundaries(hip_lib, oracle_built):
     rng = np.random.default_rng(3)
     img = ((rng.random((270, 480)) < 0.4) * 255).astype(np.uint8)

@@ -92,6 +92,13 @@ def test_dense_wide_noise_band_fallback(emu_lib, oracle_built):
     lm_checks.check_label_vs_oracle(emu_lib, img)
 
 
+def test_label_wide_frame_16_row_bands(emu_lib, oracle_built):
+    """Frames wider than 2048 px (4K: WW = 60 words) are labelled in 16-row bands (the LDS tuning for wide rows)."""
+    rng = np.random.default_rng(23)
+    img = ((rng.random((37, 2200)) < 0.35) * 255).astype(np.uint8)
+    lm_checks.check_label_vs_oracle(emu_lib, img)
+
+
 def test_grouping_crowded_tiles_vs_oracle(emu_lib, oracle_built):
     r = lm_checks.check_grouping_oracle(emu_lib, lm_checks.dot_grid_stream(n_frames=4, h=40, w=520))
     assert len(r["cc_groups"]) > 200

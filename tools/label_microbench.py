@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
-"""Times lm_label_batch alone (torch events on the launching stream) on bench-like frames.
-LM_DEBUG_BAND_PHASES=1|2 truncates lm_k_band to see where its time goes."""
-import os, sys, time
+"""Times lm_label_batch alone (torch events on the launching stream) on frames of the bench stream.
+    python tools/label_microbench.py [batch] [height width] [first_frame]
+first_frame picks the part of the stream (default: frames 5000.. of the 10,000-frame stream are dense; 192.. are the sparse
+start).  LM_LIB_PATH selects a variant build (tools/variants); LM_DEBUG_BAND_PHASES=2 leaves lm_k_band's unions to L2."""
+import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lecturemath_amd import _lib, device, synth
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-frames = np.stack(list(synth.binary_stream(256, 1080, 1920, seed=20213)))[-B:]     # late (dense) part of the stream
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+H, W = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1080, 1920)
+first = int(sys.argv[4]) if len(sys.argv) > 4 else 5000
+scale = 4 if H > 1080 else 1
+gen = synth.binary_stream(first + B, H, W, seed=20213, glyphs_per_add=40 * scale, max_ext=28 * (2 if scale > 1 else 1))
+frames = np.stack([f for i, f in enumerate(gen) if i >= first])
 d = torch.from_numpy(frames).cuda()
-lab = device.FrameLabeler(1920, 1080, B)
-labels = torch.empty((B, 1080, 1920), dtype=torch.int32, device="cuda")
-lib = lab.lib
+lib = _lib.load(os.environ.get("LM_LIB_PATH") or None)
+lab = device.FrameLabeler(W, H, B, lib)
+labels = torch.empty((B, H, W), dtype=torch.int32, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 for want in (labels, None):
     for _ in range(3):
@@ -23,5 +29,6 @@ for want in (labels, None):
         lib.check(lib.lm_label_batch(lab.ctx, d.data_ptr(), B, want.data_ptr() if want is not None else None, st))
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
-    print("phases=%s labels=%s B=%d: %.1f us/launch, %.2f us/frame, %.0f GB/s algorithmic" % (
-        os.environ.get("LM_DEBUG_BAND_PHASES", "3"), want is not None, B, ms * 1e3, ms * 1e3 / B, 5 * 1920 * 1080 * B / (ms * 1e-3) / 1e9))
+    print("%dx%d frames %d..%d lib=%s labels=%s B=%d: %.1f us/launch, %.2f us/frame, %.0f GB/s algorithmic = %.3f of 8 TB/s" % (
+        W, H, first, first + B, os.path.basename(os.environ.get("LM_LIB_PATH") or "default"), want is not None, B, ms * 1e3, ms * 1e3 / B,
+        5 * W * H * B / (ms * 1e-3) / 1e9, 5 * W * H * B / (ms * 1e-3) / 8e12))
