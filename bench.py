@@ -466,7 +466,8 @@ def main():
         ref = json.load(open(gpath)).get(str(F))
         if ref:
             keys = [k for k in dg[0] if k in ref]
-            parity["reference"] = "tests/golden/g9_stream1080p_digests.json[%d] (the reference run on the same stream in the build container)" % F
+            parity["reference"] = ("tests/golden/g9_stream1080p_digests.json[%d] (%s run on the same stream in the build container)"
+                                   % (F, "the oracle, itself pinned to the reference on the first 1,000 frames," if ref.get("produced_by") == "oracle" else "the reference"))
             parity["match"] = bool(all(dg[0][k] == ref[k] for k in keys) and ref["tempo_count"] == k1["tempo_count"] and ref["n_cc"] == k1["n_cc"])
             parity["compared"] = keys + ["tempo_count", "n_cc"]
     if parity["match"] is False or not parity["all_slots_identical"]:

@@ -128,7 +128,7 @@ extern "C" void lm_ctx_destroy(LmCtx* c)
 {
     if (!c) return;
     lm_profile_free(c);
-    void* ptrs[] = {c->bits, c->starts, c->prefix, c->rowoff, c->band_runs, c->band_base, c->band_roots, c->band_fallback, c->parent, c->final_label,
+    void* ptrs[] = {c->bits, c->starts, c->prefix, c->rowoff, c->rowcnt, c->band_runs, c->band_base, c->band_roots, c->band_fallback, c->parent, c->final_label,
                     c->n_labels, c->rootbits, c->wordprefix, c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x, c->st_count, c->kept_label,
                     c->kept_cropoff, c->frame_kept, c->frame_cropwords, c->stage_u8, c->stage_i32, c->stage_f32};
     for (void* p : ptrs)
@@ -161,6 +161,7 @@ extern "C" LmCtx* lm_ctx_create(int width, int height, int max_batch)
     rc |= lm_alloc(&c->starts, RW);
     rc |= lm_alloc(&c->prefix, RW);
     rc |= lm_alloc(&c->rowoff, R);
+    rc |= lm_alloc(&c->rowcnt, R);
     rc |= lm_alloc(&c->band_runs, (size_t)max_batch * c->nbands);
     rc |= lm_alloc(&c->band_base, (size_t)max_batch * c->nbands);
     rc |= lm_alloc(&c->band_roots, (size_t)max_batch * c->nbands);
@@ -267,9 +268,11 @@ extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, i
         band_smem_configured = band_smem;
     }
 #endif
-    const unsigned long long magic_cpr = ((1ull << 40) / (unsigned)(g.WW * 4)) + 1, magic_ww = ((1ull << 40) / (unsigned)g.WW) + 1;
-    hipLaunchKernelGGL(lm_k_band, dim3(nbands, n_frames), dim3(512), band_smem, st, d_binary, c->bits, c->starts, c->prefix, c->rowoff,
-                       c->band_runs, c->parent, c->band_fallback, g.W, g.H, g.WW, slot, g.cap, lm_debug_band_phases(), magic_cpr, magic_ww, c->band_rows);
+    const unsigned long long magic_ww = ((1ull << 40) / (unsigned)g.WW) + 1;
+    const long long R = (long long)n_frames * g.H;
+    hipLaunchKernelGGL(lm_k_pack_rows, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, d_binary, c->bits, c->starts, c->prefix, c->rowcnt, g.W, g.WW, R);
+    hipLaunchKernelGGL(lm_k_band, dim3(nbands, n_frames), dim3(512), band_smem, st, c->bits, c->starts, c->prefix, c->rowcnt, c->rowoff,
+                       c->band_runs, c->parent, c->band_fallback, g.H, g.WW, slot, g.cap, lm_debug_band_phases(), magic_ww, c->band_rows);
     hipLaunchKernelGGL(lm_k_seam_union, dim3(nbands, n_frames), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff,
                        c->band_fallback, c->parent, g.WW, g.H, g.cap, c->band_rows);
     hipLaunchKernelGGL(lm_k_flatten_flag, dim3(nbands, n_frames), dim3(256), 0, st, c->parent, c->band_runs, c->rootbits, c->wordprefix,

@@ -209,97 +209,102 @@ LM_DEV void lm_cell_contacts(const uint64_t* __restrict__ bits, const uint64_t* 
     }
 }
 
-// K4a, fused: uint8 rows of one band -> bit mask (1 B/px HBM read, the only pass over the image), run starts / prefix,
+// K1: uint8 rows -> bit mask (1 B/px HBM read, the only pass over the image), run starts, per-word run-start prefix and runs per
+// row.  One wave per row: a lane loads 16 pixels per 16-byte load (two loads in flight at 1080p), four lanes' 16-bit masks make
+// a 64-bit word, and the row's run structure follows from wave shuffles.  No LDS, no barriers: tens of thousands of
+// independent waves stream the image (the fused version -- pack inside the band kernel -- had every resident workgroup load
+// in step and then compute in step: 28 of its ~47 us per band were the load phase).
+__global__ void __launch_bounds__(256) lm_k_pack_rows(const uint8_t* __restrict__ img, uint64_t* __restrict__ bits, uint64_t* __restrict__ starts,
+                                                      uint16_t* __restrict__ prefix, uint32_t* __restrict__ rowcnt, int W, int WW, long long R)
+{
+    const int lane = lm_lane();
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const uint8_t* src = img + row * W;
+    const bool aligned = ((W & 15) == 0) && ((((uintptr_t)img) & 15) == 0);
+    const int nchunks = (W + 15) >> 4;                 // 16-px chunks of the row
+    unsigned running = 0;
+    unsigned long long carry = 0;
+    for (int w0 = 0; w0 < WW; w0 += 64) {              // 64 words = 4096 px per trip
+        // chunk c of this trip = w0 * 4 + k * 64 + lane, k = 0..3: four independent loads per lane
+        unsigned m16[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int c = w0 * 4 + k * 64 + lane;
+            unsigned m = 0;
+            if (c < nchunks) {
+                if (aligned) {
+                    const uint4 v = *(const uint4*)(src + (long long)c * 16);
+                    m = lm_nz_nibble(v.x) | (lm_nz_nibble(v.y) << 4) | (lm_nz_nibble(v.z) << 8) | (lm_nz_nibble(v.w) << 12);
+                } else {
+                    const int x = c * 16, lim = W - x < 16 ? W - x : 16;
+                    for (int i = 0; i < lim; i++) m |= (unsigned)(src[x + i] != 0) << i;
+                }
+            }
+            m16[k] = m;
+        }
+        // word w0 + lane = chunks 4 * lane .. 4 * lane + 3 of this trip: chunk q lives in register q >> 6 of lane q & 63
+        unsigned long long bw = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int q = 4 * lane + j;
+            unsigned v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned t = (unsigned)__shfl((int)m16[k], q & 63);
+                if ((q >> 6) == k) v = t;
+            }
+            bw |= (unsigned long long)v << (16 * j);
+        }
+        const int w = w0 + lane;
+        if (w >= WW) bw = 0;
+        unsigned long long prevtop = __shfl_up(bw >> 63, 1);
+        if (lane == 0) prevtop = carry;
+        const unsigned long long st = bw & ~((bw << 1) | prevtop);
+        const unsigned c = (unsigned)__popcll(st);
+        const unsigned incl = lm_wave_incl_scan(c);
+        if (w < WW) {
+            bits[row * WW + w] = bw;
+            starts[row * WW + w] = st;
+            prefix[row * WW + w] = (uint16_t)(running + incl - c);
+        }
+        carry = __shfl(bw >> 63, 63);
+        running += __shfl(incl, 63);
+    }
+    if (lane == 0) rowcnt[row] = running;
+}
+
+// K4a: one workgroup per band: the band's bit rows / run starts / prefixes (written by lm_k_pack_rows, L2-resident) go to LDS,
 // band-local run offsets, and the band's union-find forest in LDS.  Run ids are band-structured:
 //     gid = band * SLOT + (runs of the band before the run)          SLOT = worst-case runs of a band
 // which is still monotone in raster order, so no frame-wide scan is needed before the unions; `rowoff[row]` stores
 // band * SLOT + local offset, which is all the later kernels need.
-__global__ void __launch_bounds__(512) lm_k_band(const uint8_t* __restrict__ img, uint64_t* __restrict__ bits, uint64_t* __restrict__ starts,
-                                                 uint16_t* __restrict__ prefix, uint32_t* __restrict__ rowoff,
-                                                 int32_t* __restrict__ band_runs, int32_t* __restrict__ parent,
-                                                 uint8_t* __restrict__ band_fallback, int W, int H, int WW, int slot, int cap, int phases,
-                                                 unsigned long long magic_cpr, unsigned long long magic_ww, int brows)
+__global__ void __launch_bounds__(512) lm_k_band(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
+                                                 const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowcnt,
+                                                 uint32_t* __restrict__ rowoff, int32_t* __restrict__ band_runs, int32_t* __restrict__ parent,
+                                                 uint8_t* __restrict__ band_fallback, int H, int WW, int slot, int cap, int phases,
+                                                 unsigned long long magic_ww, int brows)
 {
     LM_DYN_SMEM(smem);
     const int b = blockIdx.y, band = blockIdx.x, nbands = gridDim.x;
     const int y0 = band * brows;
     const int nrows = (y0 + brows < H) ? brows : H - y0;
     const long long row0 = (long long)b * H + y0;
-    unsigned long long* s_bits = (unsigned long long*)smem;                   // [64][WW]
-    unsigned long long* s_starts = s_bits + brows * WW;                // [64][WW]
-    int32_t* s_par = (int32_t*)(s_starts + brows * WW);                // [LM_BAND_LDS]
+    unsigned long long* s_bits = (unsigned long long*)smem;                   // [brows][WW]
+    unsigned long long* s_starts = s_bits + brows * WW;                       // [brows][WW]
+    int32_t* s_par = (int32_t*)(s_starts + brows * WW);                       // [LM_BAND_LDS]
     unsigned* s_rowoff = (unsigned*)(s_par + LM_BAND_LDS);                    // [65]
     unsigned* s_rowcnt = s_rowoff + 65;                                       // [64]
-    uint16_t* s_prefix = (uint16_t*)(s_rowcnt + 64);                          // [64][WW]
+    uint16_t* s_prefix = (uint16_t*)(s_rowcnt + 64);                          // [brows][WW]
     const int lane = lm_lane(), wave = (int)(threadIdx.x >> 6);
-    // ---- 1. pack: one 16-B load per 16 pixels
+    // ---- 1. the band's rows (contiguous in the global tables) -> LDS
     {
-        const int cpr = WW * 4;
-        const bool rows_aligned = ((W & 15) == 0) && ((((uintptr_t)img) & 15) == 0);
-        uint16_t* s_bits16 = (uint16_t*)s_bits;
-        uint16_t* g_bits16 = (uint16_t*)bits;
-        const int total = nrows * cpr;
-        if (rows_aligned) {
-            // batches of 8 independent 16-B loads per thread keep enough bytes in flight at 1-2 blocks per CU
-            for (int c0 = threadIdx.x; c0 < total; c0 += (int)blockDim.x * 8) {
-                uint4 v[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int c = c0 + k * (int)blockDim.x;
-                    v[k] = make_uint4(0u, 0u, 0u, 0u);
-                    if (c < total) {
-                        const int r = (int)lm_fastdiv((unsigned)c, magic_cpr), ch = c - r * cpr;
-                        if (ch * 16 < W) v[k] = *(const uint4*)(img + (row0 + r) * W + ch * 16);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int c = c0 + k * (int)blockDim.x;
-                    if (c < total) {
-                        const int r = (int)lm_fastdiv((unsigned)c, magic_cpr), ch = c - r * cpr;
-                        const unsigned m = lm_nz_nibble(v[k].x) | (lm_nz_nibble(v[k].y) << 4) | (lm_nz_nibble(v[k].z) << 8) | (lm_nz_nibble(v[k].w) << 12);
-                        s_bits16[c] = (uint16_t)m;
-                        g_bits16[(row0 + r) * cpr + ch] = (uint16_t)m;
-                    }
-                }
-            }
-        } else {
-            for (int c = threadIdx.x; c < total; c += blockDim.x) {
-                const int r = c / cpr, ch = c - r * cpr, x = ch * 16;
-                unsigned m = 0;
-                if (x < W) {
-                    const uint8_t* p = img + (row0 + r) * W + x;
-                    int lim = W - x < 16 ? W - x : 16;
-                    for (int i = 0; i < lim; i++) m |= (unsigned)(p[i] != 0) << i;
-                }
-                s_bits16[c] = (uint16_t)m;
-                g_bits16[(row0 + r) * cpr + ch] = (uint16_t)m;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- 2. per row: run starts, exclusive prefix of run-start counts, runs per row (one wave per row)
-    for (int r = wave; r < nrows; r += (int)(blockDim.x >> 6)) {
-        unsigned running = 0;
-        unsigned long long carry = 0;
-        for (int w0 = 0; w0 < WW; w0 += 64) {
-            const int w = w0 + lane;
-            unsigned long long bw = (w < WW) ? s_bits[r * WW + w] : 0ull;
-            unsigned long long prevtop = __shfl_up(bw >> 63, 1);
-            if (lane == 0) prevtop = carry;
-            const unsigned long long st = bw & ~((bw << 1) | prevtop);
-            const unsigned c = (unsigned)__popcll(st);
-            const unsigned incl = lm_wave_incl_scan(c);
-            if (w < WW) {
-                s_starts[r * WW + w] = st;
-                s_prefix[r * WW + w] = (uint16_t)(running + incl - c);
-                starts[(row0 + r) * WW + w] = st;
-                prefix[(row0 + r) * WW + w] = (uint16_t)(running + incl - c);
-            }
-            carry = __shfl(bw >> 63, 63);
-            running += __shfl(incl, 63);
-        }
-        if (lane == 0) s_rowcnt[r] = running;
+        const int nw = nrows * WW;
+        const uint64_t* gb = bits + row0 * WW;
+        const uint64_t* gs = starts + row0 * WW;
+        const uint16_t* gp = prefix + row0 * WW;
+        for (int i = threadIdx.x; i < nw; i += blockDim.x) { s_bits[i] = gb[i]; s_starts[i] = gs[i]; s_prefix[i] = gp[i]; }
+        if ((int)threadIdx.x < nrows) s_rowcnt[threadIdx.x] = rowcnt[row0 + threadIdx.x];
     }
     __syncthreads();
     // ---- 3. band-local row offsets

@@ -58,6 +58,7 @@ struct LmCtx {
     uint64_t* starts;
     uint16_t* prefix;
     uint32_t* rowoff;        // [R] band * slot + runs of the band above the row
+    uint32_t* rowcnt;        // [R] runs of the row (lm_k_pack_rows -> lm_k_band)
     int32_t* band_runs;      // [B][nbands] runs per band
     uint32_t* band_base;     // [B][nbands] labels (roots) in the bands above
     uint32_t* band_roots;    // [B][nbands] roots per band
