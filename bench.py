@@ -301,30 +301,53 @@ def main():
     labels = None if a.no_labels else torch.empty((B, H, W), dtype=torch.int32, device="cuda")
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, depth))
 
+    gated = os.environ.get("LM_BENCH_SCHEDULE", "gated") == "gated"
+
     def front(sl, match=True, use_split=split):
-        """steps 01 (threshold) + 02 (label, records; matching when `match`) of this rank's block of the stream"""
+        """steps 01 (threshold) + 02 (label, records; matching when `match`) of this rank's block of the stream.
+        Schedule ("gated", default): the labelling launches -- the bandwidth-bound kernels the roofline is quoted on -- never share
+        the GPU with the temporal matching (dozens of small latency-bound kernels): matching of batch k-1 starts when batch k has
+        been labelled and runs under batch k's statistics / record emission and batch k+1's threshold; batch k+1 is labelled when
+        it has finished.  Uncontrolled overlap (LM_BENCH_SCHEDULE=free) stretches both."""
         fs = sl["fs"]
+        ctx = fs.labeler.ctx
         with torch.cuda.stream(s_wide):
-            ws = s_wide.cuda_stream
+            ws, ms = s_wide.cuda_stream, sl["s_match"].cuda_stream
             if sl["gr"] is not None:                # the previous step of this slot: its rendering must be done before
                 sl["rdone"].synchronize()           # its tables go away and its buffers are reused
                 sl["gr"].close()
                 sl["gr"] = None
             fs.reset()
-            for k, f0 in enumerate(range(0, n_mine, B)):
-                n = min(B, n_mine - f0)
+            batches = [(f0, min(B, n_mine - f0)) for f0 in range(0, n_mine, B)]
+            ev = sl["recorded"]
+            while len(ev) < 3 * len(batches):
+                ev.append(torch.cuda.Event())
+            lp = labels.data_ptr() if labels is not None else None
+            for k, (f0, n) in enumerate(batches):
+                evL, evR, evM = ev[3 * k], ev[3 * k + 1], ev[3 * k + 2]
                 lib.check(lib.lm_threshold_invert(logits[f0:f0 + n].data_ptr(), binary.data_ptr(), n * H * W, 128, ws))
-                lp = labels.data_ptr() if labels is not None else None
                 if match and not use_split:
                     lib.check(lib.lm_stream_push(fs.handle, binary.data_ptr(), n, lp, ws))
                     continue
-                lib.check(lib.lm_stream_push_records(fs.handle, binary.data_ptr(), n, lp, ws))
-                if match:
-                    while len(sl["recorded"]) <= k:
-                        sl["recorded"].append(torch.cuda.Event())
-                    sl["recorded"][k].record(s_wide)
-                    sl["s_match"].wait_event(sl["recorded"][k])
-                    lib.check(lib.lm_stream_match(fs.handle, n, sl["s_match"].cuda_stream))
+                if match and gated and k >= 2:
+                    s_wide.wait_event(ev[3 * (k - 2) + 2])          # matching of batch k-2 has left the GPU
+                lib.check(lib.lm_label_batch(ctx, binary.data_ptr(), n, lp, ws))
+                evL.record(s_wide)
+                lib.check(lib.lm_stream_push_labelled(fs.handle, n, ws))
+                evR.record(s_wide)
+                if not match:
+                    continue
+                if gated:
+                    if k >= 1:                                      # matching of batch k-1 under batch k's records
+                        sl["s_match"].wait_event(evL)
+                        lib.check(lib.lm_stream_match(fs.handle, batches[k - 1][1], ms))
+                        ev[3 * (k - 1) + 2].record(sl["s_match"])
+                else:
+                    sl["s_match"].wait_event(evR)
+                    lib.check(lib.lm_stream_match(fs.handle, n, ms))
+            if match and use_split and gated and batches:
+                sl["s_match"].wait_event(ev[3 * (len(batches) - 1) + 1])
+                lib.check(lib.lm_stream_match(fs.handle, batches[-1][1], ms))
             if match and use_split:
                 sl["done"].record(sl["s_match"])
             else:
@@ -534,7 +557,8 @@ def main():
                    "stages_not_in_timed_region": ["fcn conv stack (logits are synthetic, SURVEY 8(d) config 3; measured separately in `fcn` / `e2e_rgb`)"],
                    "stream": dict({k: k1[k] for k in ("n_cc", "n_unique", "tempo_count")}, n_groups=int(ginfo[2]), n_split=int(ginfo[0])),
                    "parallelism": "one stream on one GPU" if world == 1 else "frame-range shards of one stream, gather to rank 0",
-                   "pipeline_depth": depth, "matching_on_own_hip_stream": bool(split)},
+                   "pipeline_depth": depth, "matching_on_own_hip_stream": bool(split),
+                   "schedule": "gated: labelling launches do not overlap the matching kernels" if gated else "free"},
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "gen_seconds": round(gen_s, 2),
     }
     if world == 1 and a.fcn_frames > 0:

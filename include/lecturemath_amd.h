@@ -111,6 +111,9 @@ int lm_stream_push(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* 
  * the next n_frames unmatched frames (the rank that owns the whole stream, after lm_stream_import of the gathered records). */
 int lm_stream_push_records(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* d_labels, void* stream);
 int lm_stream_match(LmStream* s, int n_frames, void* stream);
+/* lm_stream_push_records in two calls, for callers that schedule the bandwidth-bound labelling apart from the rest:
+ * lm_label_batch(ctx of the stream, ...) labels n_frames frames, lm_stream_push_labelled appends their records + crops. */
+int lm_stream_push_labelled(LmStream* s, int n_frames, void* stream);
 
 /* Frame-range sharding across the GPUs of a node: the CC records + crops of frames
  * [first_frame, first_frame + n_frames) of a stream as ONE flat DEVICE buffer (32-byte aligned), so that the gather to the rank

@@ -271,7 +271,8 @@ extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, i
     const unsigned long long magic_ww = ((1ull << 40) / (unsigned)g.WW) + 1;
     const long long R = (long long)n_frames * g.H;
     hipLaunchKernelGGL(lm_k_pack_rows, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, d_binary, c->bits, c->starts, c->prefix, c->rowcnt, g.W, g.WW, R);
-    hipLaunchKernelGGL(lm_k_band, dim3(nbands, n_frames), dim3(512), band_smem, st, c->bits, c->starts, c->prefix, c->rowcnt, c->rowoff,
+    static const int band_threads = [] { const char* e = getenv("LM_BAND_THREADS"); const int v = e ? atoi(e) : 512; return (v == 128 || v == 256 || v == 512) ? v : 512; }();
+    hipLaunchKernelGGL(lm_k_band, dim3(nbands, n_frames), dim3(band_threads), band_smem, st, c->bits, c->starts, c->prefix, c->rowcnt, c->rowoff,
                        c->band_runs, c->parent, c->band_fallback, g.H, g.WW, slot, g.cap, lm_debug_band_phases(), magic_ww, c->band_rows);
     hipLaunchKernelGGL(lm_k_seam_union, dim3(nbands, n_frames), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff,
                        c->band_fallback, c->parent, g.WW, g.H, g.cap, c->band_rows);
@@ -609,6 +610,45 @@ static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st)
     }
 }
 
+// statistics, kept-CC selection, record + crop emission for the B frames last labelled in the stream's context
+static int lm_stream_emit_batch(LmStream* s, int B, void* stream)
+{
+    LmCtx* c = s->ctx;
+    const LmGeom g = c->g;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = lm_cc_stats_batch(c, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lm_k_select, dim3(B), dim3(1024), 0, st, c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x,
+                       c->st_count, c->n_labels, c->kept_label, c->kept_cropoff, c->frame_kept, c->frame_cropwords, g.cap,
+                       s->min_pixels);
+    hipLaunchKernelGGL(lm_k_batch_offsets, dim3(1), dim3(1024), 0, st, c->frame_kept, c->frame_cropwords, B, s->counters,
+                       s->frame_cc_off, s->batch_cc_base, s->batch_word_base, s->cap_cc, s->cap_words, s->cap_frames);
+    hipLaunchKernelGGL(lm_k_emit, dim3(LM_HIP_EMULATED ? 2 : 320, B), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff, c->final_label,
+                       c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x, c->st_count, c->kept_label, c->kept_cropoff,
+                       c->frame_kept, c->frame_cropwords, s->batch_cc_base, s->batch_word_base, s->cc, s->crop, s->chash, s->frames_pushed, g.WW,
+                       g.H, g.cap);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+// The second half of lm_stream_push_records for callers that label a batch themselves (lm_label_batch on the stream's context)
+// and want to schedule the two halves separately.
+extern "C" int lm_stream_push_labelled(LmStream* s, int n_frames, void* stream)
+{
+    if (!s || n_frames <= 0 || n_frames != s->ctx->last_batch) {
+        lm_set_error("lm_stream_push_labelled: %d frames, the context's last labelled batch has %d", n_frames, s ? s->ctx->last_batch : 0);
+        return LM_ERR_ARG;
+    }
+    if (s->frames_pushed + n_frames > s->cap_frames) {
+        lm_set_error("lm_stream_push_labelled: stream holds %d frames, capacity %d", s->frames_pushed, s->cap_frames);
+        return LM_ERR_CAPACITY;
+    }
+    const int rc = lm_stream_emit_batch(s, n_frames, stream);
+    if (rc) return rc;
+    s->frames_pushed += n_frames;
+    return LM_OK;
+}
+
 static int lm_stream_push_impl(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* d_labels, int do_match, void* stream)
 {
     if (!s || !d_binary || n_frames <= 0) { lm_set_error("lm_stream_push: bad arguments"); return LM_ERR_ARG; }
@@ -628,17 +668,8 @@ static int lm_stream_push_impl(LmStream* s, const uint8_t* d_binary, int n_frame
         const int B = (n_frames - done < c->max_batch) ? n_frames - done : c->max_batch;
         int rc = lm_label_batch(c, d_binary + (size_t)done * px, B, d_labels ? d_labels + (size_t)done * px : nullptr, stream);
         if (rc) return rc;
-        rc = lm_cc_stats_batch(c, stream);
+        rc = lm_stream_emit_batch(s, B, stream);
         if (rc) return rc;
-        hipLaunchKernelGGL(lm_k_select, dim3(B), dim3(1024), 0, st, c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x,
-                           c->st_count, c->n_labels, c->kept_label, c->kept_cropoff, c->frame_kept, c->frame_cropwords, g.cap,
-                           s->min_pixels);
-        hipLaunchKernelGGL(lm_k_batch_offsets, dim3(1), dim3(1024), 0, st, c->frame_kept, c->frame_cropwords, B, s->counters,
-                           s->frame_cc_off, s->batch_cc_base, s->batch_word_base, s->cap_cc, s->cap_words, s->cap_frames);
-        hipLaunchKernelGGL(lm_k_emit, dim3(LM_HIP_EMULATED ? 2 : 320, B), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff, c->final_label,
-                           c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x, c->st_count, c->kept_label, c->kept_cropoff,
-                           c->frame_kept, c->frame_cropwords, s->batch_cc_base, s->batch_word_base, s->cc, s->crop, s->chash, s->frames_pushed, g.WW,
-                           g.H, g.cap);
         if (do_match) {
             lm_launch_match_frames(s, s->frames_pushed, B, st);
             s->frames_matched += B;
