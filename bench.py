@@ -301,11 +301,11 @@ def main():
     labels = None if a.no_labels else torch.empty((B, H, W), dtype=torch.int32, device="cuda")
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, depth))
 
-    gated = os.environ.get("LM_BENCH_SCHEDULE", "gated") == "gated"
+    gated = os.environ.get("LM_BENCH_SCHEDULE", "free") == "gated"
 
     def front(sl, match=True, use_split=split):
         """steps 01 (threshold) + 02 (label, records; matching when `match`) of this rank's block of the stream.
-        Schedule ("gated", default): the labelling launches -- the bandwidth-bound kernels the roofline is quoted on -- never share
+        Schedule: "free" (default) hands the whole loop to lm_stream_run_logits.  LM_BENCH_SCHEDULE=gated: the labelling launches -- the bandwidth-bound kernels the roofline is quoted on -- never share
         the GPU with the temporal matching (dozens of small latency-bound kernels): matching of batch k-1 starts when batch k has
         been labelled and runs under batch k's statistics / record emission and batch k+1's threshold; batch k+1 is labelled when
         it has finished.  Uncontrolled overlap (LM_BENCH_SCHEDULE=free) stretches both."""
@@ -318,11 +318,19 @@ def main():
                 sl["gr"].close()
                 sl["gr"] = None
             fs.reset()
+            lp = labels.data_ptr() if labels is not None else None
+            if not gated:
+                # the whole launch loop in one library call (per batch: threshold -> label -> records on the wide stream, matching
+                # on the slot's own stream behind an event): ~5,000 launches that a Python loop issued at half the GPU's pace
+                two = match and use_split
+                lib.check(lib.lm_stream_run_logits(fs.handle, logits.data_ptr(), n_mine, B, binary.data_ptr(), lp, 128, 1 if match else 0, ws,
+                                                   ms if two else ws))
+                sl["done"].record(sl["s_match"] if two else s_wide)
+                return
             batches = [(f0, min(B, n_mine - f0)) for f0 in range(0, n_mine, B)]
             ev = sl["recorded"]
             while len(ev) < 3 * len(batches):
                 ev.append(torch.cuda.Event())
-            lp = labels.data_ptr() if labels is not None else None
             for k, (f0, n) in enumerate(batches):
                 evL, evR, evM = ev[3 * k], ev[3 * k + 1], ev[3 * k + 2]
                 lib.check(lib.lm_threshold_invert(logits[f0:f0 + n].data_ptr(), binary.data_ptr(), n * H * W, 128, ws))

@@ -442,6 +442,8 @@ extern "C" void lm_stream_destroy(LmStream* s)
             if (p) (void)hipFree(p);
         delete m;
     }
+    for (int i = 0; i < s->n_run_events; i++) (void)hipEventDestroy(s->run_events[i]);
+    free(s->run_events);
     if (s->rd_scratch) (void)hipFree(s->rd_scratch);
     if (s->garena) (void)hipFree(s->garena);
     delete s;
@@ -689,6 +691,49 @@ extern "C" int lm_stream_push(LmStream* s, const uint8_t* d_binary, int n_frames
 extern "C" int lm_stream_push_records(LmStream* s, const uint8_t* d_binary, int n_frames, int32_t* d_labels, void* stream)
 {
     return lm_stream_push_impl(s, d_binary, n_frames, d_labels, 0, stream);
+}
+
+// Steps 01-02 of a whole resident stream in one call: per batch threshold+invert -> label -> records on `stream_wide`, temporal
+// matching on `stream_match` behind an event per batch (the two must be different streams for the phases to overlap).  The
+// launch loop runs here instead of in the caller's interpreter: a 10,000-frame stream is ~5,000 kernel launches, and a Python
+// loop around them (plus a second Python thread driving step 03 of the previous stream) was the bottleneck of the pipeline.
+// d_binary: scratch for `batch` frames; d_labels: label image of one batch, or NULL.  Asynchronous: when the call returns
+// everything is enqueued; the work of the stream is complete when `stream_match` has drained.
+extern "C" int lm_stream_run_logits(LmStream* s, const float* d_logits, int n_frames, int batch, uint8_t* d_binary, int32_t* d_labels, int thr,
+                                    int do_match, void* stream_wide, void* stream_match)
+{
+    if (!s || !d_logits || !d_binary || n_frames < 0 || batch <= 0 || batch > s->ctx->max_batch) {
+        lm_set_error("lm_stream_run_logits: bad arguments (batch %d, context batch %d)", batch, s ? s->ctx->max_batch : 0);
+        return LM_ERR_ARG;
+    }
+    hipStream_t sw = (hipStream_t)stream_wide, sm = (hipStream_t)stream_match;
+    const bool two = do_match && sm != sw;
+    const size_t px = (size_t)s->ctx->g.W * s->ctx->g.H;
+    int k = 0;
+    for (int f0 = 0; f0 < n_frames; f0 += batch, k++) {
+        const int n = (n_frames - f0 < batch) ? n_frames - f0 : batch;
+        int rc = lm_threshold(d_logits + (size_t)f0 * px, d_binary, (int64_t)n * (int64_t)px, thr, 1, stream_wide);
+        if (rc) return rc;
+        rc = lm_label_batch(s->ctx, d_binary, n, d_labels, stream_wide);
+        if (rc) return rc;
+        rc = lm_stream_push_labelled(s, n, stream_wide);
+        if (rc) return rc;
+        if (!do_match) continue;
+        if (two) {
+            if (k >= s->n_run_events) {
+                const int want = k + 64;
+                hipEvent_t* ev = (hipEvent_t*)realloc(s->run_events, (size_t)want * sizeof(hipEvent_t));
+                if (!ev) { lm_set_error("lm_stream_run_logits: out of memory"); return LM_ERR_HIP; }
+                s->run_events = ev;
+                for (; s->n_run_events < want; s->n_run_events++) LM_HIP(hipEventCreateWithFlags(&s->run_events[s->n_run_events], hipEventDisableTiming));
+            }
+            LM_HIP(hipEventRecord(s->run_events[k], sw));
+            LM_HIP(hipStreamWaitEvent(sm, s->run_events[k], 0));
+        }
+        rc = lm_stream_match(s, n, two ? stream_match : stream_wide);
+        if (rc) return rc;
+    }
+    return LM_OK;
 }
 
 extern "C" int lm_stream_match(LmStream* s, int n_frames, void* stream)

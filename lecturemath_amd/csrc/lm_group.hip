@@ -1011,19 +1011,21 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
     LM_HIP(hipMemcpyAsync(h_foff, s->frame_cc_off, ((size_t)F + 1) * sizeof(long long), hipMemcpyDeviceToHost, st));
     LM_HIP(hipStreamSynchronize(st));
     tm.mark("counters + assignments D2H");
-    std::vector<int32_t> cc_frame(ncc1);
-    for (int f = 0; f < F; f++)
-        for (long long c = h_foff[f]; c < h_foff[f + 1]; c++) cc_frame[(size_t)c] = f;
     const int32_t* cc_assign = h_assign;
 
     // ---- per-unique entry lists (CC order == ascending frame, the reference's append order)
     std::vector<int64_t> cnt((size_t)nU0 + 1, 0);
     for (long long c = 0; c < n_cc; c++) cnt[(size_t)cc_assign[(size_t)c] + 1]++;
     for (int u = 0; u < nU0; u++) cnt[(size_t)u + 1] += cnt[u];
-    std::vector<int32_t> lst(ncc1);
+    std::vector<int32_t> lst(ncc1), lst_frame(ncc1);       // entries of all uniques back to back, and their frames
     {
         std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
-        for (long long c = 0; c < n_cc; c++) lst[(size_t)pos[cc_assign[(size_t)c]]++] = (int32_t)c;
+        for (int f = 0; f < F; f++)
+            for (long long c = h_foff[f]; c < h_foff[f + 1]; c++) {
+                const int64_t p = pos[cc_assign[(size_t)c]]++;
+                lst[(size_t)p] = (int32_t)c;
+                lst_frame[(size_t)p] = f;
+            }
     }
     tm.mark("entry lists");
     // ---- split_stable_cc_by_gaps (:181-228)
@@ -1042,7 +1044,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
             const int64_t n_local = e - b;
             cuts.clear();
             for (int64_t i = b + 1; i < e; i++)
-                if (cc_frame[(size_t)lst[(size_t)i]] - cc_frame[(size_t)lst[(size_t)i - 1]] > g->max_gap) cuts.push_back(i);
+                if (lst_frame[(size_t)i] - lst_frame[(size_t)i - 1] > g->max_gap) cuts.push_back(i);
             if (cuts.empty() || n_local < g->min_times) continue;
             seg[u].second = cuts[0];
             for (size_t ci = 0; ci < cuts.size(); ci++) {
@@ -1057,19 +1059,29 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
     }
     const int nU = (int)seg.size();
     g->ulist_off.assign((size_t)nU + 1, 0);
-    g->ulist_cc.resize((size_t)n_cc);
-    {
+    std::vector<int32_t> ulist_frame;
+    if (g->n_split == 0) {          // the usual case: the entry lists are the CSR
+        g->ulist_cc.swap(lst);
+        g->ulist_cc.resize((size_t)n_cc);
+        ulist_frame.swap(lst_frame);
+        ulist_frame.resize((size_t)n_cc);
+        for (int u = 0; u < nU; u++) g->ulist_off[(size_t)u + 1] = cnt[(size_t)u + 1];
+    } else {
+        g->ulist_cc.resize((size_t)n_cc);
+        ulist_frame.resize((size_t)n_cc);
         size_t w = 0;
         for (int u = 0; u < nU; u++) {
             const size_t len = (size_t)(seg[u].second - seg[u].first);
-            if (len) memcpy(g->ulist_cc.data() + w, lst.data() + seg[u].first, len * sizeof(int32_t));
+            if (len) {
+                memcpy(g->ulist_cc.data() + w, lst.data() + seg[u].first, len * sizeof(int32_t));
+                memcpy(ulist_frame.data() + w, lst_frame.data() + seg[u].first, len * sizeof(int32_t));
+            }
             w += len;
             g->ulist_off[(size_t)u + 1] = (int64_t)w;
         }
         g->ulist_cc.resize(w);
+        ulist_frame.resize(w);
     }
-    std::vector<int32_t> ulist_frame(g->ulist_cc.size());
-    for (size_t e = 0; e < g->ulist_cc.size(); e++) ulist_frame[e] = cc_frame[(size_t)g->ulist_cc[e]];
     auto first_frame = [&](int u) { return ulist_frame[(size_t)g->ulist_off[u]]; };
     auto last_frame = [&](int u) { return ulist_frame[(size_t)g->ulist_off[(size_t)u + 1] - 1]; };
     tm.mark("split + CSR");
@@ -1184,30 +1196,43 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         tm.mark("neighbour lists: fill + strong edges D2H");
         if (tm.on) fprintf(stderr, "[lm_group]   stable %d adjacency %lld aov %lld tov %lld strong %lld\n", nS, ne, g->n_aov, g->n_tov, n_str);
 
-        // ---- compute_groups (:308-413): sequential, order-dependent; works on stable indices
-        std::vector<std::vector<int32_t>> groups;
-        std::vector<int32_t> sg((size_t)nS, -1);
+        // ---- compute_groups (:308-413): sequential, order-dependent; works on stable indices.  A group is a singly linked list
+        // of its members in the order the reference's list holds them (appends and whole-list concatenations only), so a merge
+        // splices in O(1); group numbers are handed out in creation order.
+        std::vector<int32_t> sg((size_t)nS, -1), next_m((size_t)nS, -1), head, tail, alias;
+        head.reserve((size_t)nS); tail.reserve((size_t)nS); alias.reserve((size_t)nS);
+        // an absorbed group forwards to the group that absorbed it (path halving), so a merge does not walk its members:
+        // the reference re-points every member (:376-383), which is quadratic when a long-lived group is absorbed again and again
+        auto group_of = [&](int x) {
+            int k = sg[x];
+            while (alias[k] != k) { alias[k] = alias[alias[k]]; k = alias[k]; }
+            return k;
+        };
         for (int a = 0; a < nS; a++) {
             int gi;
-            if (sg[a] >= 0) gi = sg[a];
-            else { gi = (int)groups.size(); groups.push_back({a}); sg[a] = gi; }
+            if (sg[a] < 0) { gi = (int)head.size(); head.push_back(a); tail.push_back(a); alias.push_back(gi); sg[a] = gi; }
+            else gi = group_of(a);
             for (unsigned e = str_off[a]; e < str_off[(size_t)a + 1]; e++) {
                 const int b = str_j[e];
-                if (sg[b] < 0) { sg[b] = gi; groups[gi].push_back(b); }
-                else if (sg[b] != gi) {
-                    const int og = sg[b];
-                    for (int m : groups[og]) { sg[m] = gi; groups[gi].push_back(m); }
-                    groups[og].clear();
+                if (sg[b] < 0) {
+                    sg[b] = gi; next_m[tail[gi]] = b; tail[gi] = b;
+                } else {
+                    const int og = group_of(b);
+                    if (og == gi) continue;
+                    next_m[tail[gi]] = head[og]; tail[gi] = tail[og];
+                    head[og] = -1;                      // the absorbed group stays behind, empty (:399-411 drops it)
+                    alias[og] = gi;
                 }
             }
         }
         g->grp_off.assign(1, 0);
         g->grp_members.clear();
+        g->grp_members.reserve((size_t)nS);
         g->gid_of_unique.assign((size_t)nU, -1);
-        for (auto& grp : groups) {
-            if (grp.empty()) continue;
+        for (size_t k = 0; k < head.size(); k++) {
+            if (head[k] < 0) continue;
             const int ng = (int)g->grp_off.size() - 1;
-            for (int m : grp) { g->grp_members.push_back(g->stable[m]); g->gid_of_unique[g->stable[m]] = ng; }
+            for (int m = head[k]; m >= 0; m = next_m[m]) { g->grp_members.push_back(g->stable[m]); g->gid_of_unique[g->stable[m]] = ng; }
             g->grp_off.push_back((int64_t)g->grp_members.size());
         }
     } else {

@@ -61,6 +61,8 @@ struct LmStream {
     struct LmMatchBatch* mb;    // tables of the batched matcher (lm_match_batch.hip); host struct holding device pointers
     int last_match_frames;      // frames in the last batch handed to the batched matcher (lm_stream_match_stats)
     int match_per_frame;        // 1: one lm_k_match + lm_k_update per frame (LM_MATCH_PER_FRAME=1), 0: batched matcher
+    hipEvent_t* run_events;     // lm_stream_run_logits: one event per batch (records -> matching), grown on demand
+    int n_run_events;
     int frames_pushed;          // host-side mirrors (frames are pushed and matched in order)
     int frames_matched;
 };

@@ -303,7 +303,7 @@ def check_fcn_class(lib, name="k7_70x94"):
     assert ((dec == 255 - g["binary"]) | edge).all()
 
 
-def check_step01_entry_points(lib, tmp_dir, name="k7_70x94", n_frames=3):
+def check_step01_entry_points(lib, tmp_dir, name="k7_70x94", n_frames=3, tool=True):
     """The step-01 script's callbacks as the harness calls them (pre_ST3D_v3.0_01_binarize.py:20-55: get_worker builds the
     network from the configuration and a state_dict written with torch.save, the sampler feeds worker.handleFrame, get_results
     hands back (frame_times, frame_indices, compressed_frames)) and the one-image tool test_FCN_binarizer.py (:13-59) through
@@ -348,6 +348,8 @@ def check_step01_entry_points(lib, tmp_dir, name="k7_70x94", n_frames=3):
     assert len(compressed) == n_frames and not hasattr(worker, "lecture_net")
     for c in compressed:
         assert ((png.decode_gray8(c) == 255 - g["binary"]) | edge).all()
+    if not tool:
+        return
     # ---- test_FCN_binarizer.py
     PIL.Image.fromarray(g["rgb"]).save(os.path.join(tmp_dir, "in.png"))
     tool = script("test_FCN_binarizer.py")

@@ -6,7 +6,7 @@ import os
 
 import numpy as np
 
-from lecturemath_amd import device, synth
+from lecturemath_amd import _lib, device, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -83,6 +83,33 @@ def run_stream(lib, frames, w, h, max_gap, max_batch=7, split=None, records_then
         return fs.result()
     finally:
         fs.close()
+
+
+def check_stream_run_logits(lib, n_frames=23, h=96, w=160, batch=5):
+    """lm_stream_run_logits (the whole steps 01-02 loop in one call, logits in, matched stream out) == threshold_invert + push
+    batch by batch, with and without a separate matching stream argument; and the oracle."""
+    frames = np.stack(list(synth.binary_stream(n_frames, h, w, seed=8, glyphs_per_add=4, erase_every=8, jitter_p=0.4, occluder=True, max_ext=16)))
+    logits = synth.logits_from_binary(frames, seed=2)
+    ref = run_stream(lib, frames, w, h, 5, max_batch=batch)
+    fs = device.FrameStream(w, h, n_frames, 0.85, 0.85, 5, 20, max_batch=batch, lib=lib)
+    try:
+        be = fs.be
+        d_logits = be.from_host(logits)
+        scratch = be.empty((batch, h, w), np.uint8)
+        labels = be.empty((batch, h, w), np.int32)
+        st = be.stream()
+        lib.check(lib.lm_stream_run_logits(fs.handle, _lib.ptr(d_logits), n_frames, batch, _lib.ptr(scratch), _lib.ptr(labels), 128, 1, st, st))
+        got = fs.result()
+    finally:
+        fs.close()
+    for key in ("unique_cc_frames", "cc_idx_per_frame", "tempo_count"):
+        assert got[key] == ref[key], key
+    assert list(got["active"]) == list(ref["active"]) and (got["unique_recs"] == ref["unique_recs"]).all()
+    from oracle import cc as occ
+    o = occ.Stability(w, h, 0.85, 0.85, 5)
+    for f in frames:
+        o.add_frame(f)
+    state_equal_oracle(got, o.result())
 
 
 def check_stream_golden(lib, name, max_batch=7):

@@ -32,6 +32,10 @@ def test_stream_golden(hip_lib, name):
     lm_checks.check_stream_golden(hip_lib, name, max_batch=16)
 
 
+def test_stream_run_logits(hip_lib, oracle_built):
+    lm_checks.check_stream_run_logits(hip_lib)
+
+
 def test_stream_match_paths_agree(hip_lib, oracle_built):
     lm_checks.check_stream_match_paths(hip_lib, n_frames=150)
     lm_checks.check_stream_match_paths(hip_lib, n_frames=97, max_gap=1, seed=4)

@@ -120,7 +120,7 @@ def test_pipeline_short_gap(emu_lib):
 
 def test_step01_entry_points(emu_lib, tmp_path):
     """pre_ST3D_v3.0_01_binarize.py get_worker / get_results with a torch.save'd state_dict, and test_FCN_binarizer.py main()."""
-    dropin_checks.check_step01_entry_points(emu_lib, tmp_path, n_frames=1)
+    dropin_checks.check_step01_entry_points(emu_lib, tmp_path, n_frames=1, tool=False)     # the one-image tool: GPU suite
 
 
 def test_rebuilt_binary_images(emu_lib, oracle_built):

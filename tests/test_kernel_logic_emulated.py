@@ -36,6 +36,10 @@ def test_stream_vs_oracle_small(emu_lib, oracle_built):
     assert len(r["unique_recs"]) > 20
 
 
+def test_stream_run_logits(emu_lib, oracle_built):
+    lm_checks.check_stream_run_logits(emu_lib)
+
+
 def test_stream_match_paths_agree(emu_lib, oracle_built):
     lm_checks.check_stream_match_paths(emu_lib, n_frames=72)
 
@@ -131,25 +135,42 @@ def test_fcn_golden_tiny(emu_lib, precision):
     assert lm_checks.check_fcn_golden(emu_lib, "k7_70x94", precision=precision) < 1e-4
 
 
-def test_emulated_library_under_asan_ubsan(oracle_built):
+def test_emulated_library_under_asan_ubsan(oracle_built, tmp_path):
     """The product's HIP sources built for the CPU with -fsanitize=address,undefined (tests/hipemu `make asan`) and run in a
-    child interpreter with the ASan runtime preloaded: the FCN forward pass (f16x3; every dynamic-LDS kernel of lm_fcn.hip),
-    a stream with large components and step 03.  The emulator allocates the dynamic LDS of every launch at exactly the size
-    the launch asked for and fills it with NaN patterns before every block, so an LDS index past a kernel's allocation aborts
-    the child and LDS that is consumed without having been written poisons the compared results."""
+    child interpreter with the ASan runtime preloaded: the FCN forward pass (f16x3; every dynamic-LDS kernel of lm_fcn.hip, on
+    an odd-sized frame), a stream with large components and step 03 (group images, reconstruction).  The emulator allocates
+    the dynamic LDS of every launch at exactly the size the launch asked for and fills it with NaN patterns before every block,
+    so an LDS index past a kernel's allocation aborts the child and LDS that is consumed without having been written poisons
+    the compared results.  (The child stays clear of torch -- importing it under the ASan runtime takes a minute -- so the
+    oracle's FCN outputs are computed here and handed over.)"""
     import subprocess
     import sys
+    import torch
+    from oracle import fcn as ofcn
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu")
     subprocess.check_call(["make", "-s", "-C", d, "asan"])
     rt = subprocess.check_output(["make", "-s", "-C", d, "asan-runtime"]).decode().strip()
+    widths = (8, 16, 16, 8, 8, 8, 8, 8, 8, 8, 16, 16, 8, 8, 8, 8, 16, 8)
+    sd = ofcn.random_state_dict(widths, pixel_kernel=7, seed=2)
+    rgb = np.random.default_rng(1).integers(0, 256, (35, 53, 3), dtype=np.uint8)        # odd sizes: every output_size padding
+    with torch.no_grad():
+        o, t, r = ofcn.forward(sd, ofcn.prepare_image(rgb))
+    fx = str(tmp_path / "fcn_case.npz")
+    np.savez(fx, rgb=rgb, out=o[0, 0].numpy(), text=t[0, 0].numpy(), rec=r[0].numpy(), **{"sd." + k: v.numpy() for k, v in sd.items()})
     child = (
         "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "from lecturemath_amd import _lib\nimport lm_checks\n"
+        "import numpy as np\n"
+        "from lecturemath_amd import _lib, fcn\nimport lm_checks\n"
         "lib = _lib.load(%r)\n"
-        "assert lm_checks.check_fcn_golden(lib, 'k7_70x94', tol=1e-4, precision='f16x3') < 1e-4\n"
-        "lm_checks.check_stream_large_components(lib, n_frames=6)\n"
-        "lm_checks.check_grouping_golden(lib, 'short_gap_jitter')\n"
-        "print('sanitized run ok')\n" % (os.path.dirname(os.path.dirname(d)), os.path.dirname(d), os.path.join(d, "liblecturemath_emu_asan.so")))
+        "g = np.load(%r)\n"
+        "eng = fcn.FcnEngine(%r, 7, 3, 35, 53, lib, precision='f16x3')\n"
+        "eng.load_state_dict({k[3:]: g[k] for k in g.files if k.startswith('sd.')})\n"
+        "out, text, rec = eng.forward(g['rgb'])\n"
+        "assert np.abs(out - g['out']).max() < 1e-4 and np.abs(text - g['text']).max() < 1e-4 and np.abs(rec - g['rec']).max() < 1e-4\n"
+        "lm_checks.check_stream_large_components(lib, n_frames=4)\n"
+        "lm_checks.check_grouping_oracle(lib, lm_checks.dot_grid_stream(n_frames=4, h=40, w=520))\n"
+        "print('sanitized run ok')\n" % (os.path.dirname(os.path.dirname(d)), os.path.dirname(d), os.path.join(d, "liblecturemath_emu_asan.so"), fx,
+                                            widths))
     env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:detect_stack_use_after_return=0",
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=1500)
