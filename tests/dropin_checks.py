@@ -274,7 +274,7 @@ def check_labeler(lib):
     assert [(c.cc_id, c.size) for c in pre] == [(c.cc_id, c.size) for c in ref]
 
 
-def check_fcn_class(lib, name="k7_70x94"):
+def check_fcn_class(lib, name="k7_70x94", worker=True):
     """FCN_LectureNet.CreateFromConfig / load_state_dict / binarize and the step-01 worker vs the reference's outputs."""
     use_library(lib)
     import PIL.Image
@@ -295,6 +295,8 @@ def check_fcn_class(lib, name="k7_70x94"):
     edge_t = np.abs(g["text"][0, 0] - 0.01569) < 2e-3
     assert ((text_mask == g["text_mask"]) | edge_t).all()
     assert np.abs(rec_img.astype(np.int32) - g["rec_img"].astype(np.int32)).max() <= 1
+    if not worker:
+        return
     worker = FCN_LectureNet_Binarizer(net)
     worker.initialize(g["rgb"].shape[1], g["rgb"].shape[0])
     worker.handleFrame(np.ascontiguousarray(g["rgb"][:, :, ::-1]), None, 0, 1000.0, 1000.0, 30)

@@ -41,7 +41,7 @@ def test_stream_run_logits(emu_lib, oracle_built):
 
 
 def test_stream_match_paths_agree(emu_lib, oracle_built):
-    lm_checks.check_stream_match_paths(emu_lib, n_frames=72)
+    lm_checks.check_stream_match_paths(emu_lib, n_frames=48)
 
 
 def test_stream_golden_short_gap(emu_lib):
