@@ -39,6 +39,24 @@ static int lm_debug_band_phases()
     return v;
 }
 
+// LM_DEBUG_BAND_STAMPS=<file>: lm_k_band leaves wall-clock stamps per phase and workgroup (8 x u64 each); the last launch's are
+// written to <file> by lm_label_counts (tools/band_phases.py reads them).  Tuning aid only.
+static unsigned long long* g_band_stamps = nullptr;
+static size_t g_band_stamps_n = 0;
+static unsigned long long* lm_debug_band_stamps(int nbands, int n_frames)
+{
+    static const char* path = getenv("LM_DEBUG_BAND_STAMPS");
+    if (!path) return nullptr;
+    const size_t need = (size_t)nbands * n_frames * 8;
+    if (need > g_band_stamps_n) {
+        if (g_band_stamps) (void)hipFree(g_band_stamps);
+        g_band_stamps = nullptr;
+        if (hipMalloc((void**)&g_band_stamps, need * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+        g_band_stamps_n = need;
+    }
+    return g_band_stamps;
+}
+
 static inline unsigned lm_blocks(long long work_items, int block, int max_blocks = 8192)
 {
     long long b = (work_items + block - 1) / block;
@@ -273,7 +291,7 @@ extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, i
     hipLaunchKernelGGL(lm_k_pack_rows, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, d_binary, c->bits, c->starts, c->prefix, c->rowcnt, g.W, g.WW, R);
     static const int band_threads = [] { const char* e = getenv("LM_BAND_THREADS"); const int v = e ? atoi(e) : 512; return (v == 128 || v == 256 || v == 512) ? v : 512; }();
     hipLaunchKernelGGL(lm_k_band, dim3(nbands, n_frames), dim3(band_threads), band_smem, st, c->bits, c->starts, c->prefix, c->rowcnt, c->rowoff,
-                       c->band_runs, c->parent, c->band_fallback, g.H, g.WW, slot, g.cap, lm_debug_band_phases(), magic_ww, c->band_rows);
+                       c->band_runs, c->parent, c->band_fallback, g.H, g.WW, slot, g.cap, lm_debug_band_phases(), magic_ww, c->band_rows, lm_debug_band_stamps(nbands, n_frames));
     hipLaunchKernelGGL(lm_k_seam_union, dim3(nbands, n_frames), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff,
                        c->band_fallback, c->parent, g.WW, g.H, g.cap, c->band_rows);
     hipLaunchKernelGGL(lm_k_flatten_flag, dim3(nbands, n_frames), dim3(256), 0, st, c->parent, c->band_runs, c->rootbits, c->wordprefix,
@@ -303,6 +321,15 @@ extern "C" int lm_label_counts(LmCtx* c, int32_t* h_counts, void* stream)
     LM_HIP(hipMemcpyAsync(h_counts, c->n_labels, (size_t)c->last_batch * sizeof(int32_t), hipMemcpyDeviceToHost,
                           (hipStream_t)stream));
     LM_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (g_band_stamps && getenv("LM_DEBUG_BAND_STAMPS")) {
+        const size_t n = (size_t)c->nbands * c->last_batch * 8;
+        unsigned long long* h = (unsigned long long*)malloc(n * sizeof(unsigned long long));
+        if (h && hipMemcpy(h, g_band_stamps, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            FILE* f = fopen(getenv("LM_DEBUG_BAND_STAMPS"), "wb");
+            if (f) { fwrite(h, sizeof(unsigned long long), n, f); fclose(f); }
+        }
+        free(h);
+    }
     return LM_OK;
 }
 

@@ -170,6 +170,35 @@ LM_DEV int lm_find(const int32_t* parent, int x)
     return x;
 }
 
+// find with path halving: every visited node is re-pointed to its grandparent (plain stores: a racing store can only write
+// another valid ancestor, smaller than the node).  Dense frames build chains as long as a band is tall; without compression
+// the union phase of lm_k_band spent 17 of its 22 us walking them (tools/band_phases.py).
+LM_DEV int lm_find_halve(int32_t* parent, int x)
+{
+    int p = parent[x];
+    while (p != x) {
+        const int gp = parent[p];
+        if (gp != p) parent[x] = gp;
+        x = p;
+        p = gp;
+    }
+    return x;
+}
+
+template <bool HALVE>
+LM_DEV void lm_union_t(int32_t* parent, int a, int b)
+{
+    for (;;) {
+        a = HALVE ? lm_find_halve(parent, a) : lm_find(parent, a);
+        b = HALVE ? lm_find_halve(parent, b) : lm_find(parent, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        int old = atomicMin(&parent[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
 LM_DEV void lm_union(int32_t* parent, int a, int b)
 {
     for (;;) {
@@ -283,10 +312,16 @@ __global__ void __launch_bounds__(512) lm_k_band(const uint64_t* __restrict__ bi
                                                  const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowcnt,
                                                  uint32_t* __restrict__ rowoff, int32_t* __restrict__ band_runs, int32_t* __restrict__ parent,
                                                  uint8_t* __restrict__ band_fallback, int H, int WW, int slot, int cap, int phases,
-                                                 unsigned long long magic_ww, int brows)
+                                                 unsigned long long magic_ww, int brows, unsigned long long* __restrict__ stamps)
 {
     LM_DYN_SMEM(smem);
     const int b = blockIdx.y, band = blockIdx.x, nbands = gridDim.x;
+#if !LM_HIP_EMULATED
+#define LM_BAND_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define LM_BAND_STAMP(k) do { } while (0)
+#endif
+    LM_BAND_STAMP(0);
     const int y0 = band * brows;
     const int nrows = (y0 + brows < H) ? brows : H - y0;
     const long long row0 = (long long)b * H + y0;
@@ -307,6 +342,7 @@ __global__ void __launch_bounds__(512) lm_k_band(const uint64_t* __restrict__ bi
         if ((int)threadIdx.x < nrows) s_rowcnt[threadIdx.x] = rowcnt[row0 + threadIdx.x];
     }
     __syncthreads();
+    LM_BAND_STAMP(1);
     // ---- 3. band-local row offsets
     if (wave == 0) {
         const unsigned v = (lane < nrows) ? s_rowcnt[lane] : 0u;
@@ -331,10 +367,14 @@ __global__ void __launch_bounds__(512) lm_k_band(const uint64_t* __restrict__ bi
     }
     for (int i = threadIdx.x; i < n; i += blockDim.x) s_par[i] = i;
     __syncthreads();
-    // ---- 4. unions between vertically adjacent runs, all from LDS (per cell: every distinct (run, upper run) contact).
-    // Measured alternatives that were slower on MI355X (profiles/r01_label_experiments.md): run-centric parent stores +
-    // barrier-separated pointer jumping + atomics only for merges (112 vs 76 us per 32 frames); path halving in the finds
-    // (52.6 vs 50.9 us: the chains are short, the extra LDS stores cost more than they save).
+    LM_BAND_STAMP(2);
+    // ---- 4. unions between vertically adjacent runs, all from LDS
+    // Per cell (64 px of a row against the row above): every distinct (run, upper run) contact, united on the spot with path
+    // halving.  What this phase costs is the chain of dependent LDS accesses of the busiest lane of each wave (12-17 of the
+    // kernel's 17-22 us per band on dense frames, tools/band_phases.py).  Measured and rejected on MI355X: several lanes per
+    // cell (the replicated cell set-up costs more than the shorter chains save: 16 -> 23 / 32 / 46 us for 2 / 4 / 8 lanes),
+    // listing the contacts in LDS first and uniting one contact per lane (12.6 us, but 16 KB more LDS: 3 instead of 4
+    // workgroups per CU, same kernel time), run-centric stores + barrier-separated pointer jumping (round 1).
     for (int cell = threadIdx.x; cell < (nrows - 1) * WW; cell += blockDim.x) {
         const int r = 1 + (int)lm_fastdiv((unsigned)cell, magic_ww), w = cell - (r - 1) * WW;
         const unsigned long long cur = s_bits[r * WW + w];
@@ -351,11 +391,15 @@ __global__ void __launch_bounds__(512) lm_k_band(const uint64_t* __restrict__ bi
             const int p = __ffsll((long long)ps) - 1;
             ps &= ps - 1;
             const unsigned long long m = lm_lowmask_incl(p);
-            lm_union(s_par, base_cur + __popcll(s_cur & m), base_up + __popcll(s_up & m));
+            lm_union_t<true>(s_par, base_cur + __popcll(s_cur & m), base_up + __popcll(s_up & m));
         }
     }
     __syncthreads();
+    LM_BAND_STAMP(3);
     for (int i = threadIdx.x; i < n; i += blockDim.x) par_g[i] = band * slot + lm_find(s_par, i);
+    __syncthreads();
+    LM_BAND_STAMP(4);
+    if (stamps && threadIdx.x == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 5] = (unsigned long long)n;
 }
 
 #define LM_SEAM_CAP 1024       // contacts of one seam row kept in LDS (a row of W px has at most W / 2)
