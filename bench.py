@@ -301,7 +301,8 @@ def main():
     labels = None if a.no_labels else torch.empty((B, H, W), dtype=torch.int32, device="cuda")
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, depth))
 
-    gated = os.environ.get("LM_BENCH_SCHEDULE", "free") == "gated"
+    schedule = os.environ.get("LM_BENCH_SCHEDULE", "gated")       # gated (default) | free | gated-py (the Python-driven loop below)
+    gated = schedule == "gated-py"
 
     def front(sl, match=True, use_split=split):
         """steps 01 (threshold) + 02 (label, records; matching when `match`) of this rank's block of the stream.
@@ -323,8 +324,8 @@ def main():
                 # the whole launch loop in one library call (per batch: threshold -> label -> records on the wide stream, matching
                 # on the slot's own stream behind an event): ~5,000 launches that a Python loop issued at half the GPU's pace
                 two = match and use_split
-                lib.check(lib.lm_stream_run_logits(fs.handle, logits.data_ptr(), n_mine, B, binary.data_ptr(), lp, 128, 1 if match else 0, ws,
-                                                   ms if two else ws))
+                lib.check(lib.lm_stream_run_logits(fs.handle, logits.data_ptr(), n_mine, B, binary.data_ptr(), lp, 128, 1 if match else 0,
+                                                   1 if schedule == "gated" else 0, ws, ms if two else ws))
                 sl["done"].record(sl["s_match"] if two else s_wide)
                 return
             batches = [(f0, min(B, n_mine - f0)) for f0 in range(0, n_mine, B)]
@@ -566,7 +567,8 @@ def main():
                    "stream": dict({k: k1[k] for k in ("n_cc", "n_unique", "tempo_count")}, n_groups=int(ginfo[2]), n_split=int(ginfo[0])),
                    "parallelism": "one stream on one GPU" if world == 1 else "frame-range shards of one stream, gather to rank 0",
                    "pipeline_depth": depth, "matching_on_own_hip_stream": bool(split),
-                   "schedule": "gated: labelling launches do not overlap the matching kernels" if gated else "free"},
+                   "schedule": {"gated": "lm_stream_run_logits schedule 1: labelling launches kept apart from the matching's wide kernels",
+                                "free": "lm_stream_run_logits schedule 0", "gated-py": "Python-driven gated loop"}.get(schedule, schedule)},
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "gen_seconds": round(gen_s, 2),
     }
     if world == 1 and a.fcn_frames > 0:

@@ -118,10 +118,13 @@ int lm_stream_push_labelled(LmStream* s, int n_frames, void* stream);
 /* Steps 01-02 of a whole stream of fp32 logits resident on the device in ONE call (FCN_lecturenet.py:452-467 thresholding,
  * FCN_lecturenet_binarizer.py:54 inversion, labeler.py:116-191, cc_stability_estimator.py:41-155): per batch of `batch` frames
  * threshold+invert -> label -> records on stream_wide and the temporal matching on stream_match (behind an event per batch;
- * pass the same stream twice for a single queue, do_match = 0 for the records only).  d_binary is scratch for `batch` frames,
+ * pass the same stream twice for a single queue, do_match = 0 for the records only).  schedule 0: every batch's matching starts
+ * as soon as its records are in; schedule 1: the labelling launches (bandwidth bound) are kept apart from the wide kernels of the
+ * matching -- matching of batch k-1 starts when batch k has been labelled, batch k+1 is labelled when that matching has reached
+ * its single-workgroup replay.  d_binary is scratch for `batch` frames,
  * d_labels receives the label image of every batch in turn (or NULL).  Asynchronous. */
 int lm_stream_run_logits(LmStream* s, const float* d_logits, int n_frames, int batch, uint8_t* d_binary, int32_t* d_labels, int thr,
-                         int do_match, void* stream_wide, void* stream_match);
+                         int do_match, int schedule, void* stream_wide, void* stream_match);
 
 /* Frame-range sharding across the GPUs of a node: the CC records + crops of frames
  * [first_frame, first_frame + n_frames) of a stream as ONE flat DEVICE buffer (32-byte aligned), so that the gather to the rank

@@ -53,7 +53,7 @@ SIGNATURES = {
     "lm_stream_push": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "lm_stream_push_records": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "lm_stream_match": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
-    "lm_stream_run_logits": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    "lm_stream_run_logits": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     "lm_stream_push_labelled": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
     "lm_stream_pack_size": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     "lm_stream_pack": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _i64, _vp]),

@@ -594,7 +594,9 @@ static void lm_launch_match(LmStream* s, int f, hipStream_t st)
 }
 
 // Matches frames [f0, f0 + n) (all emitted already) in chunks of at most LM_MB_MAX_FRAMES frames.
-static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st)
+// ev_pre (optional): recorded on `st` in front of the last chunk's replay kernel, i.e. when the wide kernels of the matching
+// (twin detection, joins, pair evaluation) have been issued and only the single-workgroup replay, finish and tempo_count remain
+static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st, hipEvent_t ev_pre = nullptr)
 {
     if (s->match_per_frame) {
         for (int i = 0; i < n; i++) lm_launch_match(s, f0 + i, st);
@@ -630,6 +632,7 @@ static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st)
                            s->min_recall, s->min_precision, s->max_gap);
         hipLaunchKernelGGL((lm_k_mb_eval_big<1>), gb, dim3(256), 0, st, s->cc, s->crop, s->active_last, s->counters, mb, s->min_recall, s->min_precision,
                            s->max_gap);
+        if (ev_pre && done + B >= n) (void)hipEventRecord(ev_pre, st);
         hipLaunchKernelGGL(lm_k_mb_resolve, dim3(1), dim3(LM_MB_RT), LM_MB_RESOLVE_SMEM, st, s->cc, s->frame_cc_off, f, B, s->active, s->active_cc,
                            s->active_box, s->active_last, s->counters, s->assign, mb, s->max_gap, s->cap_uniq);
         hipLaunchKernelGGL(lm_k_mb_finish, dim3(160), dim3(256), 0, st, s->frame_cc_off, f, B, s->active, s->counters, s->assign, mb);
@@ -726,40 +729,72 @@ extern "C" int lm_stream_push_records(LmStream* s, const uint8_t* d_binary, int 
 // loop around them (plus a second Python thread driving step 03 of the previous stream) was the bottleneck of the pipeline.
 // d_binary: scratch for `batch` frames; d_labels: label image of one batch, or NULL.  Asynchronous: when the call returns
 // everything is enqueued; the work of the stream is complete when `stream_match` has drained.
-extern "C" int lm_stream_run_logits(LmStream* s, const float* d_logits, int n_frames, int batch, uint8_t* d_binary, int32_t* d_labels, int thr,
-                                    int do_match, void* stream_wide, void* stream_match)
+static int lm_run_events(LmStream* s, int want)
 {
-    if (!s || !d_logits || !d_binary || n_frames < 0 || batch <= 0 || batch > s->ctx->max_batch) {
-        lm_set_error("lm_stream_run_logits: bad arguments (batch %d, context batch %d)", batch, s ? s->ctx->max_batch : 0);
+    if (want <= s->n_run_events) return LM_OK;
+    want += 192;
+    hipEvent_t* ev = (hipEvent_t*)realloc(s->run_events, (size_t)want * sizeof(hipEvent_t));
+    if (!ev) { lm_set_error("lm_stream_run_logits: out of memory"); return LM_ERR_HIP; }
+    s->run_events = ev;
+    for (; s->n_run_events < want; s->n_run_events++) LM_HIP(hipEventCreateWithFlags(&s->run_events[s->n_run_events], hipEventDisableTiming));
+    return LM_OK;
+}
+
+extern "C" int lm_stream_run_logits(LmStream* s, const float* d_logits, int n_frames, int batch, uint8_t* d_binary, int32_t* d_labels, int thr,
+                                    int do_match, int schedule, void* stream_wide, void* stream_match)
+{
+    if (!s || !d_logits || !d_binary || n_frames < 0 || batch <= 0 || batch > s->ctx->max_batch || schedule < 0 || schedule > 1) {
+        lm_set_error("lm_stream_run_logits: bad arguments (batch %d, context batch %d, schedule %d)", batch, s ? s->ctx->max_batch : 0, schedule);
         return LM_ERR_ARG;
+    }
+    if (do_match && s->frames_matched != s->frames_pushed) {
+        lm_set_error("lm_stream_run_logits: %d frames pushed without matching; call lm_stream_match first", s->frames_pushed - s->frames_matched);
+        return LM_ERR_STATE;
     }
     hipStream_t sw = (hipStream_t)stream_wide, sm = (hipStream_t)stream_match;
     const bool two = do_match && sm != sw;
+    const bool gated = two && schedule == 1 && batch <= LM_MB_MAX_FRAMES && !s->match_per_frame;
     const size_t px = (size_t)s->ctx->g.W * s->ctx->g.H;
-    int k = 0;
-    for (int f0 = 0; f0 < n_frames; f0 += batch, k++) {
+    const int nb = (n_frames + batch - 1) / batch;
+    if (two) { const int rc = lm_run_events(s, 3 * nb); if (rc) return rc; }
+    // events of batch k: 3k = labelled, 3k + 1 = records appended, 3k + 2 = its matching has reached the replay kernel
+    hipEvent_t* ev = s->run_events;
+    int prev_n = 0;
+    for (int k = 0, f0 = 0; f0 < n_frames; f0 += batch, k++) {
         const int n = (n_frames - f0 < batch) ? n_frames - f0 : batch;
         int rc = lm_threshold(d_logits + (size_t)f0 * px, d_binary, (int64_t)n * (int64_t)px, thr, 1, stream_wide);
         if (rc) return rc;
+        if (gated && k >= 2) LM_HIP(hipStreamWaitEvent(sw, ev[3 * (k - 2) + 2], 0));       // the wide kernels of matching k-2 are through
         rc = lm_label_batch(s->ctx, d_binary, n, d_labels, stream_wide);
         if (rc) return rc;
+        if (gated) LM_HIP(hipEventRecord(ev[3 * k], sw));
         rc = lm_stream_push_labelled(s, n, stream_wide);
         if (rc) return rc;
         if (!do_match) continue;
-        if (two) {
-            if (k >= s->n_run_events) {
-                const int want = k + 64;
-                hipEvent_t* ev = (hipEvent_t*)realloc(s->run_events, (size_t)want * sizeof(hipEvent_t));
-                if (!ev) { lm_set_error("lm_stream_run_logits: out of memory"); return LM_ERR_HIP; }
-                s->run_events = ev;
-                for (; s->n_run_events < want; s->n_run_events++) LM_HIP(hipEventCreateWithFlags(&s->run_events[s->n_run_events], hipEventDisableTiming));
+        if (!two) {
+            rc = lm_stream_match(s, n, stream_wide);
+            if (rc) return rc;
+        } else if (!gated) {
+            LM_HIP(hipEventRecord(ev[3 * k + 1], sw));
+            LM_HIP(hipStreamWaitEvent(sm, ev[3 * k + 1], 0));
+            rc = lm_stream_match(s, n, stream_match);
+            if (rc) return rc;
+        } else {
+            LM_HIP(hipEventRecord(ev[3 * k + 1], sw));
+            if (k >= 1) {               // matching of batch k-1 starts when batch k has been labelled (which implies its records are in)
+                LM_HIP(hipStreamWaitEvent(sm, ev[3 * k], 0));
+                lm_launch_match_frames(s, s->frames_matched, prev_n, sm, ev[3 * (k - 1) + 2]);
+                s->frames_matched += prev_n;
             }
-            LM_HIP(hipEventRecord(s->run_events[k], sw));
-            LM_HIP(hipStreamWaitEvent(sm, s->run_events[k], 0));
         }
-        rc = lm_stream_match(s, n, two ? stream_match : stream_wide);
-        if (rc) return rc;
+        prev_n = n;
     }
+    if (gated && nb > 0) {
+        LM_HIP(hipStreamWaitEvent(sm, ev[3 * (nb - 1) + 1], 0));
+        lm_launch_match_frames(s, s->frames_matched, prev_n, sm, ev[3 * (nb - 1) + 2]);
+        s->frames_matched += prev_n;
+    }
+    LM_HIP(hipGetLastError());
     return LM_OK;
 }
 

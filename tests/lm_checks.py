@@ -85,7 +85,7 @@ def run_stream(lib, frames, w, h, max_gap, max_batch=7, split=None, records_then
         fs.close()
 
 
-def check_stream_run_logits(lib, n_frames=23, h=96, w=160, batch=5):
+def check_stream_run_logits(lib, n_frames=23, h=96, w=160, batch=5, schedule=0, second_stream=False):
     """lm_stream_run_logits (the whole steps 01-02 loop in one call, logits in, matched stream out) == threshold_invert + push
     batch by batch, with and without a separate matching stream argument; and the oracle."""
     frames = np.stack(list(synth.binary_stream(n_frames, h, w, seed=8, glyphs_per_add=4, erase_every=8, jitter_p=0.4, occluder=True, max_ext=16)))
@@ -98,7 +98,13 @@ def check_stream_run_logits(lib, n_frames=23, h=96, w=160, batch=5):
         scratch = be.empty((batch, h, w), np.uint8)
         labels = be.empty((batch, h, w), np.int32)
         st = be.stream()
-        lib.check(lib.lm_stream_run_logits(fs.handle, _lib.ptr(d_logits), n_frames, batch, _lib.ptr(scratch), _lib.ptr(labels), 128, 1, st, st))
+        st2 = st
+        if second_stream and be.device:
+            side = be.torch.cuda.Stream()
+            st2 = side.cuda_stream
+        lib.check(lib.lm_stream_run_logits(fs.handle, _lib.ptr(d_logits), n_frames, batch, _lib.ptr(scratch), _lib.ptr(labels), 128, 1, schedule, st, st2))
+        if st2 is not st:
+            side.synchronize()
         got = fs.result()
     finally:
         fs.close()

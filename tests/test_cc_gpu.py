@@ -33,7 +33,11 @@ def test_stream_golden(hip_lib, name):
 
 
 def test_stream_run_logits(hip_lib, oracle_built):
+    """The whole steps 01-02 loop in one call: one queue, two queues, and two queues with the gated schedule (labelling kept
+    apart from the matching's wide kernels) give the per-batch result and the oracle's."""
     lm_checks.check_stream_run_logits(hip_lib)
+    lm_checks.check_stream_run_logits(hip_lib, second_stream=True)
+    lm_checks.check_stream_run_logits(hip_lib, n_frames=41, batch=4, schedule=1, second_stream=True)
 
 
 def test_stream_match_paths_agree(hip_lib, oracle_built):
