@@ -151,6 +151,7 @@ extern "C" void lm_ctx_destroy(LmCtx* c)
                     c->kept_cropoff, c->frame_kept, c->frame_cropwords, c->stage_u8, c->stage_i32, c->stage_f32};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (c->aux_stream) { (void)hipStreamDestroy((hipStream_t)c->aux_stream); (void)hipEventDestroy((hipEvent_t)c->ev_fork); (void)hipEventDestroy((hipEvent_t)c->ev_join); }
     delete c;
 }
 
@@ -267,6 +268,47 @@ extern "C" int lm_threshold_invert(const float* d_logits, uint8_t* d_out, int64_
 // ------------------------------------------------------------------------------------------------
 // labelling
 // ------------------------------------------------------------------------------------------------
+// The launch sequence of frames [f0, f0 + n) of a batch on stream `st`.  All the per-frame tables of the context are indexed by
+// the frame's position in the batch and hold frame-relative ids, so a part of a batch is the same launches on shifted pointers.
+static int lm_label_launch(LmCtx* c, const uint8_t* d_binary, int f0, int n, int32_t* d_labels, hipStream_t st)
+{
+    const LmGeom g = c->g;
+    const int nbands = c->nbands, slot = c->slot;
+    const int capw = g.cap / 64;
+    const size_t band_smem = (size_t)c->band_rows * g.WW * 18 + LM_BAND_LDS * 4 + (65 + 64) * 4 + 64;
+    const unsigned long long magic_ww = ((1ull << 40) / (unsigned)g.WW) + 1;
+    const long long R = (long long)n * g.H;
+    const size_t px = (size_t)g.W * g.H, r0 = (size_t)f0 * g.H, w0 = r0 * g.WW, b0 = (size_t)f0 * nbands, c0 = (size_t)f0 * g.cap, cw0 = (size_t)f0 * capw;
+    hipLaunchKernelGGL(lm_k_pack_rows, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, d_binary + f0 * px, c->bits + w0, c->starts + w0, c->prefix + w0,
+                       c->rowcnt + r0, g.W, g.WW, R);
+    static const int band_threads = [] { const char* e = getenv("LM_BAND_THREADS"); const int v = e ? atoi(e) : 512; return (v == 128 || v == 256 || v == 512) ? v : 512; }();
+    hipLaunchKernelGGL(lm_k_band, dim3(nbands, n), dim3(band_threads), band_smem, st, c->bits + w0, c->starts + w0, c->prefix + w0, c->rowcnt + r0,
+                       c->rowoff + r0, c->band_runs + b0, c->parent + c0, c->band_fallback + b0, g.H, g.WW, slot, g.cap, lm_debug_band_phases(), magic_ww,
+                       c->band_rows, f0 == 0 ? lm_debug_band_stamps(nbands, n) : nullptr);
+    hipLaunchKernelGGL(lm_k_seam_union, dim3(nbands, n), dim3(256), 0, st, c->bits + w0, c->starts + w0, c->prefix + w0, c->rowoff + r0,
+                       c->band_fallback + b0, c->parent + c0, g.WW, g.H, g.cap, c->band_rows);
+    hipLaunchKernelGGL(lm_k_flatten_flag, dim3(nbands, n), dim3(256), 0, st, c->parent + c0, c->band_runs + b0, c->rootbits + cw0, c->wordprefix + cw0,
+                       c->band_roots + b0, slot, g.cap, capw);
+    hipLaunchKernelGGL(lm_k_apply_labels, dim3(nbands, n), dim3(256), 0, st, c->parent + c0, c->band_runs + b0, c->rootbits + cw0, c->wordprefix + cw0,
+                       c->band_roots + b0, c->band_base + b0, c->n_labels + f0, c->final_label + c0, slot, g.cap, capw);
+    if (d_labels) {
+        const unsigned Q = (unsigned)(g.W + 3) / 4;
+        const unsigned long long magic_q = ((1ull << 40) / Q) + 1;       // lm_fastdiv: exact for H * Q < 2^24
+        const long long quads = (long long)g.H * Q;
+        // one chunk of 64 * LM_WL_Q quads per wave (measured: work distribution moves this kernel by < 5 %, it runs at the
+        // mixed read/write bandwidth of the device)
+        const unsigned gx = (unsigned)((quads + 256 * LM_WL_Q - 1) / (256 * LM_WL_Q));
+        hipLaunchKernelGGL(lm_k_write_labels, dim3(gx, n), dim3(256), 0, st, c->bits + w0, c->starts + w0, c->prefix + w0, c->rowoff + r0,
+                           c->final_label + c0, d_labels + f0 * px, g.W, g.H, g.WW, g.cap, magic_q, 0);
+    }
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+// Parts of a batch are labelled side by side: the middle of the sequence (band forests, seams, numbering) is a chain of
+// latency-bound kernels on ~1/8 of the bytes, its two ends (row packing, the label image) stream at HBM rate -- with the parts on
+// two queues the ends of one part run under the middle of the other.  The second queue belongs to the context and is joined back
+// into the caller's stream before the call returns, so the caller's ordering is that of a single launch sequence.
 extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, int32_t* d_labels, void* stream)
 {
     if (!c || !d_binary || n_frames <= 0 || n_frames > c->max_batch) {
@@ -275,42 +317,43 @@ extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, i
     }
     const LmGeom g = c->g;
     hipStream_t st = (hipStream_t)stream;
-    if (lm_profile_mark(c, st, true, n_frames)) return LM_ERR_HIP;
-    const int nbands = c->nbands, slot = c->slot;
-    const int capw = g.cap / 64;
-    const size_t band_smem = (size_t)c->band_rows * g.WW * 18 + LM_BAND_LDS * 4 + (65 + 64) * 4 + 64;
+    if ((long long)g.H * ((g.W + 3) / 4) >= (1ll << 24) && d_labels) { lm_set_error("lm_label_batch: frame too large for the label writer (H*W/4 must be < 2^24)"); return LM_ERR_ARG; }
 #if !LM_HIP_EMULATED
-    static size_t band_smem_configured = 0;
-    if (band_smem > band_smem_configured) {
-        LM_HIP(hipFuncSetAttribute((const void*)lm_k_band, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_smem));
-        band_smem_configured = band_smem;
+    {
+        const size_t band_smem = (size_t)c->band_rows * g.WW * 18 + LM_BAND_LDS * 4 + (65 + 64) * 4 + 64;
+        static size_t band_smem_configured = 0;
+        if (band_smem > band_smem_configured) {
+            LM_HIP(hipFuncSetAttribute((const void*)lm_k_band, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_smem));
+            band_smem_configured = band_smem;
+        }
     }
 #endif
-    const unsigned long long magic_ww = ((1ull << 40) / (unsigned)g.WW) + 1;
-    const long long R = (long long)n_frames * g.H;
-    hipLaunchKernelGGL(lm_k_pack_rows, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, d_binary, c->bits, c->starts, c->prefix, c->rowcnt, g.W, g.WW, R);
-    static const int band_threads = [] { const char* e = getenv("LM_BAND_THREADS"); const int v = e ? atoi(e) : 512; return (v == 128 || v == 256 || v == 512) ? v : 512; }();
-    hipLaunchKernelGGL(lm_k_band, dim3(nbands, n_frames), dim3(band_threads), band_smem, st, c->bits, c->starts, c->prefix, c->rowcnt, c->rowoff,
-                       c->band_runs, c->parent, c->band_fallback, g.H, g.WW, slot, g.cap, lm_debug_band_phases(), magic_ww, c->band_rows, lm_debug_band_stamps(nbands, n_frames));
-    hipLaunchKernelGGL(lm_k_seam_union, dim3(nbands, n_frames), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff,
-                       c->band_fallback, c->parent, g.WW, g.H, g.cap, c->band_rows);
-    hipLaunchKernelGGL(lm_k_flatten_flag, dim3(nbands, n_frames), dim3(256), 0, st, c->parent, c->band_runs, c->rootbits, c->wordprefix,
-                       c->band_roots, slot, g.cap, capw);
-    hipLaunchKernelGGL(lm_k_apply_labels, dim3(nbands, n_frames), dim3(256), 0, st, c->parent, c->band_runs, c->rootbits, c->wordprefix,
-                       c->band_roots, c->band_base, c->n_labels, c->final_label, slot, g.cap, capw);
-    if (d_labels) {
-        const unsigned Q = (unsigned)(g.W + 3) / 4;
-        const unsigned long long magic_q = ((1ull << 40) / Q) + 1;       // lm_fastdiv: exact for H * Q < 2^24
-        const long long quads = (long long)g.H * Q;
-        if (quads >= (1ll << 24)) { lm_set_error("lm_label_batch: frame too large for the label writer (H*W/4 must be < 2^24)"); return LM_ERR_ARG; }
-        // one chunk of 64 * LM_WL_Q quads per wave (measured: work distribution moves this kernel by < 5 %, it runs at the
-        // mixed read/write bandwidth of the device)
-        const unsigned gx = (unsigned)((quads + 256 * LM_WL_Q - 1) / (256 * LM_WL_Q));
-        hipLaunchKernelGGL(lm_k_write_labels, dim3(gx, n_frames), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff,
-                           c->final_label, d_labels, g.W, g.H, g.WW, g.cap, magic_q, 0);
+    if (lm_profile_mark(c, st, true, n_frames)) return LM_ERR_HIP;
+    static const int want_parts = [] { const char* e = getenv("LM_LABEL_PARTS"); const int v = e ? atoi(e) : LM_LABEL_PARTS; return (v >= 1 && v <= 8) ? v : LM_LABEL_PARTS; }();
+    int parts = want_parts;
+    while (parts > 1 && n_frames / parts < LM_LABEL_PART_MIN) parts--;
+    if (parts > 1 && !c->aux_stream) {
+        LM_HIP(hipStreamCreateWithFlags((hipStream_t*)&c->aux_stream, hipStreamNonBlocking));
+        LM_HIP(hipEventCreateWithFlags((hipEvent_t*)&c->ev_fork, hipEventDisableTiming));
+        LM_HIP(hipEventCreateWithFlags((hipEvent_t*)&c->ev_join, hipEventDisableTiming));
+    }
+    if (parts <= 1) {
+        const int rc = lm_label_launch(c, d_binary, 0, n_frames, d_labels, st);
+        if (rc) return rc;
+    } else {
+        hipStream_t aux = (hipStream_t)c->aux_stream;
+        LM_HIP(hipEventRecord((hipEvent_t)c->ev_fork, st));
+        LM_HIP(hipStreamWaitEvent(aux, (hipEvent_t)c->ev_fork, 0));
+        for (int k = 0, f0 = 0; k < parts; k++) {
+            const int n = n_frames / parts + (k < n_frames % parts ? 1 : 0);
+            const int rc = lm_label_launch(c, d_binary, f0, n, d_labels, (k & 1) ? aux : st);
+            if (rc) return rc;
+            f0 += n;
+        }
+        LM_HIP(hipEventRecord((hipEvent_t)c->ev_join, aux));
+        LM_HIP(hipStreamWaitEvent(st, (hipEvent_t)c->ev_join, 0));
     }
     if (lm_profile_mark(c, st, false, n_frames)) return LM_ERR_HIP;
-    LM_HIP(hipGetLastError());
     c->last_batch = n_frames;
     return LM_OK;
 }

@@ -90,7 +90,14 @@ struct LmCtx {
     // optional live timing of the labelling launch sequence (bench.py roofline): hipEvent pairs per call
     int profiling;
     void* prof;     // LmProfile*, owned
+    // second queue of lm_label_batch (parts of a batch side by side), created on first use
+    void* aux_stream;
+    void* ev_fork;
+    void* ev_join;
 };
+
+#define LM_LABEL_PARTS 2        // parts a batch is labelled in (env LM_LABEL_PARTS overrides: 1..8)
+#define LM_LABEL_PART_MIN 8     // ... as long as every part has at least this many frames
 
 // ---------------------------------------------------------------- device helpers
 #if LM_HIP_EMULATED

@@ -88,6 +88,9 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMem
 static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = 0) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+#define hipStreamNonBlocking 1
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (void*)(uintptr_t)1; return hipSuccess; }   // launches are synchronous
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipPeekAtLastError() { return hipSuccess; }

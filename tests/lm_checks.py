@@ -242,6 +242,31 @@ def check_label_vs_oracle(lib, img):
         lab.close()
 
 
+def check_label_batch_in_parts(lib, n_frames=19, h=45, w=150):
+    """A batch large enough to be labelled in parts on two queues (lm_label_batch): labels, counts and statistics of every frame
+    vs the oracle, twice in a row on the same context (the second call's parts follow the first call's join)."""
+    from oracle import cc as occ
+    rng = np.random.default_rng(77)
+    frames = ((rng.random((n_frames, h, w)) < rng.uniform(0.1, 0.6, size=(n_frames, 1, 1))) * 255).astype(np.uint8)
+    frames[3] = 0
+    frames[n_frames - 1] = 255
+    lab = device.FrameLabeler(w, h, n_frames, lib)
+    try:
+        for rep in range(2):
+            dev = lab.be.from_host(frames if rep == 0 else frames[::-1].copy())
+            labels, counts = lab.label(dev)
+            got = lab.be.to_host(labels)
+            st = lab.stats(counts)
+            for k in range(n_frames):
+                img = frames[k] if rep == 0 else frames[n_frames - 1 - k]
+                l, n = occ.label4(img)
+                assert counts[k] == n and (got[k] == l).all(), (rep, k)
+                if n:
+                    assert (st[k] == np.stack(occ.age_boundaries(l, None, n)[:5])).all(), (rep, k)
+    finally:
+        lab.close()
+
+
 def grouping_equal_golden(r, g):
     """Every step-03 intermediate of the reference (G4 fixture) vs the product's Grouping.result()."""
     assert r["n_split"] == int(g["n_split"])

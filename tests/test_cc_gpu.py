@@ -32,6 +32,12 @@ def test_stream_golden(hip_lib, name):
     lm_checks.check_stream_golden(hip_lib, name, max_batch=16)
 
 
+def test_label_batch_in_parts(hip_lib, oracle_built):
+    """lm_label_batch labels the parts of a batch on two queues; every frame vs the oracle, at a size where the parts overlap."""
+    lm_checks.check_label_batch_in_parts(hip_lib)
+    lm_checks.check_label_batch_in_parts(hip_lib, n_frames=40, h=270, w=480)
+
+
 def test_stream_run_logits(hip_lib, oracle_built):
     """The whole steps 01-02 loop in one call: one queue, two queues, and two queues with the gated schedule (labelling kept
     apart from the matching's wide kernels) give the per-batch result and the oracle's."""

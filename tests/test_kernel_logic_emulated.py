@@ -96,6 +96,10 @@ def test_dense_wide_noise_band_fallback(emu_lib, oracle_built):
     lm_checks.check_label_vs_oracle(emu_lib, img)
 
 
+def test_label_batch_in_parts(emu_lib, oracle_built):
+    lm_checks.check_label_batch_in_parts(emu_lib)
+
+
 def test_label_wide_frame_16_row_bands(emu_lib, oracle_built):
     """Frames wider than 2048 px (4K: WW = 60 words) are labelled in 16-row bands (the LDS tuning for wide rows)."""
     rng = np.random.default_rng(23)
