@@ -57,6 +57,8 @@ struct LmConvArgs {
     int tmode, dy, dx, OH, OW;          // transposed mode: input (y, x) -> output (2y+dy, 2x+dx) of an OH x OW grid
     int tg;                             // f16x3 kernel: taps whose weights are staged together (divides K*K)
     int terms;                          // fp16-split kernels: products per operand pair (3, 2 or 1; see lm_k_conv_mfma_h)
+    int krows;                          // fp16-split kernels: kernel rows (0 = K: square kernel; 1 = a 1 x K row convolution)
+    float* pool; int pool_ps;           // fp16-split kernels: when set, the 2x2/s2 max-pooled output is written as well ([H/2][W/2], this pixel stride)
 };
 
 template <int CK, int NT>
@@ -188,7 +190,7 @@ lm_f32x16 hipemu_mfma_32x32x16f16(lm_h8 a, lm_h8 b, lm_f32x16 c);
 // variant needed ~200 VGPRs and the NT = 2 / transposed variants fell to one wave per SIMD.
 
 template <int MAXP>
-LM_DEV void lm_cv_load_patch(const LmConvArgs& a, int ch, int ty0, int tx0, int pad, int PW, int items, int ctot, float4 (&pr)[MAXP])
+LM_DEV void lm_cv_load_patch(const LmConvArgs& a, int ch, int ty0, int tx0, int pady, int pad, int PW, int items, int ctot, float4 (&pr)[MAXP])
 {
 #pragma unroll
     for (int k = 0; k < MAXP; k++) {
@@ -197,7 +199,7 @@ LM_DEV void lm_cv_load_patch(const LmConvArgs& a, int ch, int ty0, int tx0, int 
         if (i < items) {
             const int px = i >> 2, q = i & 3;
             const int py = px / PW, pxx = px - py * PW;
-            const int y = ty0 + py - pad, x = tx0 + pxx - pad;
+            const int y = ty0 + py - pady, x = tx0 + pxx - pad;
             const int cl = ch * 16 + q * 4;                     // logical (concatenated) channel
             if (y >= 0 && y < a.H && x >= 0 && x < a.W && cl < ctot) {
                 const long long p = (long long)y * a.W + x;
@@ -279,15 +281,18 @@ constexpr int lm_cv_tg(int K, int NT)
 // KS: kernel side known at compile time (1, 3, 7), or 0 = taken from the arguments (worst-case prefetch arrays)
 // TERMS: products per pair of operands.  3 = hi.hi + hi.lo + lo.hi (the "f16x3" format above, ~22 bits per operand);
 // 2 = hi.hi + lo.hi (activations split, weights rounded to f16); 1 = hi.hi (both operands rounded to f16).
-template <int NT, int KS, int TG = 0, int TERMS = 3>     // TG: taps per weight group, 0 = lm_cv_tg(KS, NT)
+// KH: kernel rows known at compile time (1: a 1 x KS row convolution, see lm_rowconv_layer), 0 = KS (square kernel)
+template <int NT, int KS, int TG = 0, int TERMS = 3, int KH = 0>     // TG: taps per weight group, 0 = lm_cv_tg(KS, NT)
 __global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1) lm_k_conv_mfma_h(const LmConvArgs a)      // two waves per SIMD whenever the accumulators allow
 {
     LM_DYN_SMEM(smem);
+    static_assert(KH == 0 || KS != 0, "a fixed row count needs a fixed kernel side");
     constexpr int PB = 80;                  // bytes per pixel in LDS
-    constexpr int MAXP = KS ? ((16 + KS - 1) * (16 + KS - 1) * 4 + 255) / 256 : LM_CV_MAXP;
+    constexpr int KHC = KH ? KH : KS;
+    constexpr int MAXP = KS ? ((16 + KHC - 1) * (16 + KS - 1) * 4 + 255) / 256 : LM_CV_MAXP;
     constexpr int MAXW = KS ? ((TG ? TG : lm_cv_tg(KS, NT)) * NT + 1) / 2 : LM_CV_MAXW;
-    const int K = KS ? KS : a.K, pad = (K - 1) >> 1, taps = K * K;
-    const int PW = 16 + K - 1, PH = 16 + K - 1;
+    const int K = KS ? KS : a.K, KR = KH ? KH : K, pad = (K - 1) >> 1, pady = (KR - 1) >> 1, taps = KR * K;
+    const int PW = 16 + K - 1, PH = 16 + KR - 1;
     const int patch_items = PH * PW * 4;
     char* s_patch = smem;
     const int RB = lm_cv_row_bytes(PW);
@@ -313,13 +318,13 @@ __global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1) lm_k_conv_mfma_h(const
 
     float4 pr[MAXP];
     uint4 wr[MAXW];
-    lm_cv_load_patch<MAXP>(a, 0, ty0, tx0, pad, PW, patch_items, ctot, pr);
+    lm_cv_load_patch<MAXP>(a, 0, ty0, tx0, pady, pad, PW, patch_items, ctot, pr);
     lm_cv_load_w<NT, MAXW>(a, 0, 0, a.tg < taps ? a.tg : taps, taps, nb0, wr);
     int buf = 0;
     for (int ch = 0; ch < nchunks; ch++) {
         lm_lds_barrier();                                       // everybody is done with the previous chunk's patch
         lm_cv_store_patch<MAXP>(s_patch, PW, patch_items, pr);
-        if (ch + 1 < nchunks) lm_cv_load_patch<MAXP>(a, ch + 1, ty0, tx0, pad, PW, patch_items, ctot, pr);   // in flight for a whole chunk
+        if (ch + 1 < nchunks) lm_cv_load_patch<MAXP>(a, ch + 1, ty0, tx0, pady, pad, PW, patch_items, ctot, pr);   // in flight for a whole chunk
         for (int g = 0; g < ngroups; g++) {
             const int t0 = g * a.tg;
             const int ntg = (taps - t0 < a.tg) ? taps - t0 : a.tg;
@@ -377,16 +382,30 @@ __global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1) lm_k_conv_mfma_h(const
         if (nb0 + n >= a.nblocks || co >= a.Cout) continue;
         const float b = a.bias[co];
 #pragma unroll
-        for (int m = 0; m < 2; m++)
+        for (int m = 0; m < 2; m++) {
+            float v[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int y = ty0 + wave * 4 + m * 2 + (i >> 4), x = tx0 + (i & 15);
+                v[r] = lm_act(acc[m][n][r] + b, a.act);
                 if (y >= a.H || x >= a.W) continue;
-                const float v = lm_act(acc[m][n][r] + b, a.act);
                 long long opix = a.tmode ? ((long long)(2 * y + a.dy) * a.OW + (2 * x + a.dx)) : ((long long)y * a.W + x);
-                a.out[opix * a.ops + a.ooff + co] = v;
+                a.out[opix * a.ops + a.ooff + co] = v[r];
             }
+            // 2x2 max pooling from registers: accumulator rows r, r + 1 are neighbouring columns of the block's first image row,
+            // r + 8, r + 9 the same columns of its second (the block's two rows start at an even y, tiles at an even x)
+            if (a.pool) {
+                const int OH = a.H >> 1, OW = a.W >> 1;
+                const int py = (ty0 + wave * 4 + m * 2) >> 1;
+#pragma unroll
+                for (int r = 0; r < 8; r += 2) {
+                    const int px = (tx0 + (r & 3) + 8 * (r >> 2) + 4 * half) >> 1;
+                    if (py < OH && px < OW)
+                        a.pool[((long long)py * OW + px) * a.pool_ps + co] = fmaxf(fmaxf(v[r], v[r + 1]), fmaxf(v[r + 8], v[r + 9]));
+                }
+            }
+        }
     }
 }
 
@@ -418,7 +437,7 @@ __global__ void __launch_bounds__(256, 2) lm_k_convT_mfma_h(const LmConvArgs a)
     const int prow = wave * 4 + (pi >> 4), pcol = pi & 15;
     float4 pr[4];           // 16 x 16 px x 4 items / 256 threads
     uint4 wr[2];            // 4 taps x 128 items / 256 threads
-    lm_cv_load_patch<4>(a, 0, ty0, tx0, 0, PW, PW * PW * 4, ctot, pr);
+    lm_cv_load_patch<4>(a, 0, ty0, tx0, 0, 0, PW, PW * PW * 4, ctot, pr);
     lm_cv_load_w<1, 2>(a, 0, 0, TAPS, TAPS, nb0, wr);
     int buf = 0;
     for (int ch = 0; ch < nchunks; ch++) {
@@ -428,7 +447,7 @@ __global__ void __launch_bounds__(256, 2) lm_k_convT_mfma_h(const LmConvArgs a)
         lm_cv_store_w<2>(s_w, TAPS * 128, wr);
         lm_lds_barrier();
         if (ch + 1 < nchunks) {
-            lm_cv_load_patch<4>(a, ch + 1, ty0, tx0, 0, PW, PW * PW * 4, ctot, pr);
+            lm_cv_load_patch<4>(a, ch + 1, ty0, tx0, 0, 0, PW, PW * PW * 4, ctot, pr);
             lm_cv_load_w<1, 2>(a, ch + 1, 0, TAPS, TAPS, nb0, wr);
         }
         lm_h8 ah[2], al[2];
@@ -690,6 +709,67 @@ __global__ void LM_NO_PACKED_F32 __launch_bounds__(256) lm_k_conv_c1(const float
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Heads with 1 or 3 output channels (text mask 7x7, reconstruction 3x3, output logit 7x7) on the MFMA path: a K x K convolution
+// with NV outputs is a 1 x K ROW convolution with K * NV outputs per pixel (output kh * NV + co = the contribution of kernel row kh
+// to channel co: lm_k_conv_mfma_h<1, K, 0, TERMS, 1>, weights packed that way by the host) followed by the vertical sum
+//     out[y][x][co] = act(bias[co] + sum_kh T[y + kh - pad][x][kh * NV + co])
+// below.  On the VALU (lm_k_conv_c1, lm_k_conv_small) the two 7x7 heads took 1.26 of a frame's 6.9 ms.
+// T: [pixel][TS] floats.  DIFF (reconstruction head): besides rec the kernel writes diff = (x0 - rec) * sigmoid(text) (:379)
+// as one [pixel][4] buffer, which the pixel branch reads as the first of two concatenated inputs (written into channels 0..2 of
+// three wider buffers, 12 bytes at a stride of 96-160, the same values took 190-310 us per frame instead of ~15).
+// ------------------------------------------------------------------------------------------------
+template <int KR, int NV, int TS, bool DIFF>
+__global__ void __launch_bounds__(256) lm_k_vsum(const float* __restrict__ T, int H, int W, const float* __restrict__ bias, int act,
+                                                 float* __restrict__ out, int ops, const float* __restrict__ x0, const float* __restrict__ text,
+                                                 float* __restrict__ diff4)
+{
+    constexpr int TW = 32, TH = 16, PR = TH + KR - 1, PADR = (KR - 1) / 2, RQ = TW * TS / 4;
+    __shared__ float s_t[PR * TW * TS];
+    const int tiles_x = (W + TW - 1) / TW;
+    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    for (int i = threadIdx.x; i < PR * RQ; i += blockDim.x) {
+        const int r = i / RQ, q = i - r * RQ;
+        const int y = ty0 + r - PADR, x = tx0 + (q * 4) / TS;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y >= 0 && y < H && x < W) v = *(const float4*)(T + ((long long)y * W + tx0) * TS + q * 4);
+        *(float4*)(s_t + (r * TW) * TS + q * 4) = v;
+    }
+    __syncthreads();
+    const int ly = (int)(threadIdx.x >> 4), lx = (int)(threadIdx.x & 15);
+    const int y = ty0 + ly;
+    if (y >= H) return;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int xl = lx + 16 * h, x = tx0 + xl;
+        if (x >= W) continue;
+        float v[NV];
+#pragma unroll
+        for (int co = 0; co < NV; co++) v[co] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < KR; kh++)
+#pragma unroll
+            for (int co = 0; co < NV; co++) v[co] += s_t[((ly + kh) * TW + xl) * TS + kh * NV + co];
+        const long long p = (long long)y * W + x;
+        if (DIFF) {
+            const float m = 1.0f / (1.0f + expf(-text[p]));
+            float rec[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
+            const float4 xin = *(const float4*)(x0 + p * 8);
+            const float xc[3] = {xin.x, xin.y, xin.z};
+#pragma unroll
+            for (int co = 0; co < NV && co < 3; co++) {
+                rec[co] = lm_act(v[co] + bias[co], act);
+                d[co] = (xc[co] - rec[co]) * m;
+            }
+            *(float4*)(out + p * 4) = make_float4(rec[0], rec[1], rec[2], 0.f);
+            *(float4*)(diff4 + p * 4) = make_float4(d[0], d[1], d[2], 0.f);
+        } else {
+#pragma unroll
+            for (int co = 0; co < NV; co++) out[p * ops + co] = lm_act(v[co] + bias[co], act);
+        }
+    }
+}
+
 // diff = (x0 - rec) * sigmoid(text)  (:379), written to channels 0..2 of three NHWC buffers
 __global__ void __launch_bounds__(256) lm_k_diff(const float* __restrict__ x0, const float* __restrict__ rec4,
                                                  const float* __restrict__ text, long long npx, float* __restrict__ o0, int s0,
@@ -738,6 +818,10 @@ struct LmFcn {
     // activations (allocated for max_h x max_w)
     float *x0 = nullptr, *pre[5] = {}, *pool[5] = {}, *mid = nullptr, *up[5] = {}, *cu[5] = {};
     float *text = nullptr, *rec4 = nullptr, *px0 = nullptr, *px1 = nullptr, *px2 = nullptr, *outl = nullptr;
+    float* tbuf = nullptr;      // [pixel][12] row-convolution outputs of the heads (lm_rowconv_layer)
+    // MFMA-head layout (fp16-split formats, 7x7 pixel kernels): x_up1, diff and the pixel features each in a buffer of their own;
+    // the (diff, features) concatenations are two-input convolutions
+    float *xup = nullptr, *d4 = nullptr, *p1 = nullptr, *p2 = nullptr;
 };
 
 static int lm_fcn_alloc(LmFcn* f, float** p, size_t count)
@@ -792,6 +876,11 @@ extern "C" LmFcn* lm_fcn_create(const int32_t* widths18, int pixel_kernel, int k
     rc |= lm_fcn_alloc(f, &f->text, px[0]);
     rc |= lm_fcn_alloc(f, &f->rec4, px[0] * 4);
     rc |= lm_fcn_alloc(f, &f->outl, px[0]);
+    rc |= lm_fcn_alloc(f, &f->tbuf, px[0] * 12);
+    rc |= lm_fcn_alloc(f, &f->xup, px[0] * c1);
+    rc |= lm_fcn_alloc(f, &f->d4, px[0] * 4);
+    rc |= lm_fcn_alloc(f, &f->p1, px[0] * pm1);
+    rc |= lm_fcn_alloc(f, &f->p2, px[0] * pm2);
     if (rc != LM_OK) { lm_fcn_destroy(f); return nullptr; }
     return f;
 }
@@ -849,24 +938,32 @@ static size_t lm_conv_smem_h(int K, int NT)
     return (size_t)P * (((size_t)P * 80 + 255) & ~(size_t)255) + 2 * (size_t)lm_conv_tg_h(K, NT) * NT * 2048;   // rows padded to 256 B, weights double-buffered
 }
 
-template <int NT, int KS, int TG, int TERMS> static int lm_launch_conv_hkt(const LmConvArgs& a, hipStream_t st)
+template <int NT, int KS, int TG, int TERMS, int KH = 0> static int lm_launch_conv_hkt(const LmConvArgs& a, hipStream_t st)
 {
     const int tg = TG ? TG : lm_conv_tg_h(a.K, NT);
-    const int P = 16 + a.K - 1;
-    const size_t smem = (size_t)P * (((size_t)P * 80 + 255) & ~(size_t)255) + 2 * (size_t)tg * NT * 2048;   // rows padded to 256 B, weights double-buffered
+    const int P = 16 + a.K - 1, PR = 16 + (KH ? KH : a.K) - 1;
+    const size_t smem = (size_t)PR * (((size_t)P * 80 + 255) & ~(size_t)255) + 2 * (size_t)tg * NT * 2048;   // rows padded to 256 B, weights double-buffered
 #if !LM_HIP_EMULATED
     static size_t configured = 0;
     if (smem > configured) {
-        LM_HIP(hipFuncSetAttribute((const void*)lm_k_conv_mfma_h<NT, KS, TG, TERMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        LM_HIP(hipFuncSetAttribute((const void*)lm_k_conv_mfma_h<NT, KS, TG, TERMS, KH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         configured = smem;
     }
 #endif
     const int tiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
     LmConvArgs b = a;
     b.tg = tg;
-    hipLaunchKernelGGL((lm_k_conv_mfma_h<NT, KS, TG, TERMS>), dim3(tiles, (a.nblocks + NT - 1) / NT), dim3(256), smem, st, b);
+    hipLaunchKernelGGL((lm_k_conv_mfma_h<NT, KS, TG, TERMS, KH>), dim3(tiles, (a.nblocks + NT - 1) / NT), dim3(256), smem, st, b);
     LM_HIP(hipGetLastError());
     return LM_OK;
+}
+
+// 1 x K row convolution (one n-block), see lm_rowconv_layer
+template <int KS> static int lm_launch_rowconv_h(const LmConvArgs& a, hipStream_t st)
+{
+    if (a.terms == 1) return lm_launch_conv_hkt<1, KS, 0, 1, 1>(a, st);
+    if (a.terms == 2) return lm_launch_conv_hkt<1, KS, 0, 2, 1>(a, st);
+    return lm_launch_conv_hkt<1, KS, 0, 3, 1>(a, st);
 }
 
 template <int NT, int KS, int TG = 0> static int lm_launch_conv_hk(const LmConvArgs& a, hipStream_t st)
@@ -923,7 +1020,7 @@ static int lm_launch_conv(const LmConvArgs& a0, int ck, hipStream_t st)
 }
 
 static int lm_conv_layer(LmFcn* f, int layer, const float* in0, int c0, int ps0, const float* in1, int c1, int ps1, int H, int W,
-                         float* out, int ops, int ooff, int act, hipStream_t st)
+                         float* out, int ops, int ooff, int act, hipStream_t st, float* pool = nullptr)
 {
     const LmFcnLayer& l = f->layer[layer];
     if (!l.w) { lm_set_error("lm_fcn_forward: layer %d has no weights (call lm_fcn_set_layer)", layer); return LM_ERR_STATE; }
@@ -932,6 +1029,7 @@ static int lm_conv_layer(LmFcn* f, int layer, const float* in0, int c0, int ps0,
     a.in0 = in0; a.c0 = c0; a.ps0 = ps0; a.in1 = in1; a.c1 = c1; a.ps1 = ps1; a.H = H; a.W = W;
     a.wpk = l.w; a.bias = l.bias; a.out = out; a.ops = ops; a.ooff = ooff; a.Cout = l.cout; a.nblocks = (l.cout + 31) / 32;
     a.K = l.k; a.act = act;
+    if (pool && l.ck <= 0) { a.pool = pool; a.pool_ps = l.cout; }      // the fp16-split kernel pools in its epilogue
     return lm_launch_conv(a, l.ck, st);
 }
 
@@ -1015,6 +1113,36 @@ static int lm_small_layer(LmFcn* f, int layer, const float* in, int ips, int C, 
     return (l.cout == 1) ? lm_small_launch<1>(l, in, ips, C, H, W, out, ops, act, st) : lm_small_launch<4>(l, in, ips, C, H, W, out, ops, act, st);
 }
 
+// A head with l.cout <= 3 output channels and an l.k x l.k kernel on the MFMA path (weights packed by fcn.pack_rows_h, l.ck <= 0):
+// row convolution into f->tbuf, then lm_k_vsum.  bias: [0..31] zeros (the convolution's epilogue), [32..] the folded bias.
+static int lm_rowconv_layer(LmFcn* f, int layer, const float* in0, int c0, const float* in1, int c1, int H, int W, float* out, int ops, int act,
+                            bool diff, hipStream_t st)
+{
+    const LmFcnLayer& l = f->layer[layer];
+    if (!l.w) { lm_set_error("lm_fcn_forward: layer %d has no weights", layer); return LM_ERR_STATE; }
+    const bool seven = (l.k == 7 && l.cout == 1), three = (l.k == 3 && l.cout == 3);
+    if ((!seven && !three) || (diff && !three)) {
+        lm_set_error("lm_fcn_forward: layer %d: the MFMA head path covers 7x7 kernels with one output and 3x3 kernels with three (got %dx%d, %d)", layer, l.k, l.k, l.cout);
+        return LM_ERR_ARG;
+    }
+    LmConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in0 = in0; a.c0 = c0; a.ps0 = c0; a.in1 = in1; a.c1 = c1; a.ps1 = c1; a.H = H; a.W = W;
+    a.wpk = l.w; a.bias = l.bias; a.out = f->tbuf; a.ops = seven ? 8 : 12; a.ooff = 0; a.Cout = l.k * l.cout; a.nblocks = 1;
+    a.K = l.k; a.act = LM_ACT_NONE; a.terms = lm_terms_of_ck(l.ck); a.krows = 1;
+    int rc = seven ? lm_launch_rowconv_h<7>(a, st) : lm_launch_rowconv_h<3>(a, st);
+    if (rc) return rc;
+    const int tiles = ((W + 31) / 32) * ((H + 15) / 16);
+    if (seven)
+        hipLaunchKernelGGL((lm_k_vsum<7, 1, 8, false>), dim3(tiles), dim3(256), 0, st, f->tbuf, H, W, l.bias + 32, act, out, ops, nullptr, nullptr, nullptr);
+    else if (diff)
+        hipLaunchKernelGGL((lm_k_vsum<3, 3, 12, true>), dim3(tiles), dim3(256), 0, st, f->tbuf, H, W, l.bias + 32, act, out, ops, f->x0, f->text, f->d4);
+    else
+        hipLaunchKernelGGL((lm_k_vsum<3, 3, 12, false>), dim3(tiles), dim3(256), 0, st, f->tbuf, H, W, l.bias + 32, act, out, ops, nullptr, nullptr, nullptr);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
 // forward() of the non-reconstruction branch (:364-403) on one RGB frame resident on the device.
 // Outputs (device, fp32): d_out [h*w] binarization logit, d_text [h*w] text-mask logit, d_rec [3][h*w] reconstruction.
 static int lm_fcn_forward_impl(LmFcn* f, const uint8_t* d_rgb, int h, int w, float* d_out, float* d_text, float* d_rec, void* stream)
@@ -1032,15 +1160,18 @@ static int lm_fcn_forward_impl(LmFcn* f, const uint8_t* d_rgb, int h, int w, flo
     const int c1 = wd[15], pm1 = wd[16], pm2 = wd[17];
     const int s_px0 = lm_pad8(3 + c1), s_px1 = lm_pad8(3 + pm1), s_px2 = lm_pad8(3 + pm2);
     int rc;
+    const bool heads_mfma = f->layer[16].ck <= 0;       // fp16-split formats: the heads run as row convolutions on the MFMA path
     hipLaunchKernelGGL(lm_k_prepare, dim3((unsigned)std::min<long long>((npx + 255) / 256, 8192)), dim3(256), 0, st, d_rgb, f->x0, npx);
     // ---- encoder
     const float* cur = f->x0;
     int cc = 8;
     for (int n = 0; n < 5; n++) {
-        if ((rc = lm_conv_layer(f, n, cur, cc, cc, nullptr, 0, 0, H[n], W[n], f->pre[n], wd[n], 0, LM_ACT_GELU, st))) return rc;
-        const long long tot = (long long)H[n + 1] * W[n + 1] * (wd[n] / 4);
-        hipLaunchKernelGGL(lm_k_maxpool2, dim3((unsigned)std::min<long long>((tot + 255) / 256, 8192)), dim3(256), 0, st, f->pre[n], wd[n],
-                           f->pool[n], wd[n], H[n], W[n], wd[n]);
+        if ((rc = lm_conv_layer(f, n, cur, cc, cc, nullptr, 0, 0, H[n], W[n], f->pre[n], wd[n], 0, LM_ACT_GELU, st, f->pool[n]))) return rc;
+        if (f->layer[n].ck > 0) {       // fp32 kernel: pooling is a pass of its own
+            const long long tot = (long long)H[n + 1] * W[n + 1] * (wd[n] / 4);
+            hipLaunchKernelGGL(lm_k_maxpool2, dim3((unsigned)std::min<long long>((tot + 255) / 256, 8192)), dim3(256), 0, st, f->pre[n], wd[n],
+                               f->pool[n], wd[n], H[n], W[n], wd[n]);
+        }
         cur = f->pool[n];
         cc = wd[n];
     }
@@ -1052,8 +1183,8 @@ static int lm_fcn_forward_impl(LmFcn* f, const uint8_t* d_rgb, int h, int w, flo
         const int g = 4 - n;
         const int cu = wd[6 + 2 * n], co = wd[7 + 2 * n];
         if ((rc = lm_convT_layer(f, 6 + n, cur, cc, H[g + 1], W[g + 1], f->up[n], H[g], W[g], st))) return rc;
-        float* dst = (n < 4) ? f->cu[n] : f->px0;
-        const int ops = (n < 4) ? co : s_px0, ooff = (n < 4) ? 0 : 3;
+        float* dst = (n < 4) ? f->cu[n] : (heads_mfma ? f->xup : f->px0);
+        const int ops = (n < 4) ? co : (heads_mfma ? c1 : s_px0), ooff = (n < 4 || heads_mfma) ? 0 : 3;
         if ((rc = lm_conv_layer(f, 11 + n, f->up[n], cu, cu, f->pre[g], wd[g], wd[g], H[g], W[g], dst, ops, ooff, LM_ACT_GELU, st))) return rc;
         cur = dst;
         cc = co;
@@ -1062,14 +1193,22 @@ static int lm_fcn_forward_impl(LmFcn* f, const uint8_t* d_rgb, int h, int w, flo
     const float* xup = f->px0 + 3;
     // x_up1 is not 16-byte aligned at channel offset 3, so the small kernel reads the whole (diff, x_up1) buffer with zero
     // weights on channels 0..2 (the host packs them that way)
-    if ((rc = lm_small_layer(f, 16, f->px0, s_px0, s_px0, h, w, f->text, 1, LM_ACT_NONE, st))) return rc;
-    if ((rc = lm_small_layer(f, 17, f->px0, s_px0, s_px0, h, w, f->rec4, 4, LM_ACT_TANH, st))) return rc;
+    if (heads_mfma) {
+        if ((rc = lm_rowconv_layer(f, 16, f->xup, c1, nullptr, 0, h, w, f->text, 1, LM_ACT_NONE, false, st))) return rc;
+        if ((rc = lm_rowconv_layer(f, 17, f->xup, c1, nullptr, 0, h, w, f->rec4, 4, LM_ACT_TANH, true, st))) return rc;
+        if ((rc = lm_conv_layer(f, 18, f->d4, 4, 4, f->xup, c1, c1, h, w, f->p1, pm1, 0, LM_ACT_GELU, st))) return rc;
+        if ((rc = lm_conv_layer(f, 19, f->d4, 4, 4, f->p1, pm1, pm1, h, w, f->p2, pm2, 0, LM_ACT_GELU, st))) return rc;
+        if ((rc = lm_rowconv_layer(f, 20, f->d4, 4, f->p2, pm2, h, w, f->outl, 1, LM_ACT_NONE, false, st))) return rc;
+    } else {
+        if ((rc = lm_small_layer(f, 16, f->px0, s_px0, s_px0, h, w, f->text, 1, LM_ACT_NONE, st))) return rc;
+        if ((rc = lm_small_layer(f, 17, f->px0, s_px0, s_px0, h, w, f->rec4, 4, LM_ACT_TANH, st))) return rc;
+        hipLaunchKernelGGL(lm_k_diff, dim3((unsigned)std::min<long long>((npx + 255) / 256, 8192)), dim3(256), 0, st, f->x0, f->rec4, f->text, npx,
+                           f->px0, s_px0, f->px1, s_px1, f->px2, s_px2);
+        if ((rc = lm_conv_layer(f, 18, f->px0, s_px0, s_px0, nullptr, 0, 0, h, w, f->px1, s_px1, 3, LM_ACT_GELU, st))) return rc;
+        if ((rc = lm_conv_layer(f, 19, f->px1, s_px1, s_px1, nullptr, 0, 0, h, w, f->px2, s_px2, 3, LM_ACT_GELU, st))) return rc;
+        if ((rc = lm_small_layer(f, 20, f->px2, s_px2, s_px2, h, w, f->outl, 1, LM_ACT_NONE, st))) return rc;
+    }
     (void)xup;
-    hipLaunchKernelGGL(lm_k_diff, dim3((unsigned)std::min<long long>((npx + 255) / 256, 8192)), dim3(256), 0, st, f->x0, f->rec4, f->text, npx,
-                       f->px0, s_px0, f->px1, s_px1, f->px2, s_px2);
-    if ((rc = lm_conv_layer(f, 18, f->px0, s_px0, s_px0, nullptr, 0, 0, h, w, f->px1, s_px1, 3, LM_ACT_GELU, st))) return rc;
-    if ((rc = lm_conv_layer(f, 19, f->px1, s_px1, s_px1, nullptr, 0, 0, h, w, f->px2, s_px2, 3, LM_ACT_GELU, st))) return rc;
-    if ((rc = lm_small_layer(f, 20, f->px2, s_px2, s_px2, h, w, f->outl, 1, LM_ACT_NONE, st))) return rc;
     if (d_out) LM_HIP(hipMemcpyAsync(d_out, f->outl, (size_t)npx * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (d_text) LM_HIP(hipMemcpyAsync(d_text, f->text, (size_t)npx * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (d_rec) hipLaunchKernelGGL(lm_k_nhwc4_to_chw3, dim3((unsigned)std::min<long long>((npx + 255) / 256, 8192)), dim3(256), 0, st, f->rec4, d_rec, npx);

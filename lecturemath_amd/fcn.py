@@ -63,17 +63,26 @@ def pack_mfma_h(w_oikk, cin_map, cin_logical):
     W[co = nblock*32 + (l & 31)][ci = chunk*16 + 8*(l >> 5) + j][tap]; hi = f16(w), lo = f16(w - hi).
     cin_map[i] = position of weight input channel i among the cin_logical concatenated input channels (padded to 16 here).
     Returned as a float32 view (two halfs per float) for lm_fcn_set_layer."""
-    cout, cin, k, _ = w_oikk.shape
+    cout, cin, kh, kw = w_oikk.shape                                    # square kernels, or the 1 x K rows of pack_rows_h
+    taps = kh * kw
     nblocks = (cout + 31) // 32
     cpad = ((cin_logical + 15) // 16) * 16
-    wp = np.zeros((nblocks * 32, cpad, k * k), np.float32)
-    wp[:cout][:, np.asarray(cin_map)] = w_oikk.reshape(cout, cin, k * k)
+    wp = np.zeros((nblocks * 32, cpad, taps), np.float32)
+    wp[:cout][:, np.asarray(cin_map)] = w_oikk.reshape(cout, cin, taps)
     hi = wp.astype(np.float16)
     lo = (wp - hi.astype(np.float32)).astype(np.float16)
     both = np.stack([hi, lo])                                           # hl, co, ci, tap
-    a = both.reshape(2, nblocks, 32, cpad // 16, 2, 8, k * k)          # hl, nb, j, chunk, half, e, tap
+    a = both.reshape(2, nblocks, 32, cpad // 16, 2, 8, taps)           # hl, nb, j, chunk, half, e, tap
     a = a.transpose(3, 6, 1, 0, 4, 2, 5)                                # chunk, tap, nb, hl, half, j, e
     return np.ascontiguousarray(a).reshape(-1).view(np.float32)
+
+
+def pack_rows_h(w_oikk, cin_map, cin_logical):
+    """A K x K convolution with NV <= 3 outputs as a 1 x K row convolution with K * NV outputs (lm_rowconv_layer in lm_fcn.hip):
+    virtual output kh * NV + co holds kernel row kh of channel co; lm_k_vsum adds the rows up."""
+    nv, cin, k, _ = w_oikk.shape
+    rows = np.ascontiguousarray(w_oikk.transpose(2, 0, 1, 3)).reshape(k * nv, cin, 1, k)      # [kh][co][ci][kw] -> [kh * NV + co][ci][1][kw]
+    return pack_mfma_h(rows, cin_map, cin_logical)
 
 
 def pack_small(w_oikk, cin_map, cin_padded):
@@ -179,10 +188,34 @@ class FcnEngine:
             self._set(L_UPC + i, wpk, bias_pad(b), u + skip, c, self.kk, ck)
         # heads: inputs are (diff | features | zero pad) buffers
         s0, s1, s2 = _pad8(3 + c1), _pad8(3 + pm1), _pad8(3 + pm2)
+        # The fp16-split formats with the shipped kernel sizes (7x7 pixel branch, 3x3 elsewhere) run the heads on the MFMA path
+        # (row convolution + vertical sum) and keep x_up1 / diff / pixel features in buffers of their own: a (diff, features)
+        # input is the two-input concatenation [d0 d1 d2 0 | features].  Everything else: the round-1 layout, one
+        # (diff | features | pad) buffer per stage and VALU kernels for the heads.
+        if h and self.pk == 7 and self.kk == 3:
+            def head_bias(b):       # [0..31]: zeros for the row convolution's epilogue, [32..]: the bias lm_k_vsum adds
+                out = np.zeros(64, np.float32)
+                out[32:32 + len(b)] = b
+                return out
+
+            def cat_map(nfeat):     # weight input channel -> logical channel of [diff(3) 0 | features]
+                return [0, 1, 2] + list(range(4, 4 + nfeat))
+
+            w, b = conv_bn("conv_text_mask_out")
+            self._set(L_TEXT, pack_rows_h(w, range(c1), c1), head_bias(b), c1, 1, self.pk, hck)
+            w, b = conv_bn("conv_reconstruct")
+            self._set(L_REC, pack_rows_h(w, range(c1), c1), head_bias(b), c1, 3, self.kk, hck)
+            w, b = conv_bn("conv_pixels_1")
+            self._set(L_PX1, pack_mfma_h(w, cat_map(c1), 4 + c1), bias_pad(b), 4 + c1, pm1, self.pk, hck)
+            w, b = conv_bn("conv_pixels_2")
+            self._set(L_PX2, pack_mfma_h(w, cat_map(pm1), 4 + pm1), bias_pad(b), 4 + pm1, pm2, self.pk, hck)
+            w, b = conv_bn("conv_out")
+            self._set(L_OUT, pack_rows_h(w, cat_map(pm2), 4 + pm2), head_bias(b), 4 + pm2, 1, self.pk, hck)
+            return
         w, b = conv_bn("conv_text_mask_out")
-        self._set(L_TEXT, pack_small(w, range(3, 3 + c1), s0), np.pad(b, (0, 4 - len(b))), s0, 1, self.pk, 0)
+        self._set(L_TEXT, pack_small(w, range(3, 3 + c1), s0), np.pad(b, (0, 4 - len(b))), s0, 1, self.pk, 8)
         w, b = conv_bn("conv_reconstruct")
-        self._set(L_REC, pack_small(w, range(3, 3 + c1), s0), np.pad(b, (0, 4 - len(b))), s0, 3, self.kk, 0)
+        self._set(L_REC, pack_small(w, range(3, 3 + c1), s0), np.pad(b, (0, 4 - len(b))), s0, 3, self.kk, 8)
         w, b = conv_bn("conv_pixels_1")
         wpk, ck = (pack_mfma_h(w, range(3 + c1), s0), hck) if h else (pack_mfma(w, 8, range(3 + c1), s0), 8)
         self._set(L_PX1, wpk, bias_pad(b), s0, pm1, self.pk, ck)
@@ -190,7 +223,7 @@ class FcnEngine:
         wpk, ck = (pack_mfma_h(w, range(3 + pm1), s1), hck) if h else (pack_mfma(w, 8, range(3 + pm1), s1), 8)
         self._set(L_PX2, wpk, bias_pad(b), s1, pm2, self.pk, ck)
         w, b = conv_bn("conv_out")
-        self._set(L_OUT, pack_small(w, range(3 + pm2), s2), np.pad(b, (0, 4 - len(b))), s2, 1, self.pk, 0)
+        self._set(L_OUT, pack_small(w, range(3 + pm2), s2), np.pad(b, (0, 4 - len(b))), s2, 1, self.pk, 8)
 
     def forward(self, rgb):
         """rgb: device (or host numpy) uint8 [H,W,3] -> device fp32 (logit [H,W], text logit [H,W], rec [3,H,W])."""
