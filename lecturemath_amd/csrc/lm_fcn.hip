@@ -37,11 +37,43 @@
 #define LM_ACT_GELU 1
 #define LM_ACT_TANH 2
 
+// GELU (nn.GELU default, the erf form) = max(x, 0) - |x|/2 * erfc(|x|/sqrt 2), with erfc by Abramowitz & Stegun 7.1.26
+// (t * P5(t) * exp(-z^2), t = 1 / (1 + p z); |error| <= 1.5e-7): one v_rcp, one v_exp and nine FMAs, branch-free.  Maximum
+// absolute error against the float64 GELU over [-12, 12]: 3.3e-7 -- 0.5 x (1 + erff(x / sqrt 2)) evaluated in fp32 is off by up
+// to 4.5e-7 from its own roundings.  The library erff costs ~90 VALU instructions and 14 branches per value: in the epilogues
+// below (32-128 values per lane) it was 80 % of the convolution kernels' code and, for the thin layers, most of their time.
+LM_DEV float lm_gelu(float x)
+{
+    const float ax = fabsf(x), z = ax * 0.70710678118654752440f;
+#if LM_HIP_EMULATED
+    const float t = 1.0f / fmaf(0.3275911f, z, 1.0f);
+    const float e = exp2f(-(z * z) * 1.4426950408889634f);
+#else
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(-(z * z) * 1.4426950408889634f);
+#endif
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    return fmaxf(x, 0.0f) - 0.5f * ax * (p * t * e);
+}
+
 LM_DEV float lm_act(float v, int act)
 {
-    if (act == LM_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == LM_ACT_GELU) return lm_gelu(v);
     if (act == LM_ACT_TANH) return tanhf(v);
     return v;
+}
+
+// Epilogue helper: calls body(activation functor) with the activation resolved ONCE per kernel (the per-value run-time switch
+// kept tanhf and the GELU side by side in every unrolled store of the epilogues).
+// GELU or none: what the MFMA kernels are launched with (tanh belongs to the reconstruction head: lm_k_vsum / lm_k_conv_small).
+template <class F>
+LM_DEV void lm_with_act(int act, F body)
+{
+    if (act == LM_ACT_GELU) body([](float v) { return lm_gelu(v); });
+    else body([](float v) { return v; });
 }
 
 struct LmConvArgs {
@@ -214,7 +246,7 @@ LM_DEV void lm_cv_load_patch(const LmConvArgs& a, int ch, int ty0, int tx0, int 
 // serviced in 16-lane groups that mix lanes of two patch rows ({0-3,12-15,20-27}, ...): with the row stride a multiple of
 // the 256-B bank row the 16 lanes of a group fall on pixels 0..15 of one residue class, i.e. on 16 distinct 16-B slots
 // (5 slots per pixel, 5 coprime to 16).  Measured before the padding: 37-39 % of the LDS cycles were bank conflicts.
-LM_DEV int lm_cv_row_bytes(int PW) { return (PW * 80 + 255) & ~255; }
+LM_DEV constexpr int lm_cv_row_bytes(int PW) { return (PW * 80 + 255) & ~255; }
 
 template <int MAXP>
 LM_DEV void lm_cv_store_patch(char* s_patch, int PW, int items, const float4 (&pr)[MAXP])
@@ -266,14 +298,57 @@ LM_DEV void lm_cv_store_w(char* s_w, int n16, const uint4 (&wr)[MAXW])
     }
 }
 
+// The MFMAs of NTAPS taps with every LDS address an immediate offset from two per-lane bases (pa: the lane's pixel in the patch row
+// of the group's first tap; wl: the lane's slot in the weight buffer).  Tap tt of the group sits KW taps per kernel row:
+// (kh, kw) = (tt / KW, tt % KW) relative to the group's first tap, which must be the first tap of a kernel row.
+// Fully unrolled: the compiler is free to issue the fragment loads of the next taps under the MFMAs of the current one (the
+// run-time tap loop recomputed ~28 VALU instructions of addresses per tap and could not look across iterations).
+template <int NT, int TERMS, int NTAPS, int KW, int RB>
+LM_DEV void lm_cv_taps(const char* pa, const char* wl, lm_f32x16 (&acc)[2][NT])
+{
+#pragma unroll
+    for (int tt = 0; tt < NTAPS; tt++) {
+        const int kh = tt / KW, kw = tt - kh * KW;
+        lm_h8 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const char* pp = pa + (m * 2 + kh) * RB + kw * 80;
+            ah[m] = *(const lm_h8*)pp;
+            if (TERMS >= 2) al[m] = *(const lm_h8*)(pp + 32);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            const char* wp = wl + (tt * NT + n) * 2048;
+            bh[n] = *(const lm_h8*)wp;
+            if (TERMS >= 3) bl[n] = *(const lm_h8*)(wp + 1024);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA_F16(ah[m], bh[n], acc[m][n]);
+        if (TERMS >= 3) {
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA_F16(ah[m], bl[n], acc[m][n]);
+        }
+        if (TERMS >= 2) {
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA_F16(al[m], bh[n], acc[m][n]);
+        }
+    }
+}
+
 // taps per weight group.  Chosen so that the block's LDS (patch + two weight buffers of tg * NT * 2 KB) lets at least two
-// workgroups share a CU (three for 3x3 / NT = 1) without adding barriers: 3x3 -> 5 + 4 taps, 7x7 -> a kernel row (NT = 1) or
-// 4 taps (NT = 2); never more than LM_CV_MAXW 16-B items per thread.
+// workgroups share a CU (three for 3x3 / NT = 1): 3x3 -> a kernel row, 7x7 -> a kernel row (NT = 1) or 4 taps (NT = 2);
+// never more than LM_CV_MAXW 16-B items per thread.
 constexpr int lm_cv_tg(int K, int NT)
 {
     const int cap = (LM_CV_MAXW * 2) / NT;
     int want = K * K;
-    if (K == 3) want = (NT <= 2) ? 5 : 3;
+    if (K == 3) want = 3;       // a kernel row per group (lm_cv_taps wants groups that start a kernel row)
     else if (K >= 5) want = (NT == 1) ? K : (NT == 2 ? 4 : 2);
     return want < cap ? want : cap;
 }
@@ -337,6 +412,14 @@ __global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1) lm_k_conv_mfma_h(const
             } else if (ch + 1 < nchunks) {
                 lm_cv_load_w<NT, MAXW>(a, ch + 1, 0, a.tg < taps ? a.tg : taps, taps, nb0, wr);
             }
+            // groups of whole kernel rows (all instantiations with a compile-time side except 7x7 / NT = 2): unrolled taps
+            constexpr int TGC = KS ? (TG ? TG : lm_cv_tg(KS, NT)) : 0;
+            constexpr bool ROWS = KS && (TGC % (KS ? KS : 1) == 0);
+            if (ROWS) {
+                constexpr int RBC = lm_cv_row_bytes(16 + (KS ? KS : 1) - 1);
+                lm_cv_taps<NT, TERMS, (ROWS ? TGC : 1), (KS ? KS : 1), RBC>(s_patch + (prow + t0 / (KS ? KS : 1)) * RBC + pcol * PB + half * 16,
+                                                                              s_w + lane * 16, acc);
+            } else
             for (int tt = 0; tt < ntg; tt++) {
                 const int t = t0 + tt;
                 const int kh = t / K, kw = t - kh * K;
@@ -376,6 +459,7 @@ __global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1) lm_k_conv_mfma_h(const
         }
     }
     const int cj = lane & 31;
+    lm_with_act(a.act, [&](auto actf) {
 #pragma unroll
     for (int n = 0; n < NT; n++) {
         const int co = (nb0 + n) * 32 + cj;
@@ -388,7 +472,7 @@ __global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1) lm_k_conv_mfma_h(const
             for (int r = 0; r < 16; r++) {
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int y = ty0 + wave * 4 + m * 2 + (i >> 4), x = tx0 + (i & 15);
-                v[r] = lm_act(acc[m][n][r] + b, a.act);
+                v[r] = actf(acc[m][n][r] + b);
                 if (y >= a.H || x >= a.W) continue;
                 long long opix = a.tmode ? ((long long)(2 * y + a.dy) * a.OW + (2 * x + a.dx)) : ((long long)y * a.W + x);
                 a.out[opix * a.ops + a.ooff + co] = v[r];
@@ -407,6 +491,7 @@ __global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1) lm_k_conv_mfma_h(const
             }
         }
     }
+    });
 }
 
 // 2x2 stride-2 transposed convolution (fp16-split operands): the four (dy, dx) sub-convolutions are 1x1 GEMMs over the SAME
@@ -477,6 +562,7 @@ __global__ void __launch_bounds__(256, 2) lm_k_convT_mfma_h(const LmConvArgs a)
     const int co = nb0 * 32 + (lane & 31);
     if (co >= a.Cout) return;
     const float b = a.bias[co];
+    lm_with_act(a.act, [&](auto actf) {
 #pragma unroll
     for (int t = 0; t < TAPS; t++)
 #pragma unroll
@@ -487,8 +573,9 @@ __global__ void __launch_bounds__(256, 2) lm_k_convT_mfma_h(const LmConvArgs a)
                 const int y = ty0 + wave * 4 + m * 2 + (i >> 4), x = tx0 + (i & 15);
                 if (y >= a.H || x >= a.W) continue;
                 const long long opix = (long long)(2 * y + (t >> 1)) * a.OW + (2 * x + (t & 1));
-                a.out[opix * a.ops + a.ooff + co] = lm_act(acc[t][m][r] + b, a.act);
+                a.out[opix * a.ops + a.ooff + co] = actf(acc[t][m][r] + b);
             }
+    });
 }
 
 // rows / columns of a transposed-conv output that no input pixel reaches (output_size = 2*in + 1): act(bias)
@@ -1029,6 +1116,7 @@ static int lm_conv_layer(LmFcn* f, int layer, const float* in0, int c0, int ps0,
     a.in0 = in0; a.c0 = c0; a.ps0 = ps0; a.in1 = in1; a.c1 = c1; a.ps1 = ps1; a.H = H; a.W = W;
     a.wpk = l.w; a.bias = l.bias; a.out = out; a.ops = ops; a.ooff = ooff; a.Cout = l.cout; a.nblocks = (l.cout + 31) / 32;
     a.K = l.k; a.act = act;
+    if (l.ck <= 0 && act != LM_ACT_GELU && act != LM_ACT_NONE) { lm_set_error("lm_fcn: the fp16-split convolution kernels apply GELU or nothing"); return LM_ERR_ARG; }
     if (pool && l.ck <= 0) { a.pool = pool; a.pool_ps = l.cout; }      // the fp16-split kernel pools in its epilogue
     return lm_launch_conv(a, l.ck, st);
 }
