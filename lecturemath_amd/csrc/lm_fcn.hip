@@ -857,6 +857,50 @@ __global__ void __launch_bounds__(256) lm_k_vsum(const float* __restrict__ T, in
     }
 }
 
+// Text mask (7x7, one output) and reconstruction (3x3, three outputs) read the same input: ONE 1x7 row convolution with 16
+// outputs per pixel (0..6: text kernel rows; 7 + kh * 3 + co: reconstruction rows, their three taps centred in the seven),
+// then this kernel: text logit, rec = tanh(.), diff = (x0 - rec) * sigmoid(text) (:370-379).  bias: [0] text, [1..3] rec.
+__global__ void __launch_bounds__(256) lm_k_vsum_text_rec(const float* __restrict__ T, int H, int W, const float* __restrict__ bias,
+                                                          const float* __restrict__ x0, float* __restrict__ text, float* __restrict__ rec4,
+                                                          float* __restrict__ diff4)
+{
+    constexpr int TW = 32, TH = 16, PR = TH + 6, TS = 16, RQ = TW * TS / 4;
+    __shared__ float s_t[PR * TW * TS];         // 44 KB
+    const int tiles_x = (W + TW - 1) / TW;
+    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    for (int i = threadIdx.x; i < PR * RQ; i += blockDim.x) {
+        const int r = i / RQ, q = i - r * RQ;
+        const int y = ty0 + r - 3, x = tx0 + (q >> 2);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y >= 0 && y < H && x < W) v = *(const float4*)(T + ((long long)y * W + tx0) * TS + q * 4);
+        *(float4*)(s_t + (r * TW) * TS + q * 4) = v;
+    }
+    __syncthreads();
+    const int ly = (int)(threadIdx.x >> 4), lx = (int)(threadIdx.x & 15);
+    const int y = ty0 + ly;
+    if (y >= H) return;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int xl = lx + 16 * h, x = tx0 + xl;
+        if (x >= W) continue;
+        float t = bias[0], r0 = bias[1], r1 = bias[2], r2 = bias[3];
+#pragma unroll
+        for (int kh = 0; kh < 7; kh++) t += s_t[((ly + kh) * TW + xl) * TS + kh];
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++) {
+            const float* q = s_t + ((ly + 2 + kh) * TW + xl) * TS + 7 + kh * 3;
+            r0 += q[0]; r1 += q[1]; r2 += q[2];
+        }
+        r0 = tanhf(r0); r1 = tanhf(r1); r2 = tanhf(r2);
+        const long long p = (long long)y * W + x;
+        const float m = 1.0f / (1.0f + expf(-t));
+        const float4 xin = *(const float4*)(x0 + p * 8);
+        text[p] = t;
+        *(float4*)(rec4 + p * 4) = make_float4(r0, r1, r2, 0.f);
+        *(float4*)(diff4 + p * 4) = make_float4((xin.x - r0) * m, (xin.y - r1) * m, (xin.z - r2) * m, 0.f);
+    }
+}
+
 // diff = (x0 - rec) * sigmoid(text)  (:379), written to channels 0..2 of three NHWC buffers
 __global__ void __launch_bounds__(256) lm_k_diff(const float* __restrict__ x0, const float* __restrict__ rec4,
                                                  const float* __restrict__ text, long long npx, float* __restrict__ o0, int s0,
@@ -905,7 +949,7 @@ struct LmFcn {
     // activations (allocated for max_h x max_w)
     float *x0 = nullptr, *pre[5] = {}, *pool[5] = {}, *mid = nullptr, *up[5] = {}, *cu[5] = {};
     float *text = nullptr, *rec4 = nullptr, *px0 = nullptr, *px1 = nullptr, *px2 = nullptr, *outl = nullptr;
-    float* tbuf = nullptr;      // [pixel][12] row-convolution outputs of the heads (lm_rowconv_layer)
+    float* tbuf = nullptr;      // [pixel][16] row-convolution outputs of the heads (lm_rowconv_layer, lm_text_rec_heads)
     // MFMA-head layout (fp16-split formats, 7x7 pixel kernels): x_up1, diff and the pixel features each in a buffer of their own;
     // the (diff, features) concatenations are two-input convolutions
     float *xup = nullptr, *d4 = nullptr, *p1 = nullptr, *p2 = nullptr;
@@ -963,7 +1007,7 @@ extern "C" LmFcn* lm_fcn_create(const int32_t* widths18, int pixel_kernel, int k
     rc |= lm_fcn_alloc(f, &f->text, px[0]);
     rc |= lm_fcn_alloc(f, &f->rec4, px[0] * 4);
     rc |= lm_fcn_alloc(f, &f->outl, px[0]);
-    rc |= lm_fcn_alloc(f, &f->tbuf, px[0] * 12);
+    rc |= lm_fcn_alloc(f, &f->tbuf, px[0] * 16);
     rc |= lm_fcn_alloc(f, &f->xup, px[0] * c1);
     rc |= lm_fcn_alloc(f, &f->d4, px[0] * 4);
     rc |= lm_fcn_alloc(f, &f->p1, px[0] * pm1);
@@ -1231,6 +1275,24 @@ static int lm_rowconv_layer(LmFcn* f, int layer, const float* in0, int c0, const
     return LM_OK;
 }
 
+// Text-mask and reconstruction heads as one row convolution (layer 16 packed by fcn.pack_text_rec_rows_h: l.cout == 4) + lm_k_vsum_text_rec
+static int lm_text_rec_heads(LmFcn* f, const float* in, int C, int H, int W, hipStream_t st)
+{
+    const LmFcnLayer& l = f->layer[16];
+    if (!l.w) { lm_set_error("lm_fcn_forward: layer 16 has no weights"); return LM_ERR_STATE; }
+    LmConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in0 = in; a.c0 = C; a.ps0 = C; a.H = H; a.W = W;
+    a.wpk = l.w; a.bias = l.bias; a.out = f->tbuf; a.ops = 16; a.ooff = 0; a.Cout = 16; a.nblocks = 1;
+    a.K = 7; a.act = LM_ACT_NONE; a.terms = lm_terms_of_ck(l.ck); a.krows = 1;
+    const int rc = lm_launch_rowconv_h<7>(a, st);
+    if (rc) return rc;
+    const int tiles = ((W + 31) / 32) * ((H + 15) / 16);
+    hipLaunchKernelGGL(lm_k_vsum_text_rec, dim3(tiles), dim3(256), 0, st, f->tbuf, H, W, l.bias + 32, f->x0, f->text, f->rec4, f->d4);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
 // forward() of the non-reconstruction branch (:364-403) on one RGB frame resident on the device.
 // Outputs (device, fp32): d_out [h*w] binarization logit, d_text [h*w] text-mask logit, d_rec [3][h*w] reconstruction.
 static int lm_fcn_forward_impl(LmFcn* f, const uint8_t* d_rgb, int h, int w, float* d_out, float* d_text, float* d_rec, void* stream)
@@ -1282,8 +1344,12 @@ static int lm_fcn_forward_impl(LmFcn* f, const uint8_t* d_rgb, int h, int w, flo
     // x_up1 is not 16-byte aligned at channel offset 3, so the small kernel reads the whole (diff, x_up1) buffer with zero
     // weights on channels 0..2 (the host packs them that way)
     if (heads_mfma) {
-        if ((rc = lm_rowconv_layer(f, 16, f->xup, c1, nullptr, 0, h, w, f->text, 1, LM_ACT_NONE, false, st))) return rc;
-        if ((rc = lm_rowconv_layer(f, 17, f->xup, c1, nullptr, 0, h, w, f->rec4, 4, LM_ACT_TANH, true, st))) return rc;
+        if (f->layer[16].cout == 4) {       // text mask + reconstruction packed together
+            if ((rc = lm_text_rec_heads(f, f->xup, c1, h, w, st))) return rc;
+        } else {
+            if ((rc = lm_rowconv_layer(f, 16, f->xup, c1, nullptr, 0, h, w, f->text, 1, LM_ACT_NONE, false, st))) return rc;
+            if ((rc = lm_rowconv_layer(f, 17, f->xup, c1, nullptr, 0, h, w, f->rec4, 4, LM_ACT_TANH, true, st))) return rc;
+        }
         if ((rc = lm_conv_layer(f, 18, f->d4, 4, 4, f->xup, c1, c1, h, w, f->p1, pm1, 0, LM_ACT_GELU, st))) return rc;
         if ((rc = lm_conv_layer(f, 19, f->d4, 4, 4, f->p1, pm1, pm1, h, w, f->p2, pm2, 0, LM_ACT_GELU, st))) return rc;
         if ((rc = lm_rowconv_layer(f, 20, f->d4, 4, f->p2, pm2, h, w, f->outl, 1, LM_ACT_NONE, false, st))) return rc;

@@ -85,6 +85,16 @@ def pack_rows_h(w_oikk, cin_map, cin_logical):
     return pack_mfma_h(rows, cin_map, cin_logical)
 
 
+def pack_text_rec_rows_h(w_text, w_rec, cin_map, cin_logical):
+    """Text mask (7x7, 1 output) and reconstruction (3x3, 3 outputs) over the same input as ONE 1 x 7 row convolution with 16
+    outputs (lm_text_rec_heads): 0..6 = text kernel rows, 7 + kh * 3 + co = reconstruction rows, their taps centred (kw + 2)."""
+    cin = w_text.shape[1]
+    rows = np.zeros((16, cin, 1, 7), np.float32)
+    rows[0:7, :, 0, :] = w_text[0].transpose(1, 0, 2)                   # [ci][kh][kw] -> [kh][ci][kw]
+    rows[7:16, :, 0, 2:5] = w_rec.transpose(2, 0, 1, 3).reshape(9, cin, 3)      # [co][ci][kh][kw] -> [kh * 3 + co][ci][kw]
+    return pack_mfma_h(rows, cin_map, cin_logical)
+
+
 def pack_small(w_oikk, cin_map, cin_padded):
     """[Cout<=4][Cin][K][K] -> [chunk of 8 channels][tap][8] for Cout == 1, [chunk][tap][8][4] otherwise (lm_k_conv_small)."""
     cout, cin, k, _ = w_oikk.shape
@@ -201,10 +211,9 @@ class FcnEngine:
             def cat_map(nfeat):     # weight input channel -> logical channel of [diff(3) 0 | features]
                 return [0, 1, 2] + list(range(4, 4 + nfeat))
 
-            w, b = conv_bn("conv_text_mask_out")
-            self._set(L_TEXT, pack_rows_h(w, range(c1), c1), head_bias(b), c1, 1, self.pk, hck)
-            w, b = conv_bn("conv_reconstruct")
-            self._set(L_REC, pack_rows_h(w, range(c1), c1), head_bias(b), c1, 3, self.kk, hck)
+            wt, bt = conv_bn("conv_text_mask_out")
+            wr, br = conv_bn("conv_reconstruct")
+            self._set(L_TEXT, pack_text_rec_rows_h(wt, wr, range(c1), c1), head_bias(np.concatenate([bt, br])), c1, 4, self.pk, hck)
             w, b = conv_bn("conv_pixels_1")
             self._set(L_PX1, pack_mfma_h(w, cat_map(c1), 4 + c1), bias_pad(b), 4 + c1, pm1, self.pk, hck)
             w, b = conv_bn("conv_pixels_2")

@@ -8,9 +8,9 @@ for r in rows:
     e = d.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"], "grid": r.get("Grid_Size", ""), "lds": r.get("LDS_Block_Size", "")})
     e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 ds = [v for v in d.values() if v["name"].startswith(("lm_k", "void lm_k"))]
-per = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-if per:
-    ds = ds[-per:]
+prep = [i for i, v in enumerate(ds) if v["name"].startswith("lm_k_prepare")]
+if prep:
+    ds = ds[prep[-1]:]          # the last forward pass
 out = []
 hdr = "%-46s %9s %6s %6s %6s %6s %6s %7s %7s" % ("kernel", "waveMcyc", "park%", "istal%", "activ%", "ldsst%", "mfma%", "ldsconf", "valu/wv")
 out.append(hdr)
