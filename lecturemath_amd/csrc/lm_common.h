@@ -108,6 +108,13 @@ struct LmCtx {
 
 LM_DEV int lm_lane() { return (int)(threadIdx.x & 63); }
 
+// a value that is the same in every lane of the wave, said so to the compiler (scalar registers, scalar address arithmetic)
+#if LM_HIP_EMULATED
+#define LM_UNIFORM(x) (x)
+#else
+#define LM_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
 template <class T> LM_DEV T lm_wave_incl_scan(T v)
 {
     int lane = lm_lane();

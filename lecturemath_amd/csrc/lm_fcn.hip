@@ -458,35 +458,44 @@ __global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1) lm_k_conv_mfma_h(const
             buf ^= 1;
         }
     }
+    // Epilogue.  D[row i = (r & 3) + 8 * (r >> 2) + 4 * half][col = lane & 31]: row = pixel of the 32-px block (image row i >> 4,
+    // column i & 15), col = channel.  Everything of a store address except the lane's own part (its half and its channel) is the same
+    // for the whole wave, so it is kept in scalar registers: per value the VALU does the bias, the activation and nothing else (with
+    // per-value 64-bit index arithmetic and bounds checks the epilogue was ~45 vector instructions per value -- half of the first
+    // layer's wave time was instruction issue).
     const int cj = lane & 31;
+    const int y_w = ty0 + LM_UNIFORM(wave) * 4;                     // first of the wave's four image rows
+    const bool full = (ty0 + 16 <= a.H) && (tx0 + 16 <= a.W);       // interior tile: no bounds checks
+    const int rs = a.W * a.ops;                                     // floats per image row
+    float* const wbase = a.out + ((long long)y_w * a.W + tx0) * a.ops + a.ooff;
+    const int OH = a.H >> 1, OW = a.W >> 1;
+    float* const pbase = a.pool ? a.pool + ((long long)(y_w >> 1) * OW + (tx0 >> 1)) * a.pool_ps : nullptr;
     lm_with_act(a.act, [&](auto actf) {
 #pragma unroll
     for (int n = 0; n < NT; n++) {
         const int co = (nb0 + n) * 32 + cj;
         if (nb0 + n >= a.nblocks || co >= a.Cout) continue;
         const float b = a.bias[co];
+        const int loff = 4 * half * a.ops + co;                     // the lane's part of the address (floats)
 #pragma unroll
         for (int m = 0; m < 2; m++) {
             float v[16];
 #pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = actf(acc[m][n][r] + b);
+#pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int y = ty0 + wave * 4 + m * 2 + (i >> 4), x = tx0 + (i & 15);
-                v[r] = actf(acc[m][n][r] + b);
-                if (y >= a.H || x >= a.W) continue;
-                long long opix = a.tmode ? ((long long)(2 * y + a.dy) * a.OW + (2 * x + a.dx)) : ((long long)y * a.W + x);
-                a.out[opix * a.ops + a.ooff + co] = v[r];
+                const int row = m * 2 + (r >> 3), c0 = (r & 3) + 8 * ((r >> 2) & 1);       // compile-time
+                if (full || (y_w + row < a.H && tx0 + c0 + 4 * half < a.W)) (wbase + (row * rs + c0 * a.ops))[loff] = v[r];
             }
             // 2x2 max pooling from registers: accumulator rows r, r + 1 are neighbouring columns of the block's first image row,
             // r + 8, r + 9 the same columns of its second (the block's two rows start at an even y, tiles at an even x)
-            if (a.pool) {
-                const int OH = a.H >> 1, OW = a.W >> 1;
-                const int py = (ty0 + wave * 4 + m * 2) >> 1;
+            if (pbase) {
+                const int ploff = 2 * half * a.pool_ps + co;
 #pragma unroll
                 for (int r = 0; r < 8; r += 2) {
-                    const int px = (tx0 + (r & 3) + 8 * (r >> 2) + 4 * half) >> 1;
-                    if (py < OH && px < OW)
-                        a.pool[((long long)py * OW + px) * a.pool_ps + co] = fmaxf(fmaxf(v[r], v[r + 1]), fmaxf(v[r + 8], v[r + 9]));
+                    const int pc0 = ((r & 3) + 8 * ((r >> 2) & 1)) >> 1;
+                    if (full || ((y_w >> 1) + m < OH && (tx0 >> 1) + pc0 + 2 * half < OW))
+                        (pbase + ((long long)m * OW + pc0) * a.pool_ps)[ploff] = fmaxf(fmaxf(v[r], v[r + 1]), fmaxf(v[r + 8], v[r + 9]));
                 }
             }
         }
@@ -562,6 +571,12 @@ __global__ void __launch_bounds__(256, 2) lm_k_convT_mfma_h(const LmConvArgs a)
     const int co = nb0 * 32 + (lane & 31);
     if (co >= a.Cout) return;
     const float b = a.bias[co];
+    // input pixel (y, x) -> output pixels (2y + dy, 2x + dx); address split as in lm_k_conv_mfma_h: uniform part in scalar registers
+    const int y_w = ty0 + LM_UNIFORM(wave) * 4;
+    const bool full = (ty0 + 16 <= a.H) && (tx0 + 16 <= a.W);
+    const int rs = a.OW * a.ops;
+    float* const wbase = a.out + ((long long)(2 * y_w) * a.OW + 2 * tx0) * a.ops + a.ooff;
+    const int loff = 8 * half * a.ops + co;
     lm_with_act(a.act, [&](auto actf) {
 #pragma unroll
     for (int t = 0; t < TAPS; t++)
@@ -569,11 +584,9 @@ __global__ void __launch_bounds__(256, 2) lm_k_convT_mfma_h(const LmConvArgs a)
         for (int m = 0; m < 2; m++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int y = ty0 + wave * 4 + m * 2 + (i >> 4), x = tx0 + (i & 15);
-                if (y >= a.H || x >= a.W) continue;
-                const long long opix = (long long)(2 * y + (t >> 1)) * a.OW + (2 * x + (t & 1));
-                a.out[opix * a.ops + a.ooff + co] = actf(acc[t][m][r] + b);
+                const int row = m * 2 + (r >> 3), c0 = (r & 3) + 8 * ((r >> 2) & 1);
+                if (full || (y_w + row < a.H && tx0 + c0 + 4 * half < a.W))
+                    (wbase + ((2 * row + (t >> 1)) * rs + (2 * c0 + (t & 1)) * a.ops))[loff] = actf(acc[t][m][r] + b);
             }
     });
 }
