@@ -339,12 +339,18 @@ def check_step01_entry_points(lib, tmp_dir, name="k7_70x94", n_frames=3, tool=Tr
     s01 = script("pre_ST3D_v3.0_01_binarize.py")
     process = types.SimpleNamespace(configuration=Configuration.from_file(conf_path), params={})
     worker = s01.get_worker(process)
-    h, w = g["rgb"].shape[:2]
-    worker.initialize(w, h)
-    bgr = np.ascontiguousarray(g["rgb"][:, :, ::-1])
+    # the frames come from an exported-lecture folder through the image-list frame source, as
+    # ConsoleUIProcess.start_image_list_preprocessing (console_ui_process.py:188-221) wires it
+    import json
+    from AccessMath.preprocessing.video_processor.image_list_processor import ImageListProcessor
+    img_dir = os.path.join(tmp_dir, "export", "JPEGImages")
+    os.makedirs(img_dir, exist_ok=True)
     for k in range(n_frames):
-        worker.handleFrame(bgr, None, 0, 1000.0 * (k + 1), 1000.0 * (k + 1), 30 * (k + 1))
-    worker.finalize()
+        PIL.Image.fromarray(g["rgb"]).save(os.path.join(img_dir, "%d.png" % (30 * (k + 1))))
+    with open(os.path.join(img_dir, "index.json"), "w") as f:
+        json.dump({str(30 * (k + 1)): {"video_time": 0.0, "frame_idx": 30 * (k + 1), "abs_time": 1000.0 * (k + 1), "video_idx": 0}
+                   for k in range(n_frames)}, f)
+    ImageListProcessor(os.path.join(tmp_dir, "export"), img_extension=".png").doProcessing(worker)
     times, indices, compressed = s01.get_results(worker)
     assert times == [1000.0 * (k + 1) for k in range(n_frames)] and indices == [30 * (k + 1) for k in range(n_frames)]
     assert len(compressed) == n_frames and not hasattr(worker, "lecture_net")

@@ -50,3 +50,13 @@ def resize(img, size, interpolation=INTER_NEAREST):
 def imwrite(path, img):
     Image.fromarray(img if img.ndim == 2 else img[:, :, ::-1]).save(path)
     return True
+
+
+def imread(path, flag=IMREAD_COLOR):
+    try:
+        im = Image.open(path)
+    except (FileNotFoundError, OSError):
+        return None
+    if flag == IMREAD_GRAYSCALE:
+        return np.array(im.convert("L"))
+    return np.array(im.convert("RGB"))[:, :, ::-1].copy()
