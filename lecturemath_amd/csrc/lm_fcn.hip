@@ -1121,6 +1121,13 @@ template <int NT> static int lm_launch_conv_h(const LmConvArgs& a, hipStream_t s
 {
     if (a.K > 7) { lm_set_error("lm_fcn: kernel side %d not supported by the fp16-split convolution (<= 7)", a.K); return LM_ERR_ARG; }
     const int blocks = ((a.W + 15) / 16) * ((a.H + 15) / 16) * ((a.nblocks + NT - 1) / NT);
+    // two n-blocks per wave exist for 3x3 kernels only (every layer of the shipped network with >= 64 output channels is 3x3);
+    // the other sides run one n-block per wave -- a third fewer instantiations of the kernel template to compile
+    if constexpr (NT != 1) {
+        (void)blocks;
+        if (a.K != 3) { lm_set_error("lm_fcn: two n-blocks per wave are built for 3x3 kernels only"); return LM_ERR_ARG; }
+        return lm_launch_conv_hk<NT, 3>(a, st);
+    } else
     switch (a.K) {
         case 1: return lm_launch_conv_hk<NT, 1>(a, st);
         case 3:
@@ -1143,7 +1150,7 @@ static int lm_launch_conv(const LmConvArgs& a0, int ck, hipStream_t st)
         // two n-blocks per wave when the channel blocks divide evenly and the grid still has >= 1.5 workgroups per CU (four
         // would need 128 accumulator registers: one wave per SIMD, measured slower)
         const int tiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
-        if (a.nblocks % 2 == 0 && tiles * (a.nblocks / 2) >= 384) return lm_launch_conv_h<2>(a, st);
+        if (a.K == 3 && a.nblocks % 2 == 0 && tiles * (a.nblocks / 2) >= 384) return lm_launch_conv_h<2>(a, st);
         return lm_launch_conv_h<1>(a, st);
     }
     // n-blocks per wave: as many as fit 160 KiB of LDS and divide the channel blocks evenly -- but the deep layers have few
