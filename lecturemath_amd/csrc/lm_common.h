@@ -108,6 +108,13 @@ struct LmCtx {
 
 LM_DEV int lm_lane() { return (int)(threadIdx.x & 63); }
 
+// hides a register's value from the optimiser at this point (stops loop-invariant code motion of what is derived from it)
+#if LM_HIP_EMULATED
+#define LM_OPAQUE(x) ((void)0)
+#else
+#define LM_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+
 // a value that is the same in every lane of the wave, said so to the compiler (scalar registers, scalar address arithmetic)
 #if LM_HIP_EMULATED
 #define LM_UNIFORM(x) (x)

@@ -303,7 +303,7 @@ LM_DEV void lm_cv_store_w(char* s_w, int n16, const uint4 (&wr)[MAXW])
 // (kh, kw) = (tt / KW, tt % KW) relative to the group's first tap, which must be the first tap of a kernel row.
 // Fully unrolled: the compiler is free to issue the fragment loads of the next taps under the MFMAs of the current one (the
 // run-time tap loop recomputed ~28 VALU instructions of addresses per tap and could not look across iterations).
-template <int NT, int TERMS, int NTAPS, int KW, int RB>
+template <int NT, int TERMS, int NTAPS, int KW, int RB, bool SWAP>
 LM_DEV void lm_cv_taps(const char* pa, const char* wl, lm_f32x16 (&acc)[2][NT])
 {
 #pragma unroll
@@ -325,18 +325,18 @@ LM_DEV void lm_cv_taps(const char* pa, const char* wl, lm_f32x16 (&acc)[2][NT])
 #pragma unroll
         for (int m = 0; m < 2; m++)
 #pragma unroll
-            for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA_F16(ah[m], bh[n], acc[m][n]);
+            for (int n = 0; n < NT; n++) acc[m][n] = SWAP ? LM_MFMA_F16(bh[n], ah[m], acc[m][n]) : LM_MFMA_F16(ah[m], bh[n], acc[m][n]);
         if (TERMS >= 3) {
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
-                for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA_F16(ah[m], bl[n], acc[m][n]);
+                for (int n = 0; n < NT; n++) acc[m][n] = SWAP ? LM_MFMA_F16(bl[n], ah[m], acc[m][n]) : LM_MFMA_F16(ah[m], bl[n], acc[m][n]);
         }
         if (TERMS >= 2) {
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
-                for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA_F16(al[m], bh[n], acc[m][n]);
+                for (int n = 0; n < NT; n++) acc[m][n] = SWAP ? LM_MFMA_F16(bh[n], al[m], acc[m][n]) : LM_MFMA_F16(al[m], bh[n], acc[m][n]);
         }
     }
 }
@@ -357,7 +357,8 @@ constexpr int lm_cv_tg(int K, int NT)
 // TERMS: products per pair of operands.  3 = hi.hi + hi.lo + lo.hi (the "f16x3" format above, ~22 bits per operand);
 // 2 = hi.hi + lo.hi (activations split, weights rounded to f16); 1 = hi.hi (both operands rounded to f16).
 // KH: kernel rows known at compile time (1: a 1 x KS row convolution, see lm_rowconv_layer), 0 = KS (square kernel)
-template <int NT, int KS, int TG = 0, int TERMS = 3, int KH = 0>     // TG: taps per weight group, 0 = lm_cv_tg(KS, NT)
+// SWAP: the weights are the MFMA's A operand and the pixels its B operand (see the second epilogue below): layers with <= 16 outputs
+template <int NT, int KS, int TG = 0, int TERMS = 3, int KH = 0, bool SWAP = false>     // TG: taps per weight group, 0 = lm_cv_tg(KS, NT)
 __global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1) lm_k_conv_mfma_h(const LmConvArgs a)      // two waves per SIMD whenever the accumulators allow
 {
     LM_DYN_SMEM(smem);
@@ -415,9 +416,10 @@ __global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1) lm_k_conv_mfma_h(const
             // groups of whole kernel rows (all instantiations with a compile-time side except 7x7 / NT = 2): unrolled taps
             constexpr int TGC = KS ? (TG ? TG : lm_cv_tg(KS, NT)) : 0;
             constexpr bool ROWS = KS && (TGC % (KS ? KS : 1) == 0);
+            static_assert(!SWAP || ROWS, "the swapped operand order is built for the unrolled row groups only");
             if (ROWS) {
                 constexpr int RBC = lm_cv_row_bytes(16 + (KS ? KS : 1) - 1);
-                lm_cv_taps<NT, TERMS, (ROWS ? TGC : 1), (KS ? KS : 1), RBC>(s_patch + (prow + t0 / (KS ? KS : 1)) * RBC + pcol * PB + half * 16,
+                lm_cv_taps<NT, TERMS, (ROWS ? TGC : 1), (KS ? KS : 1), RBC, SWAP>(s_patch + (prow + t0 / (KS ? KS : 1)) * RBC + pcol * PB + half * 16,
                                                                               s_w + lane * 16, acc);
             } else
             for (int tt = 0; tt < ntg; tt++) {
@@ -441,23 +443,24 @@ __global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1) lm_k_conv_mfma_h(const
 #pragma unroll
                 for (int m = 0; m < 2; m++)
 #pragma unroll
-                    for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA_F16(ah[m], bh[n], acc[m][n]);
+                    for (int n = 0; n < NT; n++) acc[m][n] = SWAP ? LM_MFMA_F16(bh[n], ah[m], acc[m][n]) : LM_MFMA_F16(ah[m], bh[n], acc[m][n]);
                 if (TERMS >= 3) {
 #pragma unroll
                     for (int m = 0; m < 2; m++)
 #pragma unroll
-                        for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA_F16(ah[m], bl[n], acc[m][n]);
+                        for (int n = 0; n < NT; n++) acc[m][n] = SWAP ? LM_MFMA_F16(bl[n], ah[m], acc[m][n]) : LM_MFMA_F16(ah[m], bl[n], acc[m][n]);
                 }
                 if (TERMS >= 2) {
 #pragma unroll
                     for (int m = 0; m < 2; m++)
 #pragma unroll
-                        for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA_F16(al[m], bh[n], acc[m][n]);
+                        for (int n = 0; n < NT; n++) acc[m][n] = SWAP ? LM_MFMA_F16(bh[n], al[m], acc[m][n]) : LM_MFMA_F16(al[m], bh[n], acc[m][n]);
                 }
             }
             buf ^= 1;
         }
     }
+    if constexpr (!SWAP) {
     // Epilogue.  D[row i = (r & 3) + 8 * (r >> 2) + 4 * half][col = lane & 31]: row = pixel of the 32-px block (image row i >> 4,
     // column i & 15), col = channel.  Everything of a store address except the lane's own part (its half and its channel) is the same
     // for the whole wave, so it is kept in scalar registers: per value the VALU does the bias, the activation and nothing else (with
@@ -501,6 +504,47 @@ __global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1) lm_k_conv_mfma_h(const
         }
     }
     });
+    } else {
+    // Epilogue (SWAP).  The weights are the MFMA's A operand and the pixels its B operand, so D[row = channel][col = pixel]: a lane owns ONE
+    // pixel of each 32-px block (lane & 31: image row >> 4, column & 15) and, in registers 4k .. 4k + 3, the four CONSECUTIVE channels
+    // 8k + 4 * half + (0..3) -- 16 contiguous bytes of the NHWC output, one global_store_dwordx4.  Measured per layer against the
+    // other operand order (a lane = one channel of 16 pixels, dword stores that cover whole 128-B lines per instruction): faster where
+    // a pixel has <= 16 outputs (half of those dword stores' lanes are idle: pixel layer 2 755 -> 671 us, head rows 152 -> 125), slower
+    // for 32+ outputs (32-B pieces of 32 different lines per instruction) -- so only those layers are launched this way.
+    const int y_w = ty0 + LM_UNIFORM(wave) * 4;                     // first of the wave's four image rows
+    const bool full = (ty0 + 16 <= a.H) && (tx0 + 16 <= a.W);       // interior tile: no bounds checks
+    const int prow_l = pi >> 4, pcol_l = pi & 15;                    // the lane's pixel inside a block
+    const bool vec = (((a.ops | a.ooff) & 3) == 0) && ((((uintptr_t)a.out) & 15) == 0);
+    const int cout4 = (a.Cout + 3) & ~3;
+    float* const wbase = a.out + ((long long)y_w * a.W + tx0) * a.ops + a.ooff;       // wave-uniform
+    const int loff = (prow_l * a.W + pcol_l) * a.ops + 4 * half;                       // the lane's part (floats)
+    lm_with_act(a.act, [&](auto actf) {
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+        if (nb0 + n >= a.nblocks) continue;
+        const int cb = (nb0 + n) * 32 + 4 * half;                   // the lane's first channel of group k = 0
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const bool inb = full || (y_w + m * 2 + prow_l < a.H && tx0 + pcol_l < a.W);
+            float* const prow_p = wbase + (m * 2) * a.W * a.ops + loff;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int ch = cb + 8 * k;
+                if (ch >= cout4) continue;
+                const float4 b4 = *(const float4*)(a.bias + ch);
+                float4 v;
+                v.x = actf(acc[m][n][4 * k + 0] + b4.x); v.y = actf(acc[m][n][4 * k + 1] + b4.y);
+                v.z = actf(acc[m][n][4 * k + 2] + b4.z); v.w = actf(acc[m][n][4 * k + 3] + b4.w);
+                if (inb) {
+                    float* dst = prow_p + (nb0 + n) * 32 + 8 * k;
+                    if (vec) *(float4*)dst = v;
+                    else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
+                }
+            }
+        }
+    }
+    });
+    }
 }
 
 // 2x2 stride-2 transposed convolution (fp16-split operands): the four (dy, dx) sub-convolutions are 1x1 GEMMs over the SAME
@@ -1082,7 +1126,7 @@ static size_t lm_conv_smem_h(int K, int NT)
     return (size_t)P * (((size_t)P * 80 + 255) & ~(size_t)255) + 2 * (size_t)lm_conv_tg_h(K, NT) * NT * 2048;   // rows padded to 256 B, weights double-buffered
 }
 
-template <int NT, int KS, int TG, int TERMS, int KH = 0> static int lm_launch_conv_hkt(const LmConvArgs& a, hipStream_t st)
+template <int NT, int KS, int TG, int TERMS, int KH = 0, bool SWAP = false> static int lm_launch_conv_hkt(const LmConvArgs& a, hipStream_t st)
 {
     const int tg = TG ? TG : lm_conv_tg_h(a.K, NT);
     const int P = 16 + a.K - 1, PR = 16 + (KH ? KH : a.K) - 1;
@@ -1090,14 +1134,14 @@ template <int NT, int KS, int TG, int TERMS, int KH = 0> static int lm_launch_co
 #if !LM_HIP_EMULATED
     static size_t configured = 0;
     if (smem > configured) {
-        LM_HIP(hipFuncSetAttribute((const void*)lm_k_conv_mfma_h<NT, KS, TG, TERMS, KH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        LM_HIP(hipFuncSetAttribute((const void*)lm_k_conv_mfma_h<NT, KS, TG, TERMS, KH, SWAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         configured = smem;
     }
 #endif
     const int tiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
     LmConvArgs b = a;
     b.tg = tg;
-    hipLaunchKernelGGL((lm_k_conv_mfma_h<NT, KS, TG, TERMS, KH>), dim3(tiles, (a.nblocks + NT - 1) / NT), dim3(256), smem, st, b);
+    hipLaunchKernelGGL((lm_k_conv_mfma_h<NT, KS, TG, TERMS, KH, SWAP>), dim3(tiles, (a.nblocks + NT - 1) / NT), dim3(256), smem, st, b);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }
@@ -1105,9 +1149,9 @@ template <int NT, int KS, int TG, int TERMS, int KH = 0> static int lm_launch_co
 // 1 x K row convolution (one n-block), see lm_rowconv_layer
 template <int KS> static int lm_launch_rowconv_h(const LmConvArgs& a, hipStream_t st)
 {
-    if (a.terms == 1) return lm_launch_conv_hkt<1, KS, 0, 1, 1>(a, st);
-    if (a.terms == 2) return lm_launch_conv_hkt<1, KS, 0, 2, 1>(a, st);
-    return lm_launch_conv_hkt<1, KS, 0, 3, 1>(a, st);
+    if (a.terms == 1) return lm_launch_conv_hkt<1, KS, 0, 1, 1, true>(a, st);
+    if (a.terms == 2) return lm_launch_conv_hkt<1, KS, 0, 2, 1, true>(a, st);
+    return lm_launch_conv_hkt<1, KS, 0, 3, 1, true>(a, st);
 }
 
 template <int NT, int KS, int TG = 0> static int lm_launch_conv_hk(const LmConvArgs& a, hipStream_t st)
@@ -1135,7 +1179,13 @@ template <int NT> static int lm_launch_conv_h(const LmConvArgs& a, hipStream_t s
             // per chunk); many workgroups: 5 + 4 taps, three workgroups per CU
             if (NT == 1 && blocks < 1000) return lm_launch_conv_hk<NT, 3, (NT == 1) ? 9 : 0>(a, st);
             return lm_launch_conv_hk<NT, 3>(a, st);
-        case 7: return lm_launch_conv_hk<NT, 7>(a, st);
+        case 7:
+            if (a.Cout <= 16 && !a.pool && ((a.ops | a.ooff) & 3) == 0) {       // 16-byte stores (SWAP)
+                if (a.terms == 1) return lm_launch_conv_hkt<1, 7, 0, 1, 0, true>(a, st);
+                if (a.terms == 2) return lm_launch_conv_hkt<1, 7, 0, 2, 0, true>(a, st);
+                return lm_launch_conv_hkt<1, 7, 0, 3, 0, true>(a, st);
+            }
+            return lm_launch_conv_hk<NT, 7>(a, st);
         default: return lm_launch_conv_hk<NT, 0>(a, st);
     }
 }
