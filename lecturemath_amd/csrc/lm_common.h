@@ -115,6 +115,13 @@ LM_DEV int lm_lane() { return (int)(threadIdx.x & 63); }
 #define LM_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 
+// a line the instruction scheduler may not move anything across
+#if LM_HIP_EMULATED
+#define LM_SCHED_BARRIER() ((void)0)
+#else
+#define LM_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 // a value that is the same in every lane of the wave, said so to the compiler (scalar registers, scalar address arithmetic)
 #if LM_HIP_EMULATED
 #define LM_UNIFORM(x) (x)
