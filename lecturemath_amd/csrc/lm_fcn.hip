@@ -1200,7 +1200,8 @@ static int lm_launch_conv(const LmConvArgs& a0, int ck, hipStream_t st)
         // two n-blocks per wave when the channel blocks divide evenly and the grid still has >= 1.5 workgroups per CU (four
         // would need 128 accumulator registers: one wave per SIMD, measured slower)
         const int tiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
-        if (a.K == 3 && a.nblocks % 2 == 0 && tiles * (a.nblocks / 2) >= 384) return lm_launch_conv_h<2>(a, st);
+        static const int nt2_min = [] { const char* e = getenv("LM_FCN_NT2_MIN_BLOCKS"); return e ? atoi(e) : 384; }();     // tuning experiments
+        if (a.K == 3 && a.nblocks % 2 == 0 && tiles * (a.nblocks / 2) >= nt2_min) return lm_launch_conv_h<2>(a, st);
         return lm_launch_conv_h<1>(a, st);
     }
     // n-blocks per wave: as many as fit 160 KiB of LDS and divide the channel blocks evenly -- but the deep layers have few
