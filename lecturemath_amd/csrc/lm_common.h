@@ -115,6 +115,15 @@ LM_DEV int lm_lane() { return (int)(threadIdx.x & 63); }
 #define LM_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 
+// All lanes of the wave have executed what precedes (data exchange through LDS inside ONE wave).  The hardware runs a wave in
+// lockstep and serves its LDS instructions in order, so this is a compiler fence there; the CPU emulator runs the lanes one after
+// another and needs a real rendezvous (a wave collective).
+#if LM_HIP_EMULATED
+#define LM_WAVE_SYNC() ((void)__ballot(1))
+#else
+#define LM_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
 // a line the instruction scheduler may not move anything across
 #if LM_HIP_EMULATED
 #define LM_SCHED_BARRIER() ((void)0)

@@ -473,26 +473,50 @@ __global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1) lm_k_conv_mfma_h(const
     float* const wbase = a.out + ((long long)y_w * a.W + tx0) * a.ops + a.ooff;
     const int OH = a.H >> 1, OW = a.W >> 1;
     float* const pbase = a.pool ? a.pool + ((long long)(y_w >> 1) * OW + (tx0 >> 1)) * a.pool_ps : nullptr;
+    // Stores.  A lane holds ONE channel of 16 pixels, so written straight from the registers a pixel's 128 bytes come from 32 lanes
+    // as dword stores -- measured, those run at ~2.4 TB/s over the chip (64 cycles of a CU's memory pipeline per wave instruction),
+    // less than half of what 16-byte stores reach.  So each wave turns its 32 px x 32 ch block around in LDS (its own 4.5 KB of the
+    // patch area, rows padded to 36 floats) and writes it as four global_store_dwordx4, every instruction 8 whole pixels (1 KB
+    // contiguous when the buffer is exactly 32 channels wide).  Same wave, in-order LDS: no barrier between its writes and reads.
+    const bool tvec = (((a.ops | a.ooff) & 3) == 0) && ((((uintptr_t)a.out) & 15) == 0);
+    float* const s_tr = (float*)smem + LM_UNIFORM(wave) * (32 * 36);
+    if (tvec) lm_lds_barrier();         // everybody is done with the patch and the weights
     lm_with_act(a.act, [&](auto actf) {
 #pragma unroll
     for (int n = 0; n < NT; n++) {
+        if (nb0 + n >= a.nblocks) continue;
         const int co = (nb0 + n) * 32 + cj;
-        if (nb0 + n >= a.nblocks || co >= a.Cout) continue;
-        const float b = a.bias[co];
+        const bool cvalid = co < a.Cout;
+        const float b = cvalid ? a.bias[co] : 0.0f;
         const int loff = 4 * half * a.ops + co;                     // the lane's part of the address (floats)
 #pragma unroll
         for (int m = 0; m < 2; m++) {
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) v[r] = actf(acc[m][n][r] + b);
+            if (tvec) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) s_tr[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + cj] = v[r];
+                LM_WAVE_SYNC();
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int p = q * 8 + (lane >> 3), ch4 = (lane & 7) * 4;
+                    const float4 t = *(const float4*)(s_tr + p * 36 + ch4);
+                    const int row = m * 2 + (p >> 4), col = p & 15;
+                    if ((nb0 + n) * 32 + ch4 < a.Cout && (full || (y_w + row < a.H && tx0 + col < a.W)))
+                        *(float4*)(wbase + (row * rs + col * a.ops) + (nb0 + n) * 32 + ch4) = t;
+                }
+                LM_WAVE_SYNC();         // the block has been read before the next one is written
+            } else if (cvalid) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = m * 2 + (r >> 3), c0 = (r & 3) + 8 * ((r >> 2) & 1);       // compile-time
                 if (full || (y_w + row < a.H && tx0 + c0 + 4 * half < a.W)) (wbase + (row * rs + c0 * a.ops))[loff] = v[r];
             }
+            }
             // 2x2 max pooling from registers: accumulator rows r, r + 1 are neighbouring columns of the block's first image row,
             // r + 8, r + 9 the same columns of its second (the block's two rows start at an even y, tiles at an even x)
-            if (pbase) {
+            if (pbase && cvalid) {
                 const int ploff = 2 * half * a.pool_ps + co;
 #pragma unroll
                 for (int r = 0; r < 8; r += 2) {
