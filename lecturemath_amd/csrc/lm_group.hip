@@ -976,6 +976,30 @@ struct LmPhaseTimer {
     }
 };
 
+// Host loops of step 03 that write disjoint ranges (entry lists, conflict rows) run on a few threads: with 10,000 frames they
+// were 24 + 25 of the 130 ms of lm_group_run.  fn(part, parts) is called once per part; parts == 1 runs inline.
+template <class F>
+static void lm_host_parts(int parts, F fn)
+{
+    if (parts <= 1) { fn(0, 1); return; }
+    std::vector<std::thread> th;
+    th.reserve((size_t)parts - 1);
+    for (int p = 1; p < parts; p++) th.emplace_back([&fn, p, parts] { fn(p, parts); });
+    fn(0, parts);
+    for (auto& t : th) t.join();
+}
+
+static int lm_host_threads(long long items)
+{
+    static const int forced = [] { const char* e = getenv("LM_GROUP_THREADS"); return (e && atoi(e) > 0) ? atoi(e) : 0; }();    // tests: any size
+    if (forced) return forced;
+    static const int hw = [] {
+        const unsigned n = std::thread::hardware_concurrency();
+        return (int)(n >= 16 ? 8 : (n >= 4 ? n / 2 : 1));
+    }();
+    return items < (1 << 16) ? 1 : hw;
+}
+
 static inline unsigned lm_gblocks(long long items, int per_block, unsigned max_blocks)
 {
     if (LM_HIP_EMULATED) return 2;
@@ -1019,13 +1043,23 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
     for (int u = 0; u < nU0; u++) cnt[(size_t)u + 1] += cnt[u];
     std::vector<int32_t> lst(ncc1), lst_frame(ncc1);       // entries of all uniques back to back, and their frames
     {
+        // counting sort by unique; part p owns the uniques whose entries lie in its share of `lst` and scans all CCs for them
         std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
-        for (int f = 0; f < F; f++)
-            for (long long c = h_foff[f]; c < h_foff[f + 1]; c++) {
-                const int64_t p = pos[cc_assign[(size_t)c]]++;
-                lst[(size_t)p] = (int32_t)c;
-                lst_frame[(size_t)p] = f;
-            }
+        const int parts = lm_host_threads(n_cc);
+        lm_host_parts(parts, [&](int part, int nparts) {
+            const int64_t e0 = (int64_t)n_cc * part / nparts, e1 = (int64_t)n_cc * (part + 1) / nparts;
+            const int u0 = (int)(std::lower_bound(cnt.begin(), cnt.begin() + nU0, e0) - cnt.begin());
+            const int u1 = (part + 1 == nparts) ? nU0 : (int)(std::lower_bound(cnt.begin(), cnt.begin() + nU0, e1) - cnt.begin());
+            if (u0 >= u1) return;
+            for (int f = 0; f < F; f++)
+                for (long long c = h_foff[f]; c < h_foff[f + 1]; c++) {
+                    const int a = cc_assign[(size_t)c];
+                    if (a < u0 || a >= u1) continue;
+                    const int64_t p = pos[(size_t)a]++;
+                    lst[(size_t)p] = (int32_t)c;
+                    lst_frame[(size_t)p] = f;
+                }
+        });
     }
     tm.mark("entry lists");
     // ---- split_stable_cc_by_gaps (:181-228)
@@ -1335,17 +1369,23 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         const size_t ntot = ents.size();
         g->conf_g1.resize(ntot); g->conf_g2.resize(ntot); g->conf_matched.resize(ntot); g->conf_unmatched.resize(ntot);
         g->conf_union.resize(ntot); g->conf_inter.resize(ntot);
-        for (int x = 0; x < nG; x++) {
-            if (coff[(size_t)x + 1] - coff[x] > 1)
-                std::sort(ents.begin() + coff[x], ents.begin() + coff[(size_t)x + 1], [](const Ent& a, const Ent& b) { return a.first < b.first; });
-            for (int64_t i = coff[x]; i < coff[(size_t)x + 1]; i++) {
-                const Ent& e = ents[(size_t)i];
-                const LmConfRow& r = h_rows[e.row];
-                g->conf_g1[(size_t)i] = x; g->conf_g2[(size_t)i] = e.g2; g->conf_matched[(size_t)i] = (int64_t)r.matched;
-                g->conf_unmatched[(size_t)i] = (int64_t)r.unmatched; g->conf_union[(size_t)i] = (int64_t)r.uni;
-                g->conf_inter[(size_t)i] = (double)(int64_t)r.inter;
+        lm_host_parts(lm_host_threads((long long)ntot), [&](int part, int nparts) {
+            // groups whose rows start inside this part's share of the output
+            const int64_t e0 = (int64_t)ntot * part / nparts, e1 = (int64_t)ntot * (part + 1) / nparts;
+            const int x0 = (int)(std::lower_bound(coff.begin(), coff.begin() + nG, e0) - coff.begin());
+            const int x1 = (part + 1 == nparts) ? nG : (int)(std::lower_bound(coff.begin(), coff.begin() + nG, e1) - coff.begin());
+            for (int x = x0; x < x1; x++) {
+                if (coff[(size_t)x + 1] - coff[x] > 1)
+                    std::sort(ents.begin() + coff[x], ents.begin() + coff[(size_t)x + 1], [](const Ent& a, const Ent& b) { return a.first < b.first; });
+                for (int64_t i = coff[x]; i < coff[(size_t)x + 1]; i++) {
+                    const Ent& e = ents[(size_t)i];
+                    const LmConfRow& r = h_rows[e.row];
+                    g->conf_g1[(size_t)i] = x; g->conf_g2[(size_t)i] = e.g2; g->conf_matched[(size_t)i] = (int64_t)r.matched;
+                    g->conf_unmatched[(size_t)i] = (int64_t)r.unmatched; g->conf_union[(size_t)i] = (int64_t)r.uni;
+                    g->conf_inter[(size_t)i] = (double)(int64_t)r.inter;
+                }
             }
-        }
+        });
     }
     tm.mark("conflicts");
     // ---- group images (:575-636): item = (group, age segment); boxes and offsets here, member / tile tables on the device

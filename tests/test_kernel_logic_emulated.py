@@ -134,6 +134,22 @@ def test_grouping_golden_short_gap(emu_lib):
     lm_checks.check_grouping_golden(emu_lib, "short_gap_jitter")
 
 
+def test_grouping_golden_host_threads(emu_lib):
+    """lm_group_run splits its two largest host loops (entry lists, conflict rows) over threads on long lectures; here the split
+    is forced (LM_GROUP_THREADS, read once per process: a child) on a short stream, more parts than some ranges have items."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+             "import lm_checks\nfrom lecturemath_amd import _lib\n"
+             "lib = _lib.load(%r)\n"
+             "lm_checks.check_grouping_golden(lib, 'short_gap_jitter')\nprint('threads ok')\n") % (
+                 root, os.path.join(root, "tests"), emu_lib.path)
+    env = dict(os.environ, LM_GROUP_THREADS="7")
+    r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "threads ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "fp32"])
 def test_fcn_golden_tiny(emu_lib, precision):
     assert lm_checks.check_fcn_golden(emu_lib, "k7_70x94", precision=precision) < 1e-4
