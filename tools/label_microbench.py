@@ -32,3 +32,14 @@ for want in (labels, None):
     print("%dx%d frames %d..%d lib=%s labels=%s B=%d: %.1f us/launch, %.2f us/frame, %.0f GB/s algorithmic = %.3f of 8 TB/s" % (
         W, H, first, first + B, os.path.basename(os.environ.get("LM_LIB_PATH") or "default"), want is not None, B, ms * 1e3, ms * 1e3 / B,
         5 * W * H * B / (ms * 1e-3) / 1e9, 5 * W * H * B / (ms * 1e-3) / 8e12))
+
+# the same launches timed the way bench.py times them inside its timed region: one HIP event pair PER launch (lm_ctx_set_profiling)
+import ctypes
+lib.check(lib.lm_ctx_set_profiling(lab.ctx, 1))
+for _ in range(20):
+    lib.check(lib.lm_label_batch(lab.ctx, d.data_ptr(), B, labels.data_ptr(), st))
+ms, calls, nfr = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
+lib.check(lib.lm_ctx_profile_read(lab.ctx, ctypes.addressof(ms), ctypes.addressof(calls), ctypes.addressof(nfr)))
+lib.check(lib.lm_ctx_set_profiling(lab.ctx, 0))
+print("per-launch events: %.1f us/launch over %d launches (%.3f of 8 TB/s)" % (ms.value * 1e3 / calls.value, calls.value,
+      5 * W * H * B / (ms.value * 1e-3 / calls.value) / 8e12))
