@@ -1304,8 +1304,13 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         for (int f = 0; f < F; f++) { live += fcnt[(size_t)f + 1]; g->gpf_off[(size_t)f + 1] = g->gpf_off[f] + live; }
         g->gpf.assign((size_t)g->gpf_off[F], 0);
         std::vector<int64_t> cur(g->gpf_off.begin(), g->gpf_off.end() - 1);
-        for (int gi = 0; gi < nG; gi++)
-            for (int f = g_from[gi]; f < g_to[gi]; f++) g->gpf[(size_t)cur[f]++] = gi;
+        lm_host_parts(lm_host_threads(g->gpf_off[F]), [&](int part, int nparts) {        // a part owns a range of frames
+            const int f0 = (int)((int64_t)F * part / nparts), f1 = (int)((int64_t)F * (part + 1) / nparts);
+            for (int gi = 0; gi < nG; gi++) {
+                const int a0 = std::max(g_from[gi], f0), a1 = std::min(g_to[gi], f1);
+                for (int f = a0; f < a1; f++) g->gpf[(size_t)cur[f]++] = gi;
+            }
+        });
     }
     tm.mark("ages + groups_per_frame");
     // ---- conflicts (:446-500): aggregated on the device per unordered group pair, ordered here.  The reference's dict of
