@@ -240,6 +240,12 @@ void lm_fcn_destroy(LmFcn* f);
 int lm_fcn_set_layer(LmFcn* f, int layer, const float* h_w, int64_t w_count, const float* h_bias, int bias_count, int cin,
                      int cout, int k, int ck);
 
+/* Operand format of one layer whose weights were packed for the fp16-split kernels (ck <= 0 above): MFMA products per
+ * operand pair, 3 = hi.hi + hi.lo + lo.hi (~22 bits per operand), 2 = activations split / weights rounded to f16,
+ * 1 = both operands rounded to f16.  The torch reference computes these contractions in fp32 (FCN_lecturenet.py:260-403);
+ * lecturemath_amd/fcn.py holds the shipped per-layer assignment and profiles/ the error attribution behind it. */
+int lm_fcn_set_layer_terms(LmFcn* f, int layer, int terms);
+
 /* forward() for one RGB frame (device, uint8 [h][w][3]).  Device fp32 outputs (each may be NULL): d_out [h*w]
  * binarization logit (no sigmoid), d_text [h*w] text-mask logit, d_rec [3][h*w] tanh reconstruction. */
 int lm_fcn_forward(LmFcn* f, const uint8_t* d_rgb, int h, int w, float* d_out, float* d_text, float* d_rec, void* stream);

@@ -77,6 +77,7 @@ SIGNATURES = {
     "lm_fcn_destroy": (None, [_vp]),
     "lm_fcn_set_layer": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _i64, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int]),
+    "lm_fcn_set_layer_terms": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "lm_fcn_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp]),
 }
 

@@ -320,12 +320,10 @@ extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, i
     if ((long long)g.H * ((g.W + 3) / 4) >= (1ll << 24) && d_labels) { lm_set_error("lm_label_batch: frame too large for the label writer (H*W/4 must be < 2^24)"); return LM_ERR_ARG; }
 #if !LM_HIP_EMULATED
     {
+        // per call: the attribute belongs to the (function, device) pair and the call is cheap; a process-wide "already configured"
+        // flag would skip it on a second device or race between caller threads
         const size_t band_smem = (size_t)c->band_rows * g.WW * 18 + LM_BAND_LDS * 4 + (65 + 64) * 4 + 64;
-        static size_t band_smem_configured = 0;
-        if (band_smem > band_smem_configured) {
-            LM_HIP(hipFuncSetAttribute((const void*)lm_k_band, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_smem));
-            band_smem_configured = band_smem;
-        }
+        LM_HIP(hipFuncSetAttribute((const void*)lm_k_band, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_smem));
     }
 #endif
     if (lm_profile_mark(c, st, true, n_frames)) return LM_ERR_HIP;
@@ -344,14 +342,21 @@ extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, i
         hipStream_t aux = (hipStream_t)c->aux_stream;
         LM_HIP(hipEventRecord((hipEvent_t)c->ev_fork, st));
         LM_HIP(hipStreamWaitEvent(aux, (hipEvent_t)c->ev_fork, 0));
-        for (int k = 0, f0 = 0; k < parts; k++) {
+        // from here on the second queue holds work: whatever fails below, it is joined back into the caller's stream before the
+        // call returns (both queues touch the context's tables and d_binary)
+        int rc = LM_OK;
+        for (int k = 0, f0 = 0; k < parts && rc == LM_OK; k++) {
             const int n = n_frames / parts + (k < n_frames % parts ? 1 : 0);
-            const int rc = lm_label_launch(c, d_binary, f0, n, d_labels, (k & 1) ? aux : st);
-            if (rc) return rc;
+            rc = lm_label_launch(c, d_binary, f0, n, d_labels, (k & 1) ? aux : st);
             f0 += n;
         }
-        LM_HIP(hipEventRecord((hipEvent_t)c->ev_join, aux));
-        LM_HIP(hipStreamWaitEvent(st, (hipEvent_t)c->ev_join, 0));
+        const hipError_t e1 = hipEventRecord((hipEvent_t)c->ev_join, aux);
+        const hipError_t e2 = (e1 == hipSuccess) ? hipStreamWaitEvent(st, (hipEvent_t)c->ev_join, 0) : e1;
+        if (e2 != hipSuccess) {
+            (void)hipStreamSynchronize(aux);        // could not order the queues with an event: drain the second one instead
+            if (rc == LM_OK) { lm_set_error("lm_label_batch: joining the second queue failed: %s", hipGetErrorString(e2)); rc = LM_ERR_HIP; }
+        }
+        if (rc) return rc;
     }
     if (lm_profile_mark(c, st, false, n_frames)) return LM_ERR_HIP;
     c->last_batch = n_frames;

@@ -121,7 +121,14 @@ LM_DEV int lm_lane() { return (int)(threadIdx.x & 63); }
 #if LM_HIP_EMULATED
 #define LM_WAVE_SYNC() ((void)__ballot(1))
 #else
-#define LM_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+// wave_barrier alone is declared memory-free to the optimiser: the release / acquire fences at wavefront scope are what forbid
+// moving the LDS loads of one side above the LDS stores of the other (they emit no instruction beyond the LDS counter wait)
+#define LM_WAVE_SYNC()                                           \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+    } while (0)
 #endif
 
 // a line the instruction scheduler may not move anything across

@@ -1117,6 +1117,17 @@ extern "C" int lm_fcn_set_layer(LmFcn* f, int layer, const float* h_w, int64_t w
     return LM_OK;
 }
 
+// Operand format of one layer packed for the fp16-split kernels (the packing holds hi and lo of every weight, so any of the three
+// formats can run from it): terms = 3 (hi.hi + hi.lo + lo.hi), 2 (activations split, weights rounded to f16) or 1 (both rounded).
+extern "C" int lm_fcn_set_layer_terms(LmFcn* f, int layer, int terms)
+{
+    if (!f || layer < 0 || layer >= LM_FCN_LAYERS || terms < 1 || terms > 3) { lm_set_error("lm_fcn_set_layer_terms: bad arguments"); return LM_ERR_ARG; }
+    LmFcnLayer& l = f->layer[layer];
+    if (!l.w || l.ck > 0) { lm_set_error("lm_fcn_set_layer_terms: layer %d is not packed for the fp16-split kernels", layer); return LM_ERR_STATE; }
+    l.ck = terms == 3 ? 0 : (terms == 2 ? -2 : -1);
+    return LM_OK;
+}
+
 static size_t lm_conv_smem(int K, int CK, int NT)
 {
     const int P = 16 + K - 1;

@@ -14,7 +14,10 @@
 // 03_cc_grouping.py:41) and the channel-1/2 painting that is never encoded (:661-671,678).
 #include "lm_stream.h"
 
+#include <sched.h>
+
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include <unordered_map>
@@ -978,23 +981,40 @@ struct LmPhaseTimer {
 
 // Host loops of step 03 that write disjoint ranges (entry lists, conflict rows) run on a few threads: with 10,000 frames they
 // were 24 + 25 of the 130 ms of lm_group_run.  fn(part, parts) is called once per part; parts == 1 runs inline.
+// Reached through the C ABI: nothing may leave as an exception.  A part whose thread cannot be started runs inline; a part that throws
+// (std::bad_alloc at worst: the parts index pre-sized vectors) is reported after every started thread has been joined.
 template <class F>
-static void lm_host_parts(int parts, F fn)
+static bool lm_host_parts(int parts, F fn)
 {
-    if (parts <= 1) { fn(0, 1); return; }
+    std::atomic<bool> ok{true};
+    auto guarded = [&fn, &ok](int p, int n) { try { fn(p, n); } catch (...) { ok = false; } };
+    if (parts <= 1) { guarded(0, 1); return ok; }
     std::vector<std::thread> th;
-    th.reserve((size_t)parts - 1);
-    for (int p = 1; p < parts; p++) th.emplace_back([&fn, p, parts] { fn(p, parts); });
-    fn(0, parts);
+    std::vector<int> inline_parts;
+    try { th.reserve((size_t)parts - 1); } catch (...) {}
+    for (int p = 1; p < parts; p++) {
+        try { th.emplace_back([&guarded, p, parts] { guarded(p, parts); }); }
+        catch (...) { inline_parts.push_back(p); }       // std::system_error (no thread to be had) or bad_alloc
+    }
+    guarded(0, parts);
+    for (int p : inline_parts) guarded(p, parts);
     for (auto& t : th) t.join();
+    return ok;
 }
+#define LM_HOST_PARTS(parts, ...)                                                                  \
+    do {                                                                                           \
+        if (!lm_host_parts(parts, __VA_ARGS__)) { lm_set_error("lm_group_run: a host worker failed (out of memory?)"); return LM_ERR_STATE; } \
+    } while (0)
 
 static int lm_host_threads(long long items)
 {
     static const int forced = [] { const char* e = getenv("LM_GROUP_THREADS"); return (e && atoi(e) > 0) ? atoi(e) : 0; }();    // tests: any size
     if (forced) return forced;
     static const int hw = [] {
-        const unsigned n = std::thread::hardware_concurrency();
+        // CPUs this process may run on (cgroup cpusets / taskset), not the machine's: hardware_concurrency() ignores both
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        unsigned n = (sched_getaffinity(0, sizeof(set), &set) == 0) ? (unsigned)CPU_COUNT(&set) : std::thread::hardware_concurrency();
         return (int)(n >= 16 ? 8 : (n >= 4 ? n / 2 : 1));
     }();
     return items < (1 << 16) ? 1 : hw;
@@ -1046,7 +1066,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         // counting sort by unique; part p owns the uniques whose entries lie in its share of `lst` and scans all CCs for them
         std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
         const int parts = lm_host_threads(n_cc);
-        lm_host_parts(parts, [&](int part, int nparts) {
+        LM_HOST_PARTS(parts, [&](int part, int nparts) {
             const int64_t e0 = (int64_t)n_cc * part / nparts, e1 = (int64_t)n_cc * (part + 1) / nparts;
             const int u0 = (int)(std::lower_bound(cnt.begin(), cnt.begin() + nU0, e0) - cnt.begin());
             const int u1 = (part + 1 == nparts) ? nU0 : (int)(std::lower_bound(cnt.begin(), cnt.begin() + nU0, e1) - cnt.begin());
@@ -1304,7 +1324,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         for (int f = 0; f < F; f++) { live += fcnt[(size_t)f + 1]; g->gpf_off[(size_t)f + 1] = g->gpf_off[f] + live; }
         g->gpf.assign((size_t)g->gpf_off[F], 0);
         std::vector<int64_t> cur(g->gpf_off.begin(), g->gpf_off.end() - 1);
-        lm_host_parts(lm_host_threads(g->gpf_off[F]), [&](int part, int nparts) {        // a part owns a range of frames
+        LM_HOST_PARTS(lm_host_threads(g->gpf_off[F]), [&](int part, int nparts) {        // a part owns a range of frames
             const int f0 = (int)((int64_t)F * part / nparts), f1 = (int)((int64_t)F * (part + 1) / nparts);
             for (int gi = 0; gi < nG; gi++) {
                 const int a0 = std::max(g_from[gi], f0), a1 = std::min(g_to[gi], f1);
@@ -1374,7 +1394,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         const size_t ntot = ents.size();
         g->conf_g1.resize(ntot); g->conf_g2.resize(ntot); g->conf_matched.resize(ntot); g->conf_unmatched.resize(ntot);
         g->conf_union.resize(ntot); g->conf_inter.resize(ntot);
-        lm_host_parts(lm_host_threads((long long)ntot), [&](int part, int nparts) {
+        LM_HOST_PARTS(lm_host_threads((long long)ntot), [&](int part, int nparts) {
             // groups whose rows start inside this part's share of the output
             const int64_t e0 = (int64_t)ntot * part / nparts, e1 = (int64_t)ntot * (part + 1) / nparts;
             const int x0 = (int)(std::lower_bound(coff.begin(), coff.begin() + nG, e0) - coff.begin());

@@ -533,7 +533,11 @@ __global__ void __launch_bounds__(256) lm_k_mb_twin_cmp(const LmCcRec* __restric
     const long long n = C1 - C0;
     if (n <= 0 || n * 2 > LM_MB_TTAB) return;
     const unsigned long long W0 = cc[C0].crop_off;
-    const unsigned long long W1 = (C1 < cnt->n_cc) ? cc[C1].crop_off : cnt->n_words;
+    // End of the batch's crop words from the batch's OWN last record (lm_k_select's layout: box rows x 32-px column words).  The
+    // stream counters and cc[C1] belong to the NEXT batch, whose emission may already be running on the other queue.
+    const LmCcRec last = cc[C1 - 1];
+    const unsigned long long W1 = last.crop_off + (unsigned long long)((last.max_x >> 5) - (last.min_x >> 5) + 1) *
+                                                      (unsigned long long)(last.max_y - last.min_y + 1);
     const int lane = lm_lane();
     const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
     for (unsigned long long w0 = W0 + wave * 64ull; w0 < W1; w0 += nwaves * 64ull) {

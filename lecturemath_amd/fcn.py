@@ -234,6 +234,11 @@ class FcnEngine:
         w, b = conv_bn("conv_out")
         self._set(L_OUT, pack_small(w, range(3 + pm2), s2), np.pad(b, (0, 4 - len(b))), s2, 1, self.pk, 8)
 
+    def set_layer_precision(self, layer, precision):
+        """Operand format of ONE layer ("f16x3" / "f16x2" / "f16"); the engine must have been loaded with an fp16-split precision."""
+        terms = {"f16x3": 3, "f16x2": 2, "f16": 1}[precision]
+        self.lib.check(self.lib.lm_fcn_set_layer_terms(self.handle, int(layer), terms))
+
     def forward(self, rgb):
         """rgb: device (or host numpy) uint8 [H,W,3] -> device fp32 (logit [H,W], text logit [H,W], rec [3,H,W])."""
         if isinstance(rgb, np.ndarray):
