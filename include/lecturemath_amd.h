@@ -250,6 +250,22 @@ int lm_fcn_set_layer_terms(LmFcn* f, int layer, int terms);
  * binarization logit (no sigmoid), d_text [h*w] text-mask logit, d_rec [3][h*w] tanh reconstruction. */
 int lm_fcn_forward(LmFcn* f, const uint8_t* d_rgb, int h, int w, float* d_out, float* d_text, float* d_rec, void* stream);
 
+/* ----------------------------------------------------------------------------------------------------
+ * Second FCN engine (csrc/lm_fcn2.hip): the same forward pass for the shipped topology (3x3 encoder / decoder, 7x7 pixel
+ * branch, every width a multiple of 16) on planar f16 activations and one gather-GEMM kernel, operand format per layer.
+ * lecturemath_amd/fcn2.py builds the per-layer recipes; lecturemath_amd/fcn.py picks this engine when the network fits it.
+ * lo25[t] = 1 keeps the lo parts of activation tensor t (a consumer runs the split format). */
+typedef struct LmFcn2 LmFcn2;
+LmFcn2* lm_fcn2_create(const int32_t* widths18, const int32_t* lo25, int max_h, int max_w);
+void lm_fcn2_destroy(LmFcn2* f);
+/* desc: kh, kw, terms, mt, epilogue, nchunks, planes per chunk, ngroups, nslices, npatterns, double-buffered planes, LDS bytes of
+ * a weight buffer, outputs; then planes [nchunks * npc][tensor, octet], weight groups [ngroups][first slice, slices, chunk],
+ * slices [nslices][LDS offset, pattern], patterns [npat][4].  HOST pointers. */
+int lm_fcn2_set_layer(LmFcn2* f, int layer, const int32_t* desc, int ndesc, const void* h_w, int64_t wbytes, int wblocks,
+                      const float* h_bias, int nbias);
+/* same contract as lm_fcn_forward */
+int lm_fcn2_forward(LmFcn2* f, const uint8_t* d_rgb, int h, int w, float* d_out, float* d_text, float* d_rec, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,10 @@ SIGNATURES = {
                                         ctypes.c_int]),
     "lm_fcn_set_layer_terms": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "lm_fcn_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "lm_fcn2_create": (_vp, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
+    "lm_fcn2_destroy": (None, [_vp]),
+    "lm_fcn2_set_layer": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int, _vp, _i64, ctypes.c_int, _vp, ctypes.c_int]),
+    "lm_fcn2_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp]),
 }
 
 

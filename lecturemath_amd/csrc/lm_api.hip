@@ -15,6 +15,7 @@
 #include "lm_match_batch.hip"
 #include "lm_group.hip"
 #include "lm_fcn.hip"
+#include "lm_fcn2.hip"
 
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";

@@ -1,0 +1,706 @@
+// lm_fcn2.hip -- FCN-LectureNet inference, second engine: planar f16 activations + one gather-GEMM kernel on v_mfma_f32_16x16x32_f16.
+//
+// Same network and reference lines as lm_fcn.hip (FCN_lecturenet.py:260-323 encode_decode, :364-403 forward, :607-618 prepare_image);
+// this engine runs the shipped topology (3x3 encoder / decoder, 7x7 pixel branch, every width a multiple of 16) with a per-layer
+// operand format: the layers below full resolution on plain f16 operands, the full-resolution layers on the f16 hi + lo split
+// ("f16x3": hi.hi + hi.lo + lo.hi).  profiles/r03_fcn_layer_precision.* is the measurement behind that assignment.
+//
+// Activations in HBM ("planar octets"): a tensor of C channels is C/8 planes of [Hp][Wp] slots of 16 bytes = 8 consecutive channels
+// of one pixel as f16 (the hi parts), followed -- when a consumer runs a split format -- by C/8 planes of the lo parts
+// (lo = f16(x - hi), so hi + lo carries ~22 bits).  Hp x Wp = the image rounded up to whole 16 x 16 tiles plus a zero halo as wide
+// as the largest padding of any consumer: a convolution's input patch is then a plain rectangle of every plane, no bounds checks.
+// A producer converts ONCE per value in its epilogue (lm_fcn.hip converted fp32 -> f16 hi / lo in every consuming workgroup: 12-24
+// times per value in the deep layers) and every load of the engine is a 16-byte LDS-DMA (global_load_lds_dwordx4).
+//
+// The kernel (lm_k_g2) is a gather-GEMM  D[channel][pixel] = sum_k A[channel][k] * B[k][pixel]  on 16 x 16 x 32 tiles:
+//   * a workgroup = 4 waves = a 16 x 16 pixel tile x MT tiles of 16 output channels; wave w owns the pixel rows 4w..4w+3 (NT = 4
+//     column tiles of 16 consecutive pixels) and all MT channel tiles: 4 * MT accumulators of 4 registers;
+//   * K is walked in SLICES of 32: the four 8-wide k-groups of a slice (lane >> 4) are four (plane, tap) pairs chosen by the HOST --
+//     four channel octets of one tap, or two octets of two taps, or taps of a "pair plane" (below) -- so a layer's K needs no padding
+//     beyond its last slice.  The B fragment of k-group g is ONE ds_read_b128 at (pair's slot of the lane's pixel); per slice the
+//     lane's four-way offset pattern comes from a small LDS table, the slice's base offset from a scalar load;
+//   * weights are the A operand, packed by the host in fragment order per (channel block, weight group, slice, tile, hi | lo);
+//   * staging: the chunk's planes (double-buffered when a layer has several chunks and LDS allows) and the next weight group are
+//     fetched by LDS-DMA while the current group's MFMAs run; one "vmcnt(0) + barrier" per weight group.
+// Pair planes: a 3-channel input (the RGB frame, the diff of the pixel branch) is stored as ONE plane whose slot x holds
+// {c0 c1 c2 0 of pixel x | c0 c1 c2 0 of pixel x + 1}: one k-group covers two horizontal taps, so a 7-tap kernel row of the 3-channel
+// part costs 4 k-groups instead of 7 x a zero-padded 16-channel chunk (lm_fcn.hip), and conv_down_1's K = 27 fits two slices.
+#include "lm_common.h"
+
+#if LM_HIP_EMULATED
+lm_f32x4 hipemu_mfma_16x16x32f16(lm_h8 a, lm_h8 b, lm_f32x4 c);
+#define LM_MFMA16(a, b, c) hipemu_mfma_16x16x32f16(a, b, c)
+// the LDS destination is wave-uniform base + lane * 16, the source address is per lane
+#define LM_DMA16(gsrc, lds_base) memcpy((char*)(lds_base) + lm_lane() * 16, (const void*)(gsrc), 16)
+#define LM_VMWAIT0() ((void)0)
+#else
+#define LM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define LM_DMA16(gsrc, lds_base)                                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),                           \
+                                     (__attribute__((address_space(3))) void*)(lds_base), 16, 0, 0)
+// LDS-DMA is a pending LDS write on the vector-memory counter: the issuing wave waits for its own, the barrier after it covers the
+// other waves' (MI355X_MICROARCH.md, "Two waves per SIMD" item 7)
+#define LM_VMWAIT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
+#define LM_G2_EPI_PO 0      // planar-octet output (+ optional lo planes, + optional 2x2 max-pooled copy), GELU or none
+#define LM_G2_EPI_T 1       // fp32 [pixel][TS] rows of the head row convolutions (lm_k_vsum2_*), no activation
+#define LM_G2_EPI_TC 2      // transposed 2x2 / stride 2: blockIdx.z = dy * 2 + dx, output pixel (2y + dy, 2x + dx), planar octets
+
+struct LmG2Args {
+    const char* arena;              // base of the engine's activation arena
+    const long long* psrc;          // [nchunks][npc][2] byte offsets of the chunk's planes in the arena: hi, lo
+    const char* wpk;                // packed weights: [channel block][wblock_bytes]
+    const int4* groups;             // [ngroups] {first slice, slices, chunk, byte offset of the group's weights inside a channel block}
+    const uint2* sdesc;             // [slices] {LDS byte offset of k-group 0's pair inside the patch buffer, pattern}
+    const int* pdelta;              // [npat][4] byte offsets of the k-groups' pairs relative to k-group 0
+    const float* bias;              // [Cout] in the kernel's channel order (= natural order)
+    long long wblock_bytes;
+    int nchunks, npc, ngroups, npat;
+    int wbuf_bytes;                 // LDS bytes of one weight buffer (largest group)
+    int pdouble;                    // 1: two patch buffers (next chunk fetched under the current one)
+    int Wp_in;                      // slots per padded input row
+    int org_in;                     // slot offset of tile (0, 0)'s patch origin in a plane
+    int tiles_x;
+    int H, W;                       // output grid of this launch (bounds of the stores; the input grid for EPI_TC)
+    int act;                        // LM_ACT_GELU or LM_ACT_NONE
+    // EPI_PO / EPI_TC output tensor
+    char* out_hi; char* out_lo;     // plane 0 of the hi / lo parts (lo may be null)
+    long long out_plane;            // bytes per plane
+    int Wp_out, halo_out;
+    char* pool_hi; char* pool_lo; long long pool_plane; int Wp_pool, halo_pool;     // EPI_PO: 2x2 max-pooled copy, null when absent
+    // EPI_T
+    float* tout; int ts, tn;        // [pixel][ts] floats, the first tn of the 16 rows are stored
+};
+
+// one 16 x 16 pixel tile x MT channel tiles; see the header comment
+template <int KH, int KW, int TERMS, int MT, int EPI>
+__global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a)
+{
+    LM_DYN_SMEM(smem);
+    constexpr int PW = 16 + KW - 1, PH = 16 + KH - 1, NSLOT = PH * PW;
+    constexpr int PLS = (NSLOT * 16 + 255) & ~255;      // LDS bytes per plane: planes a multiple of the 256-B bank row apart, so the 16
+                                                        // lanes of a ds_read_b128 service group (16 different pixels of a row, two
+                                                        // k-groups) fall on 16 different 16-B slots
+    constexpr int NHL = TERMS >= 2 ? 2 : 1;             // patch planes per octet: hi (, lo)
+    constexpr int NWL = TERMS >= 3 ? 2 : 1;             // weight fragments per tile: hi (, lo)
+    constexpr int NJ = (NSLOT + 255) / 256;             // DMA instructions per thread and plane
+    constexpr int NT = 4;
+    const int lane = lm_lane(), wave = LM_UNIFORM((int)(threadIdx.x >> 6)), kg = lane >> 4, col = lane & 15;
+    const int ty = (int)blockIdx.x / a.tiles_x, tx = (int)blockIdx.x - ty * a.tiles_x;
+    const int pbuf_bytes = a.npc * NHL * PLS;
+    char* const s_pat = smem;                                           // [npat][64] ints: column part + pattern offset of the lane's k-group
+    char* const s_p0 = smem + ((a.npat * 256 + 255) & ~255);
+    char* const s_w0 = s_p0 + (a.pdouble ? 2 : 1) * pbuf_bytes;
+    if (wave == 0)
+        for (int p = 0; p < a.npat; p++) ((int*)s_pat)[p * 64 + lane] = col * 16 + a.pdelta[p * 4 + kg];
+    const int wrow = wave * (4 * PW * 16);                              // the wave's first pixel row inside a plane
+
+    // DMA source offsets of the thread's slots inside a plane (the same for every plane and chunk)
+    int goff[NJ];
+    bool gval[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int slot = (j * 4 + wave) * 64 + lane;
+        const int row = slot / PW, x = slot - row * PW;
+        goff[j] = (row * a.Wp_in + x) * 16;
+        gval[j] = slot < NSLOT;
+    }
+    const long long tile_org = ((long long)(ty * 16) * a.Wp_in + tx * 16 + a.org_in) * 16;
+    const char* const wsrc = a.wpk + (long long)blockIdx.y * a.wblock_bytes + (EPI == LM_G2_EPI_TC ? (long long)blockIdx.z * a.wblock_bytes * gridDim.y : 0);
+
+    auto issue_patch = [&](int chunk, int buf) {
+        char* const dst = s_p0 + buf * pbuf_bytes;
+        for (int p = 0; p < a.npc; p++)
+#pragma unroll
+            for (int hl = 0; hl < NHL; hl++) {
+                const char* src = a.arena + a.psrc[(chunk * a.npc + p) * 2 + hl] + tile_org;
+#pragma unroll
+                for (int j = 0; j < NJ; j++)
+                    if (gval[j]) LM_DMA16(src + goff[j], dst + (p * NHL + hl) * PLS + (j * 4 + wave) * 1024);
+            }
+    };
+    auto issue_weights = [&](const int4 grp, int buf) {
+        const char* src = wsrc + grp.w;
+        char* const dst = s_w0 + buf * a.wbuf_bytes;
+        const int n16 = grp.y * (MT * NWL * 64);
+        for (int i = (int)threadIdx.x; i < n16; i += 256) LM_DMA16(src + (long long)i * 16, dst + (i - lane) * 16);
+    };
+
+    lm_f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[m][n][r] = 0.0f;
+
+    int4 grp = a.groups[0];
+    issue_patch(0, 0);
+    issue_weights(grp, 0);
+    LM_VMWAIT0();
+    lm_lds_barrier();
+    int pb = 0, wb = 0, prev_chunk = -1;
+    for (int g = 0; g < a.ngroups; g++) {
+        const bool more = g + 1 < a.ngroups;
+        int4 nxt = grp;
+        if (more) {
+            nxt = a.groups[g + 1];
+            issue_weights(nxt, wb ^ 1);
+            // first group of a chunk: the next chunk's planes go into the other patch buffer, read last before the barrier that ended
+            // the previous chunk
+            if (a.pdouble && grp.z + 1 < a.nchunks && grp.z != prev_chunk) issue_patch(grp.z + 1, pb ^ 1);
+        }
+        prev_chunk = grp.z;
+        const char* const pbase = s_p0 + pb * pbuf_bytes + wrow;
+        const char* const wbase = s_w0 + wb * a.wbuf_bytes + lane * 16;
+        for (int s = 0; s < grp.y; s++) {
+            const uint2 d = a.sdesc[grp.x + s];
+            const char* pa = pbase + d.x + ((const int*)s_pat)[(int)d.y * 64 + lane];
+            const char* wa = wbase + s * (MT * NWL * 1024);
+            lm_h8 bh[NT], bl[NT], ah[MT], al[MT];
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                bh[n] = *(const lm_h8*)(pa + n * (PW * 16));
+                if (TERMS >= 2) bl[n] = *(const lm_h8*)(pa + n * (PW * 16) + PLS);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                ah[m] = *(const lm_h8*)(wa + m * (NWL * 1024));
+                if (TERMS >= 3) al[m] = *(const lm_h8*)(wa + m * (NWL * 1024) + 1024);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA16(ah[m], bh[n], acc[m][n]);
+            if (TERMS >= 3) {
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+#pragma unroll
+                    for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA16(al[m], bh[n], acc[m][n]);
+            }
+            if (TERMS >= 2) {
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+#pragma unroll
+                    for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA16(ah[m], bl[n], acc[m][n]);
+            }
+        }
+        LM_VMWAIT0();
+        lm_lds_barrier();       // this group's buffers are free, the next group's weights (and planes) have landed
+        wb ^= 1;
+        if (more && nxt.z != grp.z) {
+            if (a.pdouble) pb ^= 1;
+            else {              // one patch buffer: the next chunk's planes are fetched now, in the open
+                issue_patch(nxt.z, 0);
+                LM_VMWAIT0();
+                lm_lds_barrier();
+            }
+        }
+        grp = nxt;
+    }
+
+    // ---------------------------------------------------------------- epilogues
+    // D[row = 4 * kg + r][col]: row = channel of the tile, col = pixel `col` of the wave's row n
+    const int y0 = ty * 16 + wave * 4, x = tx * 16 + col;
+    if constexpr (EPI == LM_G2_EPI_T) {
+        static_assert(MT == 1, "the head rows have at most 16 outputs");
+        if (4 * kg < a.tn && x < a.W) {
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                const int y = y0 + n;
+                if (y < a.H) *(float4*)(a.tout + ((long long)y * a.W + x) * a.ts + 4 * kg) = make_float4(acc[0][n][0], acc[0][n][1], acc[0][n][2], acc[0][n][3]);
+            }
+        }
+    } else {
+        const int cb = (int)blockIdx.y * (MT * 16);                  // first channel of the workgroup
+        const bool gelu = a.act == LM_ACT_GELU;
+        const int dy = (EPI == LM_G2_EPI_TC) ? ((int)blockIdx.z >> 1) : 0, dx = (EPI == LM_G2_EPI_TC) ? ((int)blockIdx.z & 1) : 0;
+        const int sc = (EPI == LM_G2_EPI_TC) ? 2 : 1;
+        // pairs of tiles: the host packs tile 2q with the channels 32q + 8kg + (0..3) in rows 4kg + (0..3) and tile 2q + 1 with
+        // 32q + 8kg + 4 + (0..3), so a lane holds one whole octet of its pixel: one 16-byte store per part
+#pragma unroll
+        for (int q = 0; q < MT / 2; q++) {
+            const int ch = cb + 32 * q + 8 * kg;
+            const float4 b0 = *(const float4*)(a.bias + ch), b1 = *(const float4*)(a.bias + ch + 4);
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            const long long oplane = (long long)(ch >> 3) * a.out_plane;
+            float v[NT][8];
+#pragma unroll
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float t = acc[2 * q + (j >> 2)][n][j & 3] + bb[j];
+                    v[n][j] = gelu ? lm_gelu(t) : t;
+                }
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                const int y = y0 + n;
+                if (y >= a.H || x >= a.W) continue;
+                lm_h8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; j++) { hi[j] = (_Float16)v[n][j]; lo[j] = (_Float16)(v[n][j] - (float)hi[j]); }
+                const long long so = oplane + ((long long)(sc * y + dy + a.halo_out) * a.Wp_out + sc * x + dx + a.halo_out) * 16;
+                *(lm_h8*)(a.out_hi + so) = hi;
+                if (a.out_lo) *(lm_h8*)(a.out_lo + so) = lo;
+            }
+            if constexpr (EPI == LM_G2_EPI_PO) {
+                if (a.pool_hi) {        // 2x2 / stride 2 max pooling (floor): rows (n, n + 1), columns (col, col ^ 1)
+#pragma unroll
+                    for (int n = 0; n < NT; n += 2) {
+                        lm_h8 ph, pl;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const float m2 = fmaxf(v[n][j], v[n + 1][j]);
+                            const float m4 = fmaxf(m2, __shfl_xor(m2, 1));
+                            ph[j] = (_Float16)m4; pl[j] = (_Float16)(m4 - (float)ph[j]);
+                        }
+                        const int py = (y0 + n) >> 1, px = x >> 1;
+                        if (!(col & 1) && py < (a.H >> 1) && px < (a.W >> 1)) {
+                            const long long so = (long long)(ch >> 3) * a.pool_plane + ((long long)(py + a.halo_pool) * a.Wp_pool + px + a.halo_pool) * 16;
+                            *(lm_h8*)(a.pool_hi + so) = ph;
+                            if (a.pool_lo) *(lm_h8*)(a.pool_lo + so) = pl;
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (MT & 1) {         // the unpaired last tile: channels in row order, a lane holds half an octet (8-byte stores)
+            constexpr int m = MT - 1;
+            const int ch = cb + 16 * m + 4 * kg;
+            const float4 b0 = *(const float4*)(a.bias + ch);
+            const float bb[4] = {b0.x, b0.y, b0.z, b0.w};
+            const long long oplane = (long long)(ch >> 3) * a.out_plane + (kg & 1) * 8;
+            float v[NT][4];
+#pragma unroll
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float t = acc[m][n][j] + bb[j];
+                    v[n][j] = gelu ? lm_gelu(t) : t;
+                }
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                const int y = y0 + n;
+                if (y >= a.H || x >= a.W) continue;
+                lm_h4 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { hi[j] = (_Float16)v[n][j]; lo[j] = (_Float16)(v[n][j] - (float)hi[j]); }
+                const long long so = oplane + ((long long)(sc * y + dy + a.halo_out) * a.Wp_out + sc * x + dx + a.halo_out) * 16;
+                *(lm_h4*)(a.out_hi + so) = hi;
+                if (a.out_lo) *(lm_h4*)(a.out_lo + so) = lo;
+            }
+            if constexpr (EPI == LM_G2_EPI_PO) {
+                if (a.pool_hi) {
+#pragma unroll
+                    for (int n = 0; n < NT; n += 2) {
+                        lm_h4 ph, pl;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const float m2 = fmaxf(v[n][j], v[n + 1][j]);
+                            const float m4 = fmaxf(m2, __shfl_xor(m2, 1));
+                            ph[j] = (_Float16)m4; pl[j] = (_Float16)(m4 - (float)ph[j]);
+                        }
+                        const int py = (y0 + n) >> 1, px = x >> 1;
+                        if (!(col & 1) && py < (a.H >> 1) && px < (a.W >> 1)) {
+                            const long long so = (long long)(ch >> 3) * a.pool_plane + (kg & 1) * 8 + ((long long)(py + a.halo_pool) * a.Wp_pool + px + a.halo_pool) * 16;
+                            *(lm_h4*)(a.pool_hi + so) = ph;
+                            if (a.pool_lo) *(lm_h4*)(a.pool_lo + so) = pl;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pair planes and heads
+// ------------------------------------------------------------------------------------------------
+// Writes one pixel's three values into a pair plane: slot x gets them as its first half {c0 c1 c2 0}, slot x - 1 as its second half
+// (x - 1 = -1 lies in the halo: that slot's first half stays zero = the convolution's padding).  hi and lo parts.
+LM_DEV void lm_pair_store(char* hi_plane, char* lo_plane, int Wp, int halo, int y, int x, float v0, float v1, float v2)
+{
+    lm_h4 hi, lo;
+    hi[0] = (_Float16)v0; hi[1] = (_Float16)v1; hi[2] = (_Float16)v2; hi[3] = (_Float16)0.0f;
+    lo[0] = (_Float16)(v0 - (float)hi[0]); lo[1] = (_Float16)(v1 - (float)hi[1]); lo[2] = (_Float16)(v2 - (float)hi[2]); lo[3] = (_Float16)0.0f;
+    const long long so = ((long long)(y + halo) * Wp + x + halo) * 16;
+    *(lm_h4*)(hi_plane + so) = hi;
+    *(lm_h4*)(hi_plane + so - 8) = hi;
+    *(lm_h4*)(lo_plane + so) = lo;
+    *(lm_h4*)(lo_plane + so - 8) = lo;
+}
+
+// uint8 HWC RGB -> the network's input pair plane, (x / 255 - 0.5) / 0.5 (to_tensor + normalize, FCN_lecturenet.py:607-618)
+__global__ void __launch_bounds__(256) lm_k_prepare2(const uint8_t* __restrict__ rgb, char* hi_plane, char* lo_plane, int H, int W, int Wp, int halo)
+{
+    const long long npx = (long long)H * W;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(p / W), x = (int)(p - (long long)y * W);
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) v[c] = ((float)rgb[p * 3 + c] / 255.0f - 0.5f) / 0.5f;
+        lm_pair_store(hi_plane, lo_plane, Wp, halo, y, x, v[0], v[1], v[2]);
+    }
+}
+
+// Text mask (7x7, one output) and reconstruction (3x3, three outputs) from their common 1x7 row convolution T[pixel][16] (rows 0..6:
+// text kernel rows, 7 + kh * 3 + co: reconstruction rows, see fcn.pack_text_rec_rows): text logit, rec = tanh(.),
+// diff = (x0 - rec) * sigmoid(text) (:370-379) written as the pixel branch's pair plane.  bias: [0] text, [1..3] rec.
+__global__ void __launch_bounds__(256) lm_k_vsum2_text_rec(const float* __restrict__ T, int H, int W, const float* __restrict__ bias,
+                                                           const char* x0_hi, const char* x0_lo, float* __restrict__ text, float* __restrict__ rec4,
+                                                           char* dp_hi, char* dp_lo, int Wp, int halo)
+{
+    constexpr int TW = 32, TH = 16, PR = TH + 6, TS = 16, RQ = TW * TS / 4;
+    __shared__ float s_t[PR * TW * TS];         // 44 KB
+    const int tiles_x = (W + TW - 1) / TW;
+    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    for (int i = threadIdx.x; i < PR * RQ; i += blockDim.x) {
+        const int r = i / RQ, q = i - r * RQ;
+        const int y = ty0 + r - 3, x = tx0 + (q >> 2);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y >= 0 && y < H && x < W) v = *(const float4*)(T + ((long long)y * W + tx0) * TS + q * 4);
+        *(float4*)(s_t + (r * TW) * TS + q * 4) = v;
+    }
+    __syncthreads();
+    const int ly = (int)(threadIdx.x >> 4), lx = (int)(threadIdx.x & 15);
+    const int y = ty0 + ly;
+    if (y >= H) return;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int xl = lx + 16 * h, x = tx0 + xl;
+        if (x >= W) continue;
+        float t = bias[0], r0 = bias[1], r1 = bias[2], r2 = bias[3];
+#pragma unroll
+        for (int kh = 0; kh < 7; kh++) t += s_t[((ly + kh) * TW + xl) * TS + kh];
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++) {
+            const float* q = s_t + ((ly + 2 + kh) * TW + xl) * TS + 7 + kh * 3;
+            r0 += q[0]; r1 += q[1]; r2 += q[2];
+        }
+        r0 = tanhf(r0); r1 = tanhf(r1); r2 = tanhf(r2);
+        const long long p = (long long)y * W + x;
+        const float m = 1.0f / (1.0f + expf(-t));
+        const long long so = ((long long)(y + halo) * Wp + x + halo) * 16;
+        const lm_h4 xh = *(const lm_h4*)(x0_hi + so), xl4 = *(const lm_h4*)(x0_lo + so);
+        const float x0 = (float)xh[0] + (float)xl4[0], x1 = (float)xh[1] + (float)xl4[1], x2 = (float)xh[2] + (float)xl4[2];
+        text[p] = t;
+        *(float4*)(rec4 + p * 4) = make_float4(r0, r1, r2, 0.f);
+        lm_pair_store(dp_hi, dp_lo, Wp, halo, y, x, (x0 - r0) * m, (x1 - r1) * m, (x2 - r2) * m);
+    }
+}
+
+// rows / columns of a transposed-conv output that no input pixel reaches (output_size = 2 * in + 1): act(bias), planar octets
+__global__ void __launch_bounds__(256) lm_k_convT_border2(char* out_hi, char* out_lo, long long plane, int Wp, int halo, int OH, int OW, int H2, int W2,
+                                                          int C8, const float* __restrict__ bias, int act)
+{
+    const long long nb_px = (long long)(OH - H2) * OW + (long long)H2 * (OW - W2);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nb_px * C8; i += (long long)gridDim.x * blockDim.x) {
+        const int o = (int)(i / nb_px);
+        const long long p = i - (long long)o * nb_px;
+        int y, x;
+        if (p < (long long)(OH - H2) * OW) { y = H2 + (int)(p / OW); x = (int)(p % OW); }
+        else { const long long q = p - (long long)(OH - H2) * OW; y = (int)(q / (OW - W2)); x = W2 + (int)(q % (OW - W2)); }
+        lm_h8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float v = lm_act(bias[o * 8 + j], act);
+            hi[j] = (_Float16)v; lo[j] = (_Float16)(v - (float)hi[j]);
+        }
+        const long long so = (long long)o * plane + ((long long)(y + halo) * Wp + x + halo) * 16;
+        *(lm_h8*)(out_hi + so) = hi;
+        if (out_lo) *(lm_h8*)(out_lo + so) = lo;
+    }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+#define LM_F2_TENSORS 25
+enum { LM_F2_X0P = 0, LM_F2_PRE0 = 1, LM_F2_POOL0 = 6, LM_F2_MID = 11, LM_F2_UPT0 = 12, LM_F2_CU0 = 17, LM_F2_XUP = 21, LM_F2_DP = 22, LM_F2_P1 = 23, LM_F2_P2 = 24 };
+
+struct LmF2Tensor {
+    int c8 = 0, lo = 0, level = 0;      // octet planes, lo parts kept, pyramid level (0 = full resolution)
+    long long off = 0;                  // byte offset in the arena
+    // geometry for the current frame size
+    int H = 0, W = 0, halo = 0, Hp = 0, Wp = 0;
+    long long plane = 0;
+};
+
+struct LmF2Layer {
+    int kh = 0, kw = 0, terms = 0, mt = 0, epi = 0, nchunks = 0, npc = 0, ngroups = 0, nslices = 0, npat = 0, pdouble = 0, wbuf_bytes = 0, cout = 0;
+    std::vector<int> planes;            // [nchunks * npc][2] tensor id, octet
+    long long wblock_bytes = 0;
+    char* d_w = nullptr; float* d_bias = nullptr;
+    int4* d_groups = nullptr; uint2* d_sdesc = nullptr; int* d_pdelta = nullptr; long long* d_psrc = nullptr;
+    bool set = false;
+};
+
+struct LmFcn2 {
+    int widths[18];
+    int max_h, max_w;
+    char* arena = nullptr;
+    long long arena_bytes = 0;
+    LmF2Tensor t[LM_F2_TENSORS];
+    LmF2Layer layer[LM_FCN_LAYERS];
+    float *tbuf = nullptr, *text = nullptr, *rec4 = nullptr, *outl = nullptr;
+    int cur_h = 0, cur_w = 0;
+};
+
+static inline int lm_f2_halo(int level) { return level == 0 ? 3 : 1; }
+
+static void lm_f2_geometry(LmFcn2* f, int h, int w)
+{
+    for (auto& t : f->t) {
+        t.H = h >> t.level; t.W = w >> t.level; t.halo = lm_f2_halo(t.level);
+        t.Hp = ((t.H + 15) & ~15) + 2 * t.halo; t.Wp = ((t.W + 15) & ~15) + 2 * t.halo;
+        t.plane = (long long)t.Hp * t.Wp * 16;
+    }
+}
+
+extern "C" void lm_fcn2_destroy(LmFcn2* f)
+{
+    if (!f) return;
+    if (f->arena) (void)hipFree(f->arena);
+    for (float* p : {f->tbuf, f->text, f->rec4, f->outl}) if (p) (void)hipFree(p);
+    for (auto& l : f->layer)
+        for (void* p : {(void*)l.d_w, (void*)l.d_bias, (void*)l.d_groups, (void*)l.d_sdesc, (void*)l.d_pdelta, (void*)l.d_psrc}) if (p) (void)hipFree(p);
+    delete f;
+}
+
+// widths18 as lm_fcn_create (every width a multiple of 16); lo25[t] = 1 keeps the lo parts of tensor t (a consumer runs a split format)
+extern "C" LmFcn2* lm_fcn2_create(const int32_t* widths18, const int32_t* lo25, int max_h, int max_w)
+{
+    if (!widths18 || !lo25 || max_h < 32 || max_w < 32) { lm_set_error("lm_fcn2_create: bad arguments (frames must be at least 32 px per side)"); return nullptr; }
+    for (int i = 0; i < 18; i++)
+        if (widths18[i] <= 0 || (widths18[i] & 15)) { lm_set_error("lm_fcn2_create: layer widths must be positive multiples of 16"); return nullptr; }
+    LmFcn2* f = new LmFcn2();
+    memcpy(f->widths, widths18, sizeof(f->widths));
+    f->max_h = max_h; f->max_w = max_w;
+    const int* w = f->widths;
+    auto def = [&](int id, int channels, int level) { f->t[id].c8 = channels / 8; f->t[id].level = level; f->t[id].lo = lo25[id] ? 1 : 0; };
+    def(LM_F2_X0P, 8, 0); f->t[LM_F2_X0P].lo = 1;
+    for (int n = 0; n < 5; n++) { def(LM_F2_PRE0 + n, w[n], n); def(LM_F2_POOL0 + n, w[n], n + 1); }
+    def(LM_F2_MID, w[5], 5);
+    for (int n = 0; n < 5; n++) def(LM_F2_UPT0 + n, w[6 + 2 * n], 4 - n);
+    for (int n = 0; n < 4; n++) def(LM_F2_CU0 + n, w[7 + 2 * n], 4 - n);
+    def(LM_F2_XUP, w[15], 0);
+    def(LM_F2_DP, 8, 0); f->t[LM_F2_DP].lo = 1;
+    def(LM_F2_P1, w[16], 0);
+    def(LM_F2_P2, w[17], 0);
+    lm_f2_geometry(f, max_h, max_w);
+    long long off = 0;
+    for (auto& t : f->t) { t.off = off; off += (long long)t.c8 * (1 + t.lo) * t.plane + 4096; }
+    f->arena_bytes = off;
+    const size_t px = (size_t)max_h * max_w;
+    if (hipMalloc((void**)&f->arena, (size_t)off) != hipSuccess || hipMalloc((void**)&f->tbuf, px * 16 * 4) != hipSuccess ||
+        hipMalloc((void**)&f->text, px * 4) != hipSuccess || hipMalloc((void**)&f->rec4, px * 16) != hipSuccess ||
+        hipMalloc((void**)&f->outl, px * 4) != hipSuccess) {
+        lm_set_error("lm_fcn2_create: out of device memory (%lld MB of activations)", off >> 20);
+        lm_fcn2_destroy(f);
+        return nullptr;
+    }
+    return f;
+}
+
+// One layer's recipe (lecturemath_amd/fcn2.py builds it and documents the layout).  desc: kh, kw, terms, mt, epi, nchunks, npc, ngroups,
+// nslices, npat, pdouble, wbuf_bytes, cout, then planes [nchunks * npc][2], groups [ngroups][3], sdesc [nslices][2], pdelta [npat][4].
+// HOST pointers.  wblocks = channel blocks (x 4 parities for a transposed convolution) of wbytes / wblocks bytes each.
+extern "C" int lm_fcn2_set_layer(LmFcn2* f, int layer, const int32_t* desc, int ndesc, const void* h_w, int64_t wbytes, int wblocks, const float* h_bias,
+                                 int nbias)
+{
+    if (!f || layer < 0 || layer >= LM_FCN_LAYERS || !desc || ndesc < 13 || !h_w || wbytes <= 0 || wblocks <= 0 || !h_bias || nbias <= 0) {
+        lm_set_error("lm_fcn2_set_layer: bad arguments");
+        return LM_ERR_ARG;
+    }
+    LmF2Layer& l = f->layer[layer];
+    for (void* p : {(void*)l.d_w, (void*)l.d_bias, (void*)l.d_groups, (void*)l.d_sdesc, (void*)l.d_pdelta, (void*)l.d_psrc}) if (p) (void)hipFree(p);
+    l = LmF2Layer();
+    l.kh = desc[0]; l.kw = desc[1]; l.terms = desc[2]; l.mt = desc[3]; l.epi = desc[4]; l.nchunks = desc[5]; l.npc = desc[6]; l.ngroups = desc[7];
+    l.nslices = desc[8]; l.npat = desc[9]; l.pdouble = desc[10]; l.wbuf_bytes = desc[11]; l.cout = desc[12];
+    const long long need = 13 + (long long)l.nchunks * l.npc * 2 + (long long)l.ngroups * 3 + (long long)l.nslices * 2 + (long long)l.npat * 4;
+    if (l.nchunks <= 0 || l.npc <= 0 || l.ngroups <= 0 || l.nslices <= 0 || l.npat <= 0 || l.npat > 16 || need != ndesc || wbytes % wblocks) {
+        lm_set_error("lm_fcn2_set_layer: inconsistent recipe for layer %d", layer);
+        return LM_ERR_ARG;
+    }
+    const int32_t* p = desc + 13;
+    l.planes.assign(p, p + (size_t)l.nchunks * l.npc * 2); p += (size_t)l.nchunks * l.npc * 2;
+    for (size_t i = 0; i < l.planes.size(); i += 2)
+        if (l.planes[i] < 0 || l.planes[i] >= LM_F2_TENSORS || l.planes[i + 1] < 0 || l.planes[i + 1] >= f->t[l.planes[i]].c8 ||
+            (l.terms >= 2 && !f->t[l.planes[i]].lo)) {
+            lm_set_error("lm_fcn2_set_layer: layer %d reads plane %d of tensor %d (octets %d, lo %d)", layer, l.planes[i + 1], l.planes[i],
+                         f->t[l.planes[i] < 0 || l.planes[i] >= LM_F2_TENSORS ? 0 : l.planes[i]].c8, f->t[l.planes[i] < 0 || l.planes[i] >= LM_F2_TENSORS ? 0 : l.planes[i]].lo);
+            return LM_ERR_ARG;
+        }
+    l.wblock_bytes = wbytes / wblocks;
+    std::vector<int4> groups((size_t)l.ngroups);
+    const int nwl = l.terms >= 3 ? 2 : 1;
+    for (int g = 0; g < l.ngroups; g++, p += 3) {
+        groups[g] = make_int4(p[0], p[1], p[2], p[0] * l.mt * nwl * 1024);
+        if (p[0] < 0 || p[1] <= 0 || p[0] + p[1] > l.nslices || p[2] < 0 || p[2] >= l.nchunks || p[1] * l.mt * nwl * 1024 > l.wbuf_bytes) {
+            lm_set_error("lm_fcn2_set_layer: bad weight group %d of layer %d", g, layer);
+            return LM_ERR_ARG;
+        }
+    }
+    if ((long long)l.nslices * l.mt * nwl * 1024 != l.wblock_bytes) { lm_set_error("lm_fcn2_set_layer: layer %d: weight bytes do not match the slices", layer); return LM_ERR_ARG; }
+    const int32_t* h_sdesc = p; p += (size_t)l.nslices * 2;
+    const int32_t* h_pdelta = p;
+    LM_HIP(hipMalloc((void**)&l.d_w, (size_t)wbytes));
+    LM_HIP(hipMalloc((void**)&l.d_bias, (size_t)nbias * 4));
+    LM_HIP(hipMalloc((void**)&l.d_groups, groups.size() * sizeof(int4)));
+    LM_HIP(hipMalloc((void**)&l.d_sdesc, (size_t)l.nslices * 8));
+    LM_HIP(hipMalloc((void**)&l.d_pdelta, (size_t)l.npat * 16));
+    LM_HIP(hipMalloc((void**)&l.d_psrc, (size_t)l.nchunks * l.npc * 16));
+    LM_HIP(hipMemcpy(l.d_w, h_w, (size_t)wbytes, hipMemcpyHostToDevice));
+    LM_HIP(hipMemcpy(l.d_bias, h_bias, (size_t)nbias * 4, hipMemcpyHostToDevice));
+    LM_HIP(hipMemcpy(l.d_groups, groups.data(), groups.size() * sizeof(int4), hipMemcpyHostToDevice));
+    LM_HIP(hipMemcpy(l.d_sdesc, h_sdesc, (size_t)l.nslices * 8, hipMemcpyHostToDevice));
+    LM_HIP(hipMemcpy(l.d_pdelta, h_pdelta, (size_t)l.npat * 16, hipMemcpyHostToDevice));
+    l.set = true;
+    f->cur_h = f->cur_w = 0;        // plane tables are rebuilt by the next forward
+    return LM_OK;
+}
+
+template <int KH, int KW, int TERMS, int MT, int EPI> static int lm_g2_launch_t(const LmG2Args& a, dim3 grid, size_t smem, hipStream_t st)
+{
+#if !LM_HIP_EMULATED
+    LM_HIP(hipFuncSetAttribute((const void*)lm_k_g2<KH, KW, TERMS, MT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+#endif
+    hipLaunchKernelGGL((lm_k_g2<KH, KW, TERMS, MT, EPI>), grid, dim3(256), smem, st, a);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+template <int KH, int KW, int EPI, int MT> static int lm_g2_launch_terms(int terms, const LmG2Args& a, dim3 grid, size_t smem, hipStream_t st)
+{
+    return terms >= 3 ? lm_g2_launch_t<KH, KW, 3, MT, EPI>(a, grid, smem, st) : lm_g2_launch_t<KH, KW, 1, MT, EPI>(a, grid, smem, st);
+}
+
+static int lm_g2_launch(const LmF2Layer& l, const LmG2Args& a, dim3 grid, size_t smem, hipStream_t st)
+{
+    const int shape = l.kh * 10 + l.kw;
+    if (l.terms != 1 && l.terms != 3) { lm_set_error("lm_fcn2: operand formats are 1 (f16) or 3 (f16 hi + lo split) products per pair"); return LM_ERR_ARG; }
+    if (shape == 33 && l.epi == LM_G2_EPI_PO) {
+        if (l.mt == 1) return lm_g2_launch_terms<3, 3, LM_G2_EPI_PO, 1>(l.terms, a, grid, smem, st);
+        if (l.mt == 2) return lm_g2_launch_terms<3, 3, LM_G2_EPI_PO, 2>(l.terms, a, grid, smem, st);
+        if (l.mt == 3) return lm_g2_launch_terms<3, 3, LM_G2_EPI_PO, 3>(l.terms, a, grid, smem, st);
+        if (l.mt == 4) return lm_g2_launch_terms<3, 3, LM_G2_EPI_PO, 4>(l.terms, a, grid, smem, st);
+    } else if (shape == 11 && l.epi == LM_G2_EPI_TC) {
+        if (l.mt == 1) return lm_g2_launch_terms<1, 1, LM_G2_EPI_TC, 1>(l.terms, a, grid, smem, st);
+        if (l.mt == 2) return lm_g2_launch_terms<1, 1, LM_G2_EPI_TC, 2>(l.terms, a, grid, smem, st);
+        if (l.mt == 3) return lm_g2_launch_terms<1, 1, LM_G2_EPI_TC, 3>(l.terms, a, grid, smem, st);
+        if (l.mt == 4) return lm_g2_launch_terms<1, 1, LM_G2_EPI_TC, 4>(l.terms, a, grid, smem, st);
+    } else if (shape == 17 && l.epi == LM_G2_EPI_T) {
+        if (l.mt == 1) return lm_g2_launch_terms<1, 7, LM_G2_EPI_T, 1>(l.terms, a, grid, smem, st);
+    } else if (shape == 77 && l.epi == LM_G2_EPI_PO) {
+        if (l.mt == 1) return lm_g2_launch_terms<7, 7, LM_G2_EPI_PO, 1>(l.terms, a, grid, smem, st);
+        if (l.mt == 2) return lm_g2_launch_terms<7, 7, LM_G2_EPI_PO, 2>(l.terms, a, grid, smem, st);
+    }
+    lm_set_error("lm_fcn2: no kernel for a %dx%d layer with %d channel tiles, epilogue %d", l.kh, l.kw, l.mt, l.epi);
+    return LM_ERR_ARG;
+}
+
+// launches layer `li`: input planes per the recipe; `out` (EPI_PO / EPI_TC) with an optional pooled copy, or the T rows (EPI_T)
+static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor* pool, int act, float* tout, int ts, int tn, hipStream_t st)
+{
+    const LmF2Layer& l = f->layer[li];
+    if (!l.set) { lm_set_error("lm_fcn2_forward: layer %d has no weights (call lm_fcn2_set_layer)", li); return LM_ERR_STATE; }
+    const LmF2Tensor& in = f->t[l.planes[0]];
+    LmG2Args a;
+    memset(&a, 0, sizeof(a));
+    a.arena = f->arena; a.psrc = l.d_psrc; a.wpk = l.d_w; a.groups = l.d_groups; a.sdesc = l.d_sdesc; a.pdelta = l.d_pdelta; a.bias = l.d_bias;
+    a.wblock_bytes = l.wblock_bytes; a.nchunks = l.nchunks; a.npc = l.npc; a.ngroups = l.ngroups; a.npat = l.npat; a.wbuf_bytes = l.wbuf_bytes;
+    a.pdouble = l.pdouble; a.Wp_in = in.Wp;
+    a.org_in = (in.halo - (l.kh - 1) / 2) * in.Wp + in.halo - (l.kw - 1) / 2;
+    a.H = in.H; a.W = in.W;         // a convolution's output grid is its input grid; EPI_TC bounds its stores by the input grid
+    a.tiles_x = (in.W + 15) / 16;
+    a.act = act;
+    if (out) {
+        a.out_hi = f->arena + out->off; a.out_lo = out->lo ? a.out_hi + (long long)out->c8 * out->plane : nullptr;
+        a.out_plane = out->plane; a.Wp_out = out->Wp; a.halo_out = out->halo;
+        if (l.cout != out->c8 * 8) { lm_set_error("lm_fcn2_forward: layer %d has %d outputs for a tensor of %d channels", li, l.cout, out->c8 * 8); return LM_ERR_STATE; }
+    }
+    if (pool) { a.pool_hi = f->arena + pool->off; a.pool_lo = pool->lo ? a.pool_hi + (long long)pool->c8 * pool->plane : nullptr; a.pool_plane = pool->plane; a.Wp_pool = pool->Wp; a.halo_pool = pool->halo; }
+    a.tout = tout; a.ts = ts; a.tn = tn;
+    const int nhl = l.terms >= 2 ? 2 : 1;
+    const int PW = 16 + l.kw - 1, PH = 16 + l.kh - 1, PLS = (PH * PW * 16 + 255) & ~255;
+    const size_t smem = (size_t)((l.npat * 256 + 255) & ~255) + (size_t)(l.pdouble ? 2 : 1) * l.npc * nhl * PLS + (size_t)(l.ngroups > 1 ? 2 : 1) * l.wbuf_bytes;
+    if (smem > 160 * 1024) { lm_set_error("lm_fcn2_forward: layer %d needs %zu bytes of LDS", li, smem); return LM_ERR_STATE; }
+    const int tiles = a.tiles_x * ((in.H + 15) / 16);
+    const int blocks = l.cout / (16 * l.mt);
+    if (blocks * 16 * l.mt != l.cout) { lm_set_error("lm_fcn2_forward: layer %d: %d outputs are not whole blocks of %d tiles", li, l.cout, l.mt); return LM_ERR_STATE; }
+    return lm_g2_launch(l, a, dim3(tiles, blocks, l.epi == LM_G2_EPI_TC ? 4 : 1), smem, st);
+}
+
+extern "C" int lm_fcn2_forward(LmFcn2* f, const uint8_t* d_rgb, int h, int w, float* d_out, float* d_text, float* d_rec, void* stream)
+{
+    if (!f || !d_rgb || h < 32 || w < 32 || h > f->max_h || w > f->max_w) {
+        lm_set_error("lm_fcn2_forward: bad arguments (frame %dx%d, network sized for %dx%d)", w, h, f ? f->max_w : 0, f ? f->max_h : 0);
+        return LM_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (h != f->cur_h || w != f->cur_w) {
+        // new frame size: plane pitches change and everything outside the new images must read as zero (halos, tile overhang)
+        lm_f2_geometry(f, h, w);
+        LM_HIP(hipMemsetAsync(f->arena, 0, (size_t)f->arena_bytes, st));
+        for (auto& l : f->layer) {
+            if (!l.set) continue;
+            std::vector<long long> psrc((size_t)l.nchunks * l.npc * 2);
+            for (size_t i = 0; i < (size_t)l.nchunks * l.npc; i++) {
+                const LmF2Tensor& t = f->t[l.planes[2 * i]];
+                psrc[2 * i] = t.off + (long long)l.planes[2 * i + 1] * t.plane;
+                psrc[2 * i + 1] = psrc[2 * i] + (t.lo ? (long long)t.c8 * t.plane : 0);
+            }
+            LM_HIP(hipMemcpyAsync(l.d_psrc, psrc.data(), psrc.size() * 8, hipMemcpyHostToDevice, st));
+            LM_HIP(hipStreamSynchronize(st));       // psrc is a stack vector
+        }
+        f->cur_h = h; f->cur_w = w;
+    }
+    const long long npx = (long long)h * w;
+    LmF2Tensor* T = f->t;
+    int rc;
+    {
+        const LmF2Tensor& x0 = T[LM_F2_X0P];
+        char* hi = f->arena + x0.off;
+        hipLaunchKernelGGL(lm_k_prepare2, dim3((unsigned)std::min<long long>((npx + 255) / 256, 8192)), dim3(256), 0, st, d_rgb, hi, hi + x0.plane, h, w, x0.Wp, x0.halo);
+    }
+    // ---- encoder: conv_down_block_n -> PRE n (before pooling, the skip connection) + POOL n
+    for (int n = 0; n < 5; n++)
+        if ((rc = lm_f2_run(f, n, &T[LM_F2_PRE0 + n], &T[LM_F2_POOL0 + n], LM_ACT_GELU, nullptr, 0, 0, st))) return rc;
+    if ((rc = lm_f2_run(f, 5, &T[LM_F2_MID], nullptr, LM_ACT_GELU, nullptr, 0, 0, st))) return rc;
+    // ---- decoder
+    for (int n = 0; n < 5; n++) {
+        const LmF2Tensor& up = T[LM_F2_UPT0 + n];
+        const LmF2Tensor& in = T[f->layer[6 + n].planes[0]];
+        if ((rc = lm_f2_run(f, 6 + n, &up, nullptr, LM_ACT_GELU, nullptr, 0, 0, st))) return rc;
+        if (up.H > 2 * in.H || up.W > 2 * in.W) {
+            const long long nb = ((long long)(up.H - 2 * in.H) * up.W + (long long)2 * in.H * (up.W - 2 * in.W)) * up.c8;
+            char* hi = f->arena + up.off;
+            hipLaunchKernelGGL(lm_k_convT_border2, dim3((unsigned)std::min<long long>((nb + 255) / 256, 4096)), dim3(256), 0, st, hi,
+                               up.lo ? hi + (long long)up.c8 * up.plane : nullptr, up.plane, up.Wp, up.halo, up.H, up.W, 2 * in.H, 2 * in.W, up.c8,
+                               f->layer[6 + n].d_bias, LM_ACT_GELU);
+        }
+        if ((rc = lm_f2_run(f, 11 + n, n < 4 ? &T[LM_F2_CU0 + n] : &T[LM_F2_XUP], nullptr, LM_ACT_GELU, nullptr, 0, 0, st))) return rc;
+    }
+    // ---- heads
+    if ((rc = lm_f2_run(f, 16, nullptr, nullptr, LM_ACT_NONE, f->tbuf, 16, 16, st))) return rc;
+    {
+        const LmF2Tensor &x0 = T[LM_F2_X0P], &dp = T[LM_F2_DP];
+        const int tiles = ((w + 31) / 32) * ((h + 15) / 16);
+        hipLaunchKernelGGL(lm_k_vsum2_text_rec, dim3(tiles), dim3(256), 0, st, f->tbuf, h, w, f->layer[16].d_bias + 16, f->arena + x0.off,
+                           f->arena + x0.off + x0.plane, f->text, f->rec4, f->arena + dp.off, f->arena + dp.off + dp.plane, dp.Wp, dp.halo);
+    }
+    if ((rc = lm_f2_run(f, 18, &T[LM_F2_P1], nullptr, LM_ACT_GELU, nullptr, 0, 0, st))) return rc;
+    if ((rc = lm_f2_run(f, 19, &T[LM_F2_P2], nullptr, LM_ACT_GELU, nullptr, 0, 0, st))) return rc;
+    if ((rc = lm_f2_run(f, 20, nullptr, nullptr, LM_ACT_NONE, f->tbuf, 8, 8, st))) return rc;
+    {
+        const int tiles = ((w + 31) / 32) * ((h + 15) / 16);
+        hipLaunchKernelGGL((lm_k_vsum<7, 1, 8, false>), dim3(tiles), dim3(256), 0, st, f->tbuf, h, w, f->layer[20].d_bias + 16, LM_ACT_NONE, f->outl, 1,
+                           nullptr, nullptr, nullptr);
+    }
+    if (d_out) LM_HIP(hipMemcpyAsync(d_out, f->outl, (size_t)npx * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (d_text) LM_HIP(hipMemcpyAsync(d_text, f->text, (size_t)npx * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (d_rec) hipLaunchKernelGGL(lm_k_nhwc4_to_chw3, dim3((unsigned)std::min<long long>((npx + 255) / 256, 8192)), dim3(256), 0, st, f->rec4, d_rec, npx);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}

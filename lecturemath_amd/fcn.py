@@ -113,17 +113,33 @@ def _pad8(c):
 class FcnEngine:
     """Device network built from a reference state_dict."""
 
-    def __init__(self, widths, pixel_kernel, kernel, max_h, max_w, lib=None, precision="f16x3"):
-        """precision: "f16x3" (default; fp16-split operands, three f16 MFMAs per product, fp32 accumulate, ~1e-6 relative
-        error at 5x the fp32 MFMA rate), "f16x2" (activations split, weights rounded to f16: two MFMAs), "f16" (both operands
-        rounded to f16: one MFMA) or "fp32" (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains)."""
-        assert precision in ("f16x3", "f16x2", "f16", "fp32")
-        self.precision = precision
+    # layers that keep the f16 hi + lo split in the "mixed" assignment: the full-resolution ones (profiles/r03_fcn_layer_precision.*:
+    # every layer below full resolution on plain f16 operands changes the logits by 3e-5 in all, each of these by 0.5-3e-4 alone)
+    MIXED_SPLIT_LAYERS = (L_DOWN, L_UPC + 4, L_TEXT, L_REC, L_PX1, L_PX2, L_OUT)
+
+    def __init__(self, widths, pixel_kernel, kernel, max_h, max_w, lib=None, precision="mixed"):
+        """precision:
+        "mixed" (default) -- the planar engine (csrc/lm_fcn2.hip): f16 hi + lo split operands (three MFMAs per product, ~22 bits per
+            operand) in the full-resolution layers, plain f16 operands below; needs the shipped kernel sizes (7x7 pixel branch, 3x3
+            elsewhere) and widths that are multiples of 16, otherwise this falls back to "f16x3";
+        "planar-f16x3" / "planar-f16" -- the planar engine with one format everywhere;
+        "f16x3" / "f16x2" / "f16" / "fp32" -- the first engine (csrc/lm_fcn.hip): fp32 activations, operands split while staged
+            (three, two or one f16 MFMA per product) or exact fp32 MFMA chains."""
+        assert precision in ("mixed", "planar-f16x3", "planar-f16", "f16x3", "f16x2", "f16", "fp32")
         self.lib = lib or _lib.load()
         self.be = Backend(self.lib)
         self.widths = [int(v) for v in widths]
         self.pk, self.kk = int(pixel_kernel), int(kernel)
         self.max_h, self.max_w = max_h, max_w
+        planar_ok = self.pk == 7 and self.kk == 3 and all(v % 16 == 0 for v in self.widths)
+        if precision in ("mixed", "planar-f16x3", "planar-f16") and not planar_ok:
+            precision = {"mixed": "f16x3", "planar-f16x3": "f16x3", "planar-f16": "f16"}[precision]
+        self.precision = precision
+        self.planar = precision in ("mixed", "planar-f16x3", "planar-f16")
+        self.handle = None
+        self.handle2 = None
+        if self.planar:
+            return          # lm_fcn2_create needs the tensors' lo flags: created by load_state_dict
         arr = (ctypes.c_int32 * 18)(*self.widths)
         self.handle = self.lib.lm_fcn_create(arr, self.pk, self.kk, max_h, max_w)
         if not self.handle:
@@ -133,6 +149,9 @@ class FcnEngine:
         if getattr(self, "handle", None):
             self.lib.lm_fcn_destroy(self.handle)
             self.handle = None
+        if getattr(self, "handle2", None):
+            self.lib.lm_fcn2_destroy(self.handle2)
+            self.handle2 = None
 
     def __del__(self):
         try:
@@ -145,7 +164,89 @@ class FcnEngine:
         b = np.ascontiguousarray(b, np.float32)
         self.lib.check(self.lib.lm_fcn_set_layer(self.handle, layer, w.ctypes.data, w.size, b.ctypes.data, b.size, cin, cout, k, ck))
 
+    def layer_terms(self, layer):
+        """MFMA products per operand pair of a layer of the planar engine"""
+        if self.precision == "planar-f16":
+            return 1
+        if self.precision == "planar-f16x3":
+            return 3
+        return 3 if layer in self.MIXED_SPLIT_LAYERS else 1
+
+    def _load_planar(self, sd):
+        """recipes of csrc/lm_fcn2.hip (lecturemath_amd/fcn2.py)"""
+        from . import fcn2 as f2
+        d1, d2, d3, d4, d5, mid, u5, c5, u4, c4, u3, c3, u2, c2, u1, c1, pm1, pm2 = self.widths
+        downs = [d1, d2, d3, d4, d5]
+
+        def conv_bn(name):
+            w, b = _np(sd[name + ".0.weight"]).astype(np.float32), _np(sd[name + ".0.bias"]).astype(np.float32)
+            return fold_bn(w, b, sd, name + ".1", 0)
+
+        def tiles(level):
+            return (((self.max_h >> level) + 15) // 16) * (((self.max_w >> level) + 15) // 16)
+
+        T = self.layer_terms
+        recipes = {}
+        # encoder: layer 1 reads the input pair plane (3 channels, two horizontal taps per slot)
+        w, b = conv_bn("conv_down_block_1")
+        pairs = [f2.pairplane_pair(0, dy, dx, 0, 3) for dy in range(3) for dx in (0, 2)]
+        recipes[L_DOWN] = (f2.build([w], [{"planes": [(f2.T_X0P, 0)], "pairs": pairs}], 3, 3, 3 if T(L_DOWN) > 1 else 1, f2.pick_mt(d1, tiles(0)), f2.EPI_PO), b)
+        cin = [3] + downs
+        for n in range(1, 5):
+            w, b = conv_bn("conv_down_block_%d" % (n + 1))
+            recipes[L_DOWN + n] = (f2.conv_layer(w, [(f2.T_POOL0 + n - 1, cin[n] // 8)], T(L_DOWN + n), tiles(n)), b)
+        w, b = conv_bn("mid_block")
+        recipes[L_MID] = (f2.conv_layer(w, [(f2.T_POOL0 + 4, d5 // 8)], T(L_MID), tiles(5)), b)
+        ups = {5: (mid, u5, c5, d5), 4: (c5, u4, c4, d4), 3: (c4, u3, c3, d3), 2: (c3, u2, c2, d2), 1: (c2, u1, c1, d1)}
+        for i, lvl in enumerate((5, 4, 3, 2, 1)):
+            tin, u, c, skip = ups[lvl]
+            wt = _np(sd["transposed_conv_%d.weight" % lvl]).astype(np.float32)          # [Cin][Cout][2][2]
+            bt = _np(sd["transposed_conv_%d.bias" % lvl]).astype(np.float32)
+            wt, bt = fold_bn(wt, bt, sd, "upsample_block_%d.0" % lvl, 1)
+            src = f2.T_MID if i == 0 else f2.T_CU0 + i - 1
+            w4 = [np.ascontiguousarray(wt[:, :, dy, dx].T)[:, :, None, None] for dy in (0, 1) for dx in (0, 1)]
+            co = 4 if (tin // 8) % 4 == 0 else 2
+            chunks = f2.conv_chunks([(src, tin // 8)], 1, 1, co)
+            recipes[L_UPT + i] = (f2.build(w4, chunks, 1, 1, T(L_UPT + i), f2.pick_mt(u, tiles(lvl)), f2.EPI_TC), bt)
+            w, b = conv_bn("conv_up_block_%d" % lvl)                                      # input = cat(up, skip_pre)
+            recipes[L_UPC + i] = (f2.conv_layer(w, [(f2.T_UPT0 + i, u // 8), (f2.T_PRE0 + lvl - 1, skip // 8)], T(L_UPC + i), tiles(lvl - 1)), b)
+        # heads
+        wt, bt = conv_bn("conv_text_mask_out")
+        wr, br = conv_bn("conv_reconstruct")
+        rows = f2.text_rec_rows(wt, wr)
+        recipes[L_TEXT] = (f2.build([rows], f2.conv_chunks([(f2.T_XUP, c1 // 8)], 1, 7, c1 // 8), 1, 7, T(L_TEXT), 1, f2.EPI_T),
+                           np.concatenate([np.zeros(16, np.float32), bt, br]))
+        w, b = conv_bn("conv_pixels_1")
+        recipes[L_PX1] = (f2.build([w], f2.pixel_chunks(f2.T_XUP, c1 // 8, f2.T_DP, 7, 7), 7, 7, T(L_PX1), 2 if pm1 % 32 == 0 else 1, f2.EPI_PO, pdouble=False), b)
+        w, b = conv_bn("conv_pixels_2")
+        recipes[L_PX2] = (f2.build([w], f2.pixel_chunks(f2.T_P1, pm1 // 8, f2.T_DP, 7, 7), 7, 7, T(L_PX2), 2 if pm2 % 32 == 0 else 1, f2.EPI_PO, pdouble=False), b)
+        w, b = conv_bn("conv_out")
+        recipes[L_OUT] = (f2.build([f2.out_rows(w)], f2.pixel_chunks(f2.T_P2, pm2 // 8, f2.T_DP, 1, 7), 1, 7, T(L_OUT), 1, f2.EPI_T, pdouble=False),
+                          np.concatenate([np.zeros(16, np.float32), b]))
+        # a tensor keeps its lo parts when a layer reading it runs the split format
+        lo = np.zeros(f2.N_TENSORS, np.int32)
+        for (desc, _, _, _), _ in recipes.values():
+            if desc[2] >= 2:
+                npl = int(desc[5] * desc[6])
+                lo[desc[13:13 + 2 * npl:2]] = 1
+        if self.handle2:
+            self.lib.lm_fcn2_destroy(self.handle2)
+        arr = (ctypes.c_int32 * 18)(*self.widths)
+        self.handle2 = self.lib.lm_fcn2_create(arr, lo.ctypes.data, self.max_h, self.max_w)
+        if not self.handle2:
+            raise _lib.LecturemathError(_lib.LM_ERR_ARG, self.lib.last_error())
+        self.recipes = {}
+        for layer, ((desc, wpk, wblocks, need), bias) in recipes.items():
+            bias = np.ascontiguousarray(bias, np.float32)
+            self.lib.check(self.lib.lm_fcn2_set_layer(self.handle2, layer, desc.ctypes.data, desc.size, wpk.ctypes.data, wpk.nbytes, wblocks,
+                                                      bias.ctypes.data, bias.size))
+            self.recipes[layer] = {"kh": int(desc[0]), "kw": int(desc[1]), "terms": int(desc[2]), "mt": int(desc[3]), "chunks": int(desc[5]),
+                                   "planes_per_chunk": int(desc[6]), "groups": int(desc[7]), "slices": int(desc[8]), "patterns": int(desc[9]),
+                                   "lds_bytes": int(need)}
+
     def load_state_dict(self, sd):
+        if self.planar:
+            return self._load_planar(sd)
         d1, d2, d3, d4, d5, mid, u5, c5, u4, c4, u3, c3, u2, c2, u1, c1, pm1, pm2 = self.widths
         downs = [d1, d2, d3, d4, d5]
 
@@ -237,6 +338,8 @@ class FcnEngine:
     def set_layer_precision(self, layer, precision):
         """Operand format of ONE layer ("f16x3" / "f16x2" / "f16"); the engine must have been loaded with an fp16-split precision."""
         terms = {"f16x3": 3, "f16x2": 2, "f16": 1}[precision]
+        if self.planar:
+            raise _lib.LecturemathError(_lib.LM_ERR_STATE, "the planar engine's formats are fixed by load_state_dict (precision=...)")
         self.lib.check(self.lib.lm_fcn_set_layer_terms(self.handle, int(layer), terms))
 
     def forward(self, rgb):
@@ -247,6 +350,8 @@ class FcnEngine:
         out = self.be.empty((h, w), np.float32)
         text = self.be.empty((h, w), np.float32)
         rec = self.be.empty((3, h, w), np.float32)
-        self.lib.check(self.lib.lm_fcn_forward(self.handle, _lib.ptr(rgb), h, w, _lib.ptr(out), _lib.ptr(text), _lib.ptr(rec),
-                                               self.be.stream()))
+        fwd, hd = (self.lib.lm_fcn2_forward, self.handle2) if self.planar else (self.lib.lm_fcn_forward, self.handle)
+        if not hd:
+            raise _lib.LecturemathError(_lib.LM_ERR_STATE, "FcnEngine.forward before load_state_dict")
+        self.lib.check(fwd(hd, _lib.ptr(rgb), h, w, _lib.ptr(out), _lib.ptr(text), _lib.ptr(rec), self.be.stream()))
         return out, text, rec

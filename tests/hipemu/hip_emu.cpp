@@ -305,3 +305,34 @@ lm_f32x16 hipemu_mfma_32x32x16f16(emu_h8 a, emu_h8 b, lm_f32x16 c)
     }
     return c;
 }
+
+// v_mfma_f32_16x16x32_f16: lane l holds A[row l&15][k = 8*(l>>4) + j] and B[k = 8*(l>>4) + j][col l&15], j = 0..7;
+// C/D: col = lane & 15, row = (lane >> 4) * 4 + reg (cdna_hip_programming.md section 3)
+typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+emu_f32x4 hipemu_mfma_16x16x32f16(emu_h8 a, emu_h8 b, emu_f32x4 c)
+{
+    static thread_local _Float16 A[64][8], B[64][8];
+    unsigned long long raw[4];
+    memcpy(raw, &a, 16);
+    memcpy(raw + 2, &b, 16);
+    unsigned long long act;
+    const int lane = hipemu::lane_id();
+    unsigned long long all[4][64];
+    for (int q = 0; q < 4; q++) {
+        const unsigned long long* v = hipemu::wave_gather(raw[q], &act);
+        memcpy(all[q], v, sizeof(all[q]));
+    }
+    for (int l = 0; l < 64; l++) {
+        memcpy(&A[l][0], &all[0][l], 8); memcpy(&A[l][4], &all[1][l], 8);
+        memcpy(&B[l][0], &all[2][l], 8); memcpy(&B[l][4], &all[3][l], 8);
+    }
+    const int col = lane & 15;
+    for (int r = 0; r < 4; r++) {
+        const int row = (lane >> 4) * 4 + r;
+        float acc = c[r];
+        for (int g = 0; g < 4; g++)
+            for (int j = 0; j < 8; j++) acc += (float)A[row + 16 * g][j] * (float)B[col + 16 * g][j];
+        c[r] = acc;
+    }
+    return c;
+}
