@@ -43,6 +43,23 @@ lm_f32x4 hipemu_mfma_16x16x32f16(lm_h8 a, lm_h8 b, lm_f32x4 c);
 #define LM_VMWAIT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 
+// waits until at most n (wave-uniform, 0..6) of the wave's vector-memory operations are outstanding; they retire in issue order, so
+// this leaves the n youngest -- the LDS-DMA of the weight group after next -- in flight across the barrier
+LM_DEV void lm_vmwait(int n)
+{
+#if !LM_HIP_EMULATED
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    }
+#endif
+}
+
 #define LM_G2_EPI_PO 0      // planar-octet output (+ optional lo planes, + optional 2x2 max-pooled copy), GELU or none
 #define LM_G2_EPI_T 1       // fp32 [pixel][TS] rows of the head row convolutions (lm_k_vsum2_*), no activation
 #define LM_G2_EPI_TC 2      // transposed 2x2 / stride 2: blockIdx.z = dy * 2 + dx, output pixel (2y + dy, 2x + dx), planar octets
@@ -58,10 +75,11 @@ struct LmG2Args {
     long long wblock_bytes;
     int nchunks, npc, ngroups, npat;
     int wbuf_bytes;                 // LDS bytes of one weight buffer (largest group)
+    int wring;                      // weight buffers (2 or 3): wring - 1 groups are in flight or in use ahead of the one being read
     int pdouble;                    // 1: two patch buffers (next chunk fetched under the current one)
     int Wp_in;                      // slots per padded input row
     int org_in;                     // slot offset of tile (0, 0)'s patch origin in a plane
-    int tiles_x;
+    int tiles_x, tiles_y, cblocks;  // pixel tiles, channel blocks of MT * 16 outputs
     int H, W;                       // output grid of this launch (bounds of the stores; the input grid for EPI_TC)
     int act;                        // LM_ACT_GELU or LM_ACT_NONE
     // EPI_PO / EPI_TC output tensor
@@ -75,8 +93,12 @@ struct LmG2Args {
 
 // one 16 x 16 pixel tile x MT channel tiles; see the header comment
 template <int KH, int KW, int TERMS, int MT, int EPI>
-__global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a)
+__global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a, const long long* __restrict__ t_psrc, const int4* __restrict__ t_groups,
+                                                  const uint2* __restrict__ t_sdesc, const int* __restrict__ t_pdelta, const float* __restrict__ t_bias)
 {
+    // The tables come as __restrict__ kernel arguments of their own: read-only and never aliased by the kernel's stores, they are read
+    // with SCALAR loads.  As members of `a` they were vector loads -- and a wave waits for a vector load's result with vmcnt, which also
+    // waits for every LDS-DMA issued before it: one such load per slice serialised the whole fetch pipeline.
     LM_DYN_SMEM(smem);
     constexpr int PW = 16 + KW - 1, PH = 16 + KH - 1, NSLOT = PH * PW;
     constexpr int PLS = (NSLOT * 16 + 255) & ~255;      // LDS bytes per plane: planes a multiple of the 256-B bank row apart, so the 16
@@ -87,13 +109,24 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a)
     constexpr int NJ = (NSLOT + 255) / 256;             // DMA instructions per thread and plane
     constexpr int NT = 4;
     const int lane = lm_lane(), wave = LM_UNIFORM((int)(threadIdx.x >> 6)), kg = lane >> 4, col = lane & 15;
-    const int ty = (int)blockIdx.x / a.tiles_x, tx = (int)blockIdx.x - ty * a.tiles_x;
+    // Workgroup -> (pixel tile, channel block).  The launch is one-dimensional; consecutive ids go round the 8 XCDs, so id % 8 names
+    // the workgroups that share an L2.  Each of them takes a contiguous share of the (channel block, tile) list: an XCD then streams
+    // the weights of one or two channel blocks (they stay in its 4 MB L2) instead of every block's (5-10 MB in the deep layers).
+    int wg = (int)blockIdx.x;
+    {
+        const int nwg = (int)gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7, j = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int cblk = wg / tiles, tile = wg - cblk * tiles;          // channel block (x parity for EPI_TC), tile
+    const int cby = (EPI == LM_G2_EPI_TC) ? cblk % a.cblocks : cblk, par = (EPI == LM_G2_EPI_TC) ? cblk / a.cblocks : 0;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int pbuf_bytes = a.npc * NHL * PLS;
     char* const s_pat = smem;                                           // [npat][64] ints: column part + pattern offset of the lane's k-group
     char* const s_p0 = smem + ((a.npat * 256 + 255) & ~255);
     char* const s_w0 = s_p0 + (a.pdouble ? 2 : 1) * pbuf_bytes;
     if (wave == 0)
-        for (int p = 0; p < a.npat; p++) ((int*)s_pat)[p * 64 + lane] = col * 16 + a.pdelta[p * 4 + kg];
+        for (int p = 0; p < a.npat; p++) ((int*)s_pat)[p * 64 + lane] = col * 16 + t_pdelta[p * 4 + kg];
     const int wrow = wave * (4 * PW * 16);                              // the wave's first pixel row inside a plane
 
     // DMA source offsets of the thread's slots inside a plane (the same for every plane and chunk)
@@ -107,24 +140,27 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a)
         gval[j] = slot < NSLOT;
     }
     const long long tile_org = ((long long)(ty * 16) * a.Wp_in + tx * 16 + a.org_in) * 16;
-    const char* const wsrc = a.wpk + (long long)blockIdx.y * a.wblock_bytes + (EPI == LM_G2_EPI_TC ? (long long)blockIdx.z * a.wblock_bytes * gridDim.y : 0);
+    const char* const wsrc = a.wpk + ((long long)par * a.cblocks + cby) * a.wblock_bytes;
 
     auto issue_patch = [&](int chunk, int buf) {
         char* const dst = s_p0 + buf * pbuf_bytes;
         for (int p = 0; p < a.npc; p++)
 #pragma unroll
             for (int hl = 0; hl < NHL; hl++) {
-                const char* src = a.arena + a.psrc[(chunk * a.npc + p) * 2 + hl] + tile_org;
+                const char* src = a.arena + t_psrc[(chunk * a.npc + p) * 2 + hl] + tile_org;
 #pragma unroll
                 for (int j = 0; j < NJ; j++)
                     if (gval[j]) LM_DMA16(src + goff[j], dst + (p * NHL + hl) * PLS + (j * 4 + wave) * 1024);
             }
     };
-    auto issue_weights = [&](const int4 grp, int buf) {
+    // returns the number of DMA instructions THIS wave issued (wave-uniform: a group is a whole number of 1-KB fragments)
+    auto issue_weights = [&](const int4 grp, int buf) -> int {
         const char* src = wsrc + grp.w;
         char* const dst = s_w0 + buf * a.wbuf_bytes;
         const int n16 = grp.y * (MT * NWL * 64);
         for (int i = (int)threadIdx.x; i < n16; i += 256) LM_DMA16(src + (long long)i * 16, dst + (i - lane) * 16);
+        const int mine = n16 - wave * 64;
+        return mine > 0 ? (mine + 255) >> 8 : 0;
     };
 
     lm_f32x4 acc[MT][NT];
@@ -135,69 +171,109 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a)
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[m][n][r] = 0.0f;
 
-    int4 grp = a.groups[0];
+    // Weight groups go through a ring of a.wring buffers: while group g is read, g + 1 has landed or is landing and (ring of 3) g + 2
+    // is being fetched.  Per group: issue the fetches, run the group's MFMAs, wait until only the youngest fetch (the group after
+    // next) is outstanding, barrier.
+    const int ring = a.wring;
+    int4 grp = t_groups[0];
     issue_patch(0, 0);
     issue_weights(grp, 0);
-    LM_VMWAIT0();
+    int n_ahead = 0;                            // DMA instructions of this wave that may stay in flight across the next barrier
+    int4 nxt = grp;
+    if (a.ngroups > 1) { nxt = t_groups[1]; n_ahead = issue_weights(nxt, 1); }
+    if (ring < 3) n_ahead = 0;
+    lm_vmwait(n_ahead);
     lm_lds_barrier();
     int pb = 0, wb = 0, prev_chunk = -1;
     for (int g = 0; g < a.ngroups; g++) {
         const bool more = g + 1 < a.ngroups;
-        int4 nxt = grp;
-        if (more) {
-            nxt = a.groups[g + 1];
-            issue_weights(nxt, wb ^ 1);
-            // first group of a chunk: the next chunk's planes go into the other patch buffer, read last before the barrier that ended
-            // the previous chunk
-            if (a.pdouble && grp.z + 1 < a.nchunks && grp.z != prev_chunk) issue_patch(grp.z + 1, pb ^ 1);
-        }
+        int wb2 = wb + 2; if (wb2 >= ring) wb2 -= ring;
+        // first group of a chunk: the next chunk's planes go into the other patch buffer, read last before the barrier that ended the
+        // previous chunk.  Issued BEFORE the weights: it must have landed by the end of this group, the weights need not.
+        if (a.pdouble && grp.z + 1 < a.nchunks && grp.z != prev_chunk) issue_patch(grp.z + 1, pb ^ 1);
         prev_chunk = grp.z;
+        n_ahead = 0;
+        if (ring >= 3) {
+            if (g + 2 < a.ngroups) n_ahead = issue_weights(t_groups[g + 2], wb2);
+        } else if (more && g > 0) {
+            // ring of 2: group g + 1 goes into the buffer group g - 1 was read from (group 1 was fetched in the prologue)
+            issue_weights(nxt, wb ^ 1);
+        }
         const char* const pbase = s_p0 + pb * pbuf_bytes + wrow;
         const char* const wbase = s_w0 + wb * a.wbuf_bytes + lane * 16;
-        for (int s = 0; s < grp.y; s++) {
-            const uint2 d = a.sdesc[grp.x + s];
-            const char* pa = pbase + d.x + ((const int*)s_pat)[(int)d.y * 64 + lane];
-            const char* wa = wbase + s * (MT * NWL * 1024);
-            lm_h8 bh[NT], bl[NT], ah[MT], al[MT];
+        // The group's slices, software-pipelined by hand: the fragments of slice s + 1 are requested before the MFMAs of slice s, its
+        // descriptor (scalar load -> pattern word from LDS -> fragment addresses: three dependent latencies) one slice earlier still.
+        // t_sdesc is padded by two entries, so the look-ahead needs no bounds.
+        struct Frag { lm_h8 bh[NT], bl[NT], ah[MT], al[MT]; };
+        auto pat = [&](const uint2 d) { return ((const int*)s_pat)[(int)d.y * 64 + lane]; };
+        auto load = [&](const uint2 d, int po, int sl, Frag& f) {
+            const char* pa = pbase + d.x + po;
+            const char* wa = wbase + sl * (MT * NWL * 1024);
 #pragma unroll
             for (int n = 0; n < NT; n++) {
-                bh[n] = *(const lm_h8*)(pa + n * (PW * 16));
-                if (TERMS >= 2) bl[n] = *(const lm_h8*)(pa + n * (PW * 16) + PLS);
+                f.bh[n] = *(const lm_h8*)(pa + n * (PW * 16));
+                if (TERMS >= 2) f.bl[n] = *(const lm_h8*)(pa + n * (PW * 16) + PLS);
             }
 #pragma unroll
             for (int m = 0; m < MT; m++) {
-                ah[m] = *(const lm_h8*)(wa + m * (NWL * 1024));
-                if (TERMS >= 3) al[m] = *(const lm_h8*)(wa + m * (NWL * 1024) + 1024);
+                f.ah[m] = *(const lm_h8*)(wa + m * (NWL * 1024));
+                if (TERMS >= 3) f.al[m] = *(const lm_h8*)(wa + m * (NWL * 1024) + 1024);
             }
+        };
+        auto mma = [&](const Frag& f) {
 #pragma unroll
             for (int m = 0; m < MT; m++)
 #pragma unroll
-                for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA16(ah[m], bh[n], acc[m][n]);
+                for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA16(f.ah[m], f.bh[n], acc[m][n]);
             if (TERMS >= 3) {
 #pragma unroll
                 for (int m = 0; m < MT; m++)
 #pragma unroll
-                    for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA16(al[m], bh[n], acc[m][n]);
+                    for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA16(f.al[m], f.bh[n], acc[m][n]);
             }
             if (TERMS >= 2) {
 #pragma unroll
                 for (int m = 0; m < MT; m++)
 #pragma unroll
-                    for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA16(ah[m], bl[n], acc[m][n]);
+                    for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA16(f.ah[m], f.bl[n], acc[m][n]);
+            }
+        };
+        {
+            const uint2* dsc = t_sdesc + grp.x;
+            const int ns = grp.y;
+            Frag f0, f1;
+            uint2 dn = dsc[1];
+            int pn = pat(dn);
+            load(dsc[0], pat(dsc[0]), 0, f0);
+            int sl = 0;
+            for (; sl + 1 < ns; sl += 2) {
+                const uint2 d2 = dsc[sl + 2];
+                const int p2 = pat(d2);
+                load(dn, pn, sl + 1, f1);
+                mma(f0);
+                dn = dsc[sl + 3];
+                pn = pat(dn);
+                if (sl + 2 < ns) load(d2, p2, sl + 2, f0);
+                mma(f1);
+            }
+            if (sl < ns) mma(f0);
+        }
+        lm_vmwait(n_ahead);
+        lm_lds_barrier();       // this group's buffer is free; the next group's weights (and the next chunk's planes) have landed
+        if (++wb >= ring) wb = 0;
+        if (more) {
+            const int4 cur = grp;
+            grp = nxt;
+            if (g + 2 < a.ngroups) nxt = t_groups[g + 2];
+            if (grp.z != cur.z) {
+                if (a.pdouble) pb ^= 1;
+                else {              // one patch buffer: the next chunk's planes are fetched now, in the open
+                    issue_patch(grp.z, 0);
+                    LM_VMWAIT0();
+                    lm_lds_barrier();
+                }
             }
         }
-        LM_VMWAIT0();
-        lm_lds_barrier();       // this group's buffers are free, the next group's weights (and planes) have landed
-        wb ^= 1;
-        if (more && nxt.z != grp.z) {
-            if (a.pdouble) pb ^= 1;
-            else {              // one patch buffer: the next chunk's planes are fetched now, in the open
-                issue_patch(nxt.z, 0);
-                LM_VMWAIT0();
-                lm_lds_barrier();
-            }
-        }
-        grp = nxt;
     }
 
     // ---------------------------------------------------------------- epilogues
@@ -213,16 +289,16 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a)
             }
         }
     } else {
-        const int cb = (int)blockIdx.y * (MT * 16);                  // first channel of the workgroup
+        const int cb = cby * (MT * 16);                  // first channel of the workgroup
         const bool gelu = a.act == LM_ACT_GELU;
-        const int dy = (EPI == LM_G2_EPI_TC) ? ((int)blockIdx.z >> 1) : 0, dx = (EPI == LM_G2_EPI_TC) ? ((int)blockIdx.z & 1) : 0;
+        const int dy = par >> 1, dx = par & 1;
         const int sc = (EPI == LM_G2_EPI_TC) ? 2 : 1;
         // pairs of tiles: the host packs tile 2q with the channels 32q + 8kg + (0..3) in rows 4kg + (0..3) and tile 2q + 1 with
         // 32q + 8kg + 4 + (0..3), so a lane holds one whole octet of its pixel: one 16-byte store per part
 #pragma unroll
         for (int q = 0; q < MT / 2; q++) {
             const int ch = cb + 32 * q + 8 * kg;
-            const float4 b0 = *(const float4*)(a.bias + ch), b1 = *(const float4*)(a.bias + ch + 4);
+            const float4 b0 = *(const float4*)(t_bias + ch), b1 = *(const float4*)(t_bias + ch + 4);
             const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
             const long long oplane = (long long)(ch >> 3) * a.out_plane;
             float v[NT][8];
@@ -268,7 +344,7 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a)
         if constexpr (MT & 1) {         // the unpaired last tile: channels in row order, a lane holds half an octet (8-byte stores)
             constexpr int m = MT - 1;
             const int ch = cb + 16 * m + 4 * kg;
-            const float4 b0 = *(const float4*)(a.bias + ch);
+            const float4 b0 = *(const float4*)(t_bias + ch);
             const float bb[4] = {b0.x, b0.y, b0.z, b0.w};
             const long long oplane = (long long)(ch >> 3) * a.out_plane + (kg & 1) * 8;
             float v[NT][4];
@@ -548,13 +624,14 @@ extern "C" int lm_fcn2_set_layer(LmFcn2* f, int layer, const int32_t* desc, int 
     LM_HIP(hipMalloc((void**)&l.d_w, (size_t)wbytes));
     LM_HIP(hipMalloc((void**)&l.d_bias, (size_t)nbias * 4));
     LM_HIP(hipMalloc((void**)&l.d_groups, groups.size() * sizeof(int4)));
-    LM_HIP(hipMalloc((void**)&l.d_sdesc, (size_t)l.nslices * 8));
+    LM_HIP(hipMalloc((void**)&l.d_sdesc, (size_t)(l.nslices + 2) * 8));      // + 2: the kernel's descriptor look-ahead
     LM_HIP(hipMalloc((void**)&l.d_pdelta, (size_t)l.npat * 16));
     LM_HIP(hipMalloc((void**)&l.d_psrc, (size_t)l.nchunks * l.npc * 16));
     LM_HIP(hipMemcpy(l.d_w, h_w, (size_t)wbytes, hipMemcpyHostToDevice));
     LM_HIP(hipMemcpy(l.d_bias, h_bias, (size_t)nbias * 4, hipMemcpyHostToDevice));
     LM_HIP(hipMemcpy(l.d_groups, groups.data(), groups.size() * sizeof(int4), hipMemcpyHostToDevice));
     LM_HIP(hipMemcpy(l.d_sdesc, h_sdesc, (size_t)l.nslices * 8, hipMemcpyHostToDevice));
+    for (int k = 0; k < 2; k++) LM_HIP(hipMemcpy(l.d_sdesc + l.nslices + k, h_sdesc + (size_t)(l.nslices - 1) * 2, 8, hipMemcpyHostToDevice));
     LM_HIP(hipMemcpy(l.d_pdelta, h_pdelta, (size_t)l.npat * 16, hipMemcpyHostToDevice));
     l.set = true;
     f->cur_h = f->cur_w = 0;        // plane tables are rebuilt by the next forward
@@ -566,7 +643,7 @@ template <int KH, int KW, int TERMS, int MT, int EPI> static int lm_g2_launch_t(
 #if !LM_HIP_EMULATED
     LM_HIP(hipFuncSetAttribute((const void*)lm_k_g2<KH, KW, TERMS, MT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 #endif
-    hipLaunchKernelGGL((lm_k_g2<KH, KW, TERMS, MT, EPI>), grid, dim3(256), smem, st, a);
+    hipLaunchKernelGGL((lm_k_g2<KH, KW, TERMS, MT, EPI>), grid, dim3(256), smem, st, a, a.psrc, a.groups, a.sdesc, a.pdelta, a.bias);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }
@@ -624,12 +701,21 @@ static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor*
     a.tout = tout; a.ts = ts; a.tn = tn;
     const int nhl = l.terms >= 2 ? 2 : 1;
     const int PW = 16 + l.kw - 1, PH = 16 + l.kh - 1, PLS = (PH * PW * 16 + 255) & ~255;
-    const size_t smem = (size_t)((l.npat * 256 + 255) & ~255) + (size_t)(l.pdouble ? 2 : 1) * l.npc * nhl * PLS + (size_t)(l.ngroups > 1 ? 2 : 1) * l.wbuf_bytes;
+    // weight ring: three buffers when they fit beside two resident workgroups (or the layer cannot have two anyway), else two
+    const size_t fixed = (size_t)((l.npat * 256 + 255) & ~255) + (size_t)(l.pdouble ? 2 : 1) * l.npc * nhl * PLS;
+    static const int ring_env = [] { const char* e = getenv("LM_FCN2_RING"); return e ? atoi(e) : 0; }();
+    int ring = l.ngroups > 2 ? 3 : (l.ngroups > 1 ? 2 : 1);
+    if (ring == 3 && fixed + 3 * (size_t)l.wbuf_bytes > 80 * 1024 && fixed + 2 * (size_t)l.wbuf_bytes <= 80 * 1024) ring = 2;
+    if (ring_env == 2 && ring == 3) ring = 2;
+    a.wring = ring < 2 ? 2 : ring;
+    const size_t smem = fixed + (size_t)ring * l.wbuf_bytes;
     if (smem > 160 * 1024) { lm_set_error("lm_fcn2_forward: layer %d needs %zu bytes of LDS", li, smem); return LM_ERR_STATE; }
-    const int tiles = a.tiles_x * ((in.H + 15) / 16);
+    a.tiles_y = (in.H + 15) / 16;
+    const int tiles = a.tiles_x * a.tiles_y;
     const int blocks = l.cout / (16 * l.mt);
     if (blocks * 16 * l.mt != l.cout) { lm_set_error("lm_fcn2_forward: layer %d: %d outputs are not whole blocks of %d tiles", li, l.cout, l.mt); return LM_ERR_STATE; }
-    return lm_g2_launch(l, a, dim3(tiles, blocks, l.epi == LM_G2_EPI_TC ? 4 : 1), smem, st);
+    a.cblocks = blocks;
+    return lm_g2_launch(l, a, dim3((unsigned)tiles * blocks * (l.epi == LM_G2_EPI_TC ? 4 : 1)), smem, st);
 }
 
 extern "C" int lm_fcn2_forward(LmFcn2* f, const uint8_t* d_rgb, int h, int w, float* d_out, float* d_text, float* d_rec, void* stream)
