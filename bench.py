@@ -54,8 +54,9 @@ def parse():
     p.add_argument("--no-labels", action="store_true", help="do not materialise the int32 label image")
     p.add_argument("--depth", type=int, default=2, help="N = 1: streams in flight (step 03 of one step under steps 01-02 of the next); 1 = none")
     p.add_argument("--seed", type=int, default=20213)
-    p.add_argument("--fcn-precision", default=os.environ.get("LM_FCN_PRECISION", "f16x3"), choices=["f16", "f16x2", "f16x3", "fp32"],
-                   help="MFMA operand format of the FCN conv stack (fp32 accumulate in all)")
+    p.add_argument("--fcn-precision", default=os.environ.get("LM_FCN_PRECISION", "mixed"),
+                   choices=["mixed", "planar-f16x3", "planar-f16", "f16", "f16x2", "f16x3", "fp32"],
+                   help="MFMA operand format of the FCN conv stack (fp32 accumulate in all); mixed = per layer (lecturemath_amd/fcn.py)")
     p.add_argument("--fcn-frames", type=int, default=5, help="frames timed for the `fcn` object (0 = skip fcn and e2e_rgb)")
     p.add_argument("--e2e-frames", type=int, default=64, help="RGB frames of the `e2e_rgb` measurement (0 = skip)")
     p.add_argument("--no-fcn-oracle", action="store_true", help="skip the CPU oracle forward pass (max |logit diff|, FCN cpu baseline)")
@@ -121,9 +122,16 @@ def measure_fcn(a, lib, H, W, n_frames, with_oracle):
     if a.fcn_precision == "fp32":
         res.update({"peak_tflops": MFMA_F32_PEAK_TFLOPS, "frac_of_peak_algorithmic": round(tflops / MFMA_F32_PEAK_TFLOPS, 4)})
     else:
-        k = FCN_MFMA_PER_PRODUCT[a.fcn_precision]
-        res.update({"peak_tflops": MFMA_F16_PEAK_TFLOPS, "frac_of_peak_algorithmic": round(tflops / MFMA_F16_PEAK_TFLOPS, 4),
-                    "mfma_per_product": k, "executed_tflops": round(k * tflops, 2)})
+        res.update({"peak_tflops": MFMA_F16_PEAK_TFLOPS, "frac_of_peak_algorithmic": round(tflops / MFMA_F16_PEAK_TFLOPS, 4)})
+        if eng.planar:
+            # per layer: products per operand pair and the K walk chosen by lecturemath_amd/fcn2.py
+            res["engine"] = "planar (csrc/lm_fcn2.hip)"
+            res["layer_formats"] = {str(k): ("f16 hi+lo split, 3 MFMAs per product" if v["terms"] == 3 else "f16, 1 MFMA per product")
+                                    for k, v in sorted(eng.recipes.items())}
+            res["layer_formats_source"] = "profiles/r03_fcn_layer_precision.json"
+        else:
+            k = FCN_MFMA_PER_PRODUCT[a.fcn_precision]
+            res.update({"mfma_per_product": k, "executed_tflops": round(k * tflops, 2)})
     if with_oracle:
         from oracle import fcn as ofcn          # the checker / CPU baseline leg only
         torch.set_num_threads(os.cpu_count())

@@ -155,6 +155,30 @@ def test_fcn_golden_tiny(emu_lib, precision):
     assert lm_checks.check_fcn_golden(emu_lib, "k7_70x94", precision=precision) < 1e-4
 
 
+PLANAR_TINY_WIDTHS = (16, 32, 16, 16, 16, 32, 16, 16, 16, 16, 16, 16, 16, 48, 16, 32, 32, 16)       # channel blocks of 1, 2 and 3 tiles
+
+
+@pytest.mark.parametrize("precision,tol", [("mixed", 1e-4), ("planar-f16x3", 1e-5)])
+def test_fcn_planar_tiny_vs_oracle(emu_lib, precision, tol):
+    """The planar FCN engine (csrc/lm_fcn2.hip: gather-GEMM on 16x16x32 MFMA tiles, planar f16 activations, LDS-DMA staging, pair
+    planes) on the CPU emulator against the torch oracle: an odd-sized frame (every output_size border, floor pooling), then a
+    smaller frame through the SAME engine (halos / tile overhang re-zeroed)."""
+    import torch
+    from lecturemath_amd import fcn, synth
+    from oracle import fcn as ofcn
+    sd = ofcn.random_state_dict(PLANAR_TINY_WIDTHS, pixel_kernel=7, seed=1)
+    eng = fcn.FcnEngine(PLANAR_TINY_WIDTHS, 7, 3, 45, 61, emu_lib, precision=precision)
+    assert eng.planar
+    eng.load_state_dict(sd)
+    for h, w in ((45, 61), (33, 40)):
+        rgb, _ = synth.whiteboard_rgb(h, w, n_glyphs=20, seed=4)
+        out, text, rec = (np.asarray(x) for x in eng.forward(rgb))
+        with torch.no_grad():
+            o, t, r = ofcn.forward(sd, ofcn.prepare_image(rgb))
+        assert np.abs(out - o[0, 0].numpy()).max() <= tol and np.abs(text - t[0, 0].numpy()).max() <= tol and np.abs(rec - r[0].numpy()).max() <= tol, (h, w)
+    eng.close()
+
+
 def test_emulated_library_under_asan_ubsan(oracle_built, tmp_path):
     """The product's HIP sources built for the CPU with -fsanitize=address,undefined (tests/hipemu `make asan`) and run in a
     child interpreter with the ASan runtime preloaded: the FCN forward pass (f16x3; every dynamic-LDS kernel of lm_fcn.hip, on
@@ -177,6 +201,13 @@ def test_emulated_library_under_asan_ubsan(oracle_built, tmp_path):
         o, t, r = ofcn.forward(sd, ofcn.prepare_image(rgb))
     fx = str(tmp_path / "fcn_case.npz")
     np.savez(fx, rgb=rgb, out=o[0, 0].numpy(), text=t[0, 0].numpy(), rec=r[0].numpy(), **{"sd." + k: v.numpy() for k, v in sd.items()})
+    # the planar engine (lm_fcn2.hip) on a network it accepts (widths in multiples of 16)
+    pwidths = (16,) * 13 + (48, 16, 32, 32, 16)
+    psd = ofcn.random_state_dict(pwidths, pixel_kernel=7, seed=5)
+    with torch.no_grad():
+        po, pt, pr = ofcn.forward(psd, ofcn.prepare_image(rgb))
+    pfx = str(tmp_path / "fcn_planar_case.npz")
+    np.savez(pfx, out=po[0, 0].numpy(), text=pt[0, 0].numpy(), rec=pr[0].numpy(), **{"sd." + k: v.numpy() for k, v in psd.items()})
     child = (
         "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "import numpy as np\n"
@@ -187,10 +218,16 @@ def test_emulated_library_under_asan_ubsan(oracle_built, tmp_path):
         "eng.load_state_dict({k[3:]: g[k] for k in g.files if k.startswith('sd.')})\n"
         "out, text, rec = eng.forward(g['rgb'])\n"
         "assert np.abs(out - g['out']).max() < 1e-4 and np.abs(text - g['text']).max() < 1e-4 and np.abs(rec - g['rec']).max() < 1e-4\n"
+        "p = np.load(%r)\n"
+        "eng2 = fcn.FcnEngine(%r, 7, 3, 35, 53, lib, precision='mixed')\n"
+        "assert eng2.planar\n"
+        "eng2.load_state_dict({k[3:]: p[k] for k in p.files if k.startswith('sd.')})\n"
+        "out, text, rec = eng2.forward(g['rgb'])\n"
+        "assert np.abs(out - p['out']).max() < 1e-4 and np.abs(text - p['text']).max() < 1e-4 and np.abs(rec - p['rec']).max() < 1e-4\n"
         "lm_checks.check_stream_large_components(lib, n_frames=4)\n"
         "lm_checks.check_grouping_oracle(lib, lm_checks.dot_grid_stream(n_frames=4, h=40, w=520))\n"
         "print('sanitized run ok')\n" % (os.path.dirname(os.path.dirname(d)), os.path.dirname(d), os.path.join(d, "liblecturemath_emu_asan.so"), fx,
-                                            widths))
+                                            widths, pfx, pwidths))
     env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:detect_stack_use_after_return=0",
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=1500)
