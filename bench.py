@@ -534,14 +534,33 @@ def main():
 
     launch_ms = tot_ms / max(tot_calls, 1)
     frames_per_launch = tot_fr / max(tot_calls, 1)
-    algo_bytes = ALGO_BYTES_PER_PX * W * H * frames_per_launch
+    # The timed launch is lm_label_batch_logits: fp32 logits in (4 B/px), int32 labels out (4 B/px) -- the threshold is fused into the
+    # row packing, so the byte frame SURVEY 8(d)'s 5 B/px figure counts (1 B in + 4 B out) is never written nor read.  Both accountings
+    # are reported: `frac` on the launch's own algorithmic bytes, `frac_survey_5Bpx` on SURVEY's figure over the same (longer) launch.
+    fused = bool(lib.lm_label_was_fused(slots[0]["fs"].labeler.ctx)) if slots else False
+    bpp = (4 if fused else 1) + (4 if labels is not None else 0)
+    algo_bytes = bpp * W * H * frames_per_launch
     achieved = algo_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "lm_label_batch[lm_k_band+lm_k_seam_union+lm_k_flatten_flag+lm_k_apply_labels+lm_k_write_labels]",
+    kern = ("lm_label_batch_logits[lm_k_pack_rows_logits+lm_k_band+lm_k_seam_union+lm_k_flatten_flag+lm_k_apply_labels+lm_k_write_labels]" if fused else
+            "lm_label_batch[lm_k_pack_rows+lm_k_band+lm_k_seam_union+lm_k_flatten_flag+lm_k_apply_labels+lm_k_write_labels]")
+    roofline = {"bound": "hbm", "kernel": kern,
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_px": {"in": 4 if fused else 1, "out": 4 if labels is not None else 0,
+                                             "note": ("fp32 logit read + int32 label written; threshold fused, no byte frame" if fused else
+                                                      "uint8 frame read + int32 label written (SURVEY 8(d))")},
+                "frac_survey_5Bpx": round(ALGO_BYTES_PER_PX * W * H * frames_per_launch / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if launch_ms > 0 else None,
                 "traffic": None, "traffic_note": "PMC passes cannot be collected inside this process; see profiles/ for the rocprofv3 --pmc runs of this command",
                 "launch_ms": round(launch_ms, 4), "launches": tot_calls, "frames_per_launch": round(frames_per_launch, 2),
                 "algorithmic_bytes_per_launch": int(algo_bytes), "label_image_written": labels is not None,
-                "timed": "HIP events around every lm_label_batch inside the timed region"}
+                "timed": "HIP events around every labelling launch sequence inside the timed region"}
+    tpath = os.path.join(ROOT, "profiles", "r03_label_traffic_pmc.json")
+    if os.path.exists(tpath):
+        tr = json.load(open(tpath))
+        if (tr.get("width"), tr.get("height"), tr.get("fused")) == (W, H, fused) and tr.get("frames_per_launch"):
+            # HBM bytes of one launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied
+            # there), scaled to this run's frames per launch
+            roofline["traffic"] = int(tr["hbm_bytes_per_launch"] * frames_per_launch / tr["frames_per_launch"])
+            roofline["traffic_note"] = "profiles/r03_label_traffic_pmc.json (separate --pmc passes of tools/label_microbench, %d frames per launch)" % tr["frames_per_launch"]
     if alone_ms:
         roofline["alone"] = {"launch_ms": round(alone_ms, 4), "achieved": round(algo_bytes / (alone_ms * 1e-3) / 1e9, 2),
                              "frac": round(algo_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -560,7 +579,24 @@ def main():
         cdt = time.perf_counter() - t0
         cpu = {"value": round(n / cdt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": "first %d frames of the same stream: threshold+invert, label, stats, crops, temporal matching "
-                         "(oracle/cc_oracle.c, single thread; host has %d cores)" % (n, os.cpu_count())}
+                         "(oracle/cc_oracle.c, single thread; host has %d cores)" % (n, os.cpu_count()),
+               "reference_in_build_container": {"value": 3.7, "unit": "frames/s", "cores": 1,
+                                                "note": "the reference itself (steps 02 + 03, first 1,000 frames of this stream, 8-vCPU build container): BASELINE.md section 4"}}
+        # the same work as `value` on a DENSE window of the stream (the board is full around frame 5000): steps 01-03 incl. reconstruction
+        d0 = min(5000, max(F - n, 0))
+        if F >= d0 + n and d0 > 0:
+            from oracle import grouping as ogr
+            lg = logits[d0:d0 + n].cpu().numpy()
+            t0 = time.perf_counter()
+            st = occ.Stability(W, H, 0.85, 0.85, 85)
+            for i in range(n):
+                st.add_frame(occ.threshold_invert(lg[i]))
+            t1 = time.perf_counter()
+            ogr.run_step03(st.result(), max_gap=85, min_times=3, t_window=5, min_recall=0.5, img_threshold=0.5, reconstruct=True)
+            t2 = time.perf_counter()
+            cpu["dense_window"] = {"value": round(n / (t2 - t0), 3), "unit": "frames/s", "cores": 1,
+                                   "sample": "frames %d..%d of the same stream as a stream of their own: steps 01-02 %.1f s (oracle/cc_oracle.c) + step 03 with "
+                                             "all frames reconstructed %.1f s (oracle/grouping.py, numpy)" % (d0, d0 + n, t1 - t0, t2 - t1)}
 
     out = {
         "metric": "frames/sec end-to-end binarize+CC+group @1080p", "value": round(F * a.steps / dt, 2), "unit": "frames/s",

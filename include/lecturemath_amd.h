@@ -69,6 +69,14 @@ int lm_threshold(const float* d_logits, uint8_t* d_out, int64_t n, int thr, int 
  * wanted.  Leaves the run structures of the batch in the workspace for the calls below. */
 int lm_label_batch(LmCtx* ctx, const uint8_t* d_binary, int n_frames, int32_t* d_labels, void* stream);
 
+/* lm_threshold + lm_label_batch in ONE pass over fp32 logits (FCN_lecturenet.py:452-467, FCN_lecturenet_binarizer.py:54,
+ * labeler.py:126): the frames are never materialised as bytes unless d_binary (may be NULL) asks for them.  Rows must be a
+ * multiple of 4 pixels and 16-byte aligned for the fused kernel; otherwise the two calls run (d_binary required then).
+ * lm_label_was_fused tells which of the two the last call on the context took (1 = fused). */
+int lm_label_batch_logits(LmCtx* ctx, const float* d_logits, int n_frames, int thr, int invert, uint8_t* d_binary, int32_t* d_labels,
+                          void* stream);
+int lm_label_was_fused(LmCtx* ctx);
+
 /* Number of labels of every frame of the last batch -> h_counts[n_frames] (synchronises the stream). */
 int lm_label_counts(LmCtx* ctx, int32_t* h_counts, void* stream);
 
@@ -121,8 +129,8 @@ int lm_stream_push_labelled(LmStream* s, int n_frames, void* stream);
  * pass the same stream twice for a single queue, do_match = 0 for the records only).  schedule 0: every batch's matching starts
  * as soon as its records are in; schedule 1: the labelling launches (bandwidth bound) are kept apart from the wide kernels of the
  * matching -- matching of batch k-1 starts when batch k has been labelled, batch k+1 is labelled when that matching has reached
- * its single-workgroup replay.  d_binary is scratch for `batch` frames,
- * d_labels receives the label image of every batch in turn (or NULL).  Asynchronous. */
+ * its single-workgroup replay.  d_binary (may be NULL: the fused logits -> runs kernel needs no byte frames) is scratch for
+ * `batch` frames, d_labels receives the label image of every batch in turn (or NULL).  Asynchronous. */
 int lm_stream_run_logits(LmStream* s, const float* d_logits, int n_frames, int batch, uint8_t* d_binary, int32_t* d_labels, int thr,
                          int do_match, int schedule, void* stream_wide, void* stream_match);
 

@@ -73,6 +73,8 @@ SIGNATURES = {
     "lm_group_destroy": (None, [_vp]),
     "lm_group_render": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     "lm_group_array": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
+    "lm_label_batch_logits": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
+    "lm_label_was_fused": (ctypes.c_int, [_vp]),
     "lm_fcn_create": (_vp, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "lm_fcn_destroy": (None, [_vp]),
     "lm_fcn_set_layer": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _i64, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

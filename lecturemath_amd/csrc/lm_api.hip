@@ -271,8 +271,16 @@ extern "C" int lm_threshold_invert(const float* d_logits, uint8_t* d_out, int64_
 // ------------------------------------------------------------------------------------------------
 // The launch sequence of frames [f0, f0 + n) of a batch on stream `st`.  All the per-frame tables of the context are indexed by
 // the frame's position in the batch and hold frame-relative ids, so a part of a batch is the same launches on shifted pointers.
-static int lm_label_launch(LmCtx* c, const uint8_t* d_binary, int f0, int n, int32_t* d_labels, hipStream_t st)
+// The frames come as {0, non-zero} bytes (d_binary) or -- logits != null -- as fp32 logits thresholded on the fly ((x >= edge ? 255 : 0) ^
+// flip; d_binary, when given as well, receives that frame).
+struct LmLabelSrc {
+    const uint8_t* d_binary;
+    const float* logits; float edge; unsigned flip; uint8_t* d_binary_out;
+};
+
+static int lm_label_launch(LmCtx* c, const LmLabelSrc& src, int f0, int n, int32_t* d_labels, hipStream_t st)
 {
+    const uint8_t* d_binary = src.d_binary;
     const LmGeom g = c->g;
     const int nbands = c->nbands, slot = c->slot;
     const int capw = g.cap / 64;
@@ -280,8 +288,12 @@ static int lm_label_launch(LmCtx* c, const uint8_t* d_binary, int f0, int n, int
     const unsigned long long magic_ww = ((1ull << 40) / (unsigned)g.WW) + 1;
     const long long R = (long long)n * g.H;
     const size_t px = (size_t)g.W * g.H, r0 = (size_t)f0 * g.H, w0 = r0 * g.WW, b0 = (size_t)f0 * nbands, c0 = (size_t)f0 * g.cap, cw0 = (size_t)f0 * capw;
-    hipLaunchKernelGGL(lm_k_pack_rows, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, d_binary + f0 * px, c->bits + w0, c->starts + w0, c->prefix + w0,
-                       c->rowcnt + r0, g.W, g.WW, R);
+    if (src.logits)
+        hipLaunchKernelGGL(lm_k_pack_rows_logits, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, src.logits + f0 * px, src.edge, src.flip,
+                           src.d_binary_out ? src.d_binary_out + f0 * px : nullptr, c->bits + w0, c->starts + w0, c->prefix + w0, c->rowcnt + r0, g.W, g.WW, R);
+    else
+        hipLaunchKernelGGL(lm_k_pack_rows, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, d_binary + f0 * px, c->bits + w0, c->starts + w0, c->prefix + w0,
+                           c->rowcnt + r0, g.W, g.WW, R);
     static const int band_threads = [] { const char* e = getenv("LM_BAND_THREADS"); const int v = e ? atoi(e) : 512; return (v == 128 || v == 256 || v == 512) ? v : 512; }();
     hipLaunchKernelGGL(lm_k_band, dim3(nbands, n), dim3(band_threads), band_smem, st, c->bits + w0, c->starts + w0, c->prefix + w0, c->rowcnt + r0,
                        c->rowoff + r0, c->band_runs + b0, c->parent + c0, c->band_fallback + b0, g.H, g.WW, slot, g.cap, lm_debug_band_phases(), magic_ww,
@@ -310,9 +322,9 @@ static int lm_label_launch(LmCtx* c, const uint8_t* d_binary, int f0, int n, int
 // latency-bound kernels on ~1/8 of the bytes, its two ends (row packing, the label image) stream at HBM rate -- with the parts on
 // two queues the ends of one part run under the middle of the other.  The second queue belongs to the context and is joined back
 // into the caller's stream before the call returns, so the caller's ordering is that of a single launch sequence.
-extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, int32_t* d_labels, void* stream)
+static int lm_label_batch_src(LmCtx* c, const LmLabelSrc& src, int n_frames, int32_t* d_labels, void* stream)
 {
-    if (!c || !d_binary || n_frames <= 0 || n_frames > c->max_batch) {
+    if (!c || (!src.d_binary && !src.logits) || n_frames <= 0 || n_frames > c->max_batch) {
         lm_set_error("lm_label_batch: bad arguments (n_frames=%d, max_batch=%d)", n_frames, c ? c->max_batch : -1);
         return LM_ERR_ARG;
     }
@@ -337,7 +349,7 @@ extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, i
         LM_HIP(hipEventCreateWithFlags((hipEvent_t*)&c->ev_join, hipEventDisableTiming));
     }
     if (parts <= 1) {
-        const int rc = lm_label_launch(c, d_binary, 0, n_frames, d_labels, st);
+        const int rc = lm_label_launch(c, src, 0, n_frames, d_labels, st);
         if (rc) return rc;
     } else {
         hipStream_t aux = (hipStream_t)c->aux_stream;
@@ -348,7 +360,7 @@ extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, i
         int rc = LM_OK;
         for (int k = 0, f0 = 0; k < parts && rc == LM_OK; k++) {
             const int n = n_frames / parts + (k < n_frames % parts ? 1 : 0);
-            rc = lm_label_launch(c, d_binary, f0, n, d_labels, (k & 1) ? aux : st);
+            rc = lm_label_launch(c, src, f0, n, d_labels, (k & 1) ? aux : st);
             f0 += n;
         }
         const hipError_t e1 = hipEventRecord((hipEvent_t)c->ev_join, aux);
@@ -361,8 +373,46 @@ extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, i
     }
     if (lm_profile_mark(c, st, false, n_frames)) return LM_ERR_HIP;
     c->last_batch = n_frames;
+    c->last_fused = src.logits ? 1 : 0;
     return LM_OK;
 }
+
+extern "C" int lm_label_batch(LmCtx* c, const uint8_t* d_binary, int n_frames, int32_t* d_labels, void* stream)
+{
+    LmLabelSrc src = {d_binary, nullptr, 0.0f, 0u, nullptr};
+    return lm_label_batch_src(c, src, n_frames, d_labels, stream);
+}
+
+// Labelling straight from fp32 logits: binary = ((uint8)(sigmoid(x) * 255) >= thr ? 255 : 0), inverted when `invert` (the step-01 worker's
+// 255 - binary), 4-connected labels of its non-zero pixels -- lm_threshold + lm_label_batch in one pass over the logits (4 B/px read
+// instead of 4 B/px read + 1 B/px written + 1 B/px read).  d_binary may be null; when given it receives the {0, 255} frames.
+// Falls back to the two calls (d_binary required then) when the row width is not a multiple of 4 pixels, the buffers are not 16-byte
+// aligned or the threshold has no comparison form (lm_threshold_edge).
+extern "C" int lm_label_batch_logits(LmCtx* c, const float* d_logits, int n_frames, int thr, int invert, uint8_t* d_binary, int32_t* d_labels, void* stream)
+{
+    if (!c || !d_logits || n_frames <= 0 || n_frames > c->max_batch) {
+        lm_set_error("lm_label_batch_logits: bad arguments (n_frames=%d, max_batch=%d)", n_frames, c ? c->max_batch : -1);
+        return LM_ERR_ARG;
+    }
+    const LmGeom g = c->g;
+    float edge = 0.0f;
+    int state = 0;
+    const bool shape_ok = (g.W & 3) == 0 && ((((uintptr_t)d_logits) & 15) == 0) && (!d_binary || ((((uintptr_t)d_binary) & 3) == 0));
+    if (shape_ok && thr >= 1 && thr <= 255 && !getenv("LM_THRESHOLD_FORMULA") && !getenv("LM_LABEL_UNFUSED")) {
+        const int rc = lm_threshold_edge(thr, (hipStream_t)stream, &edge, &state);
+        if (rc) return rc;
+    }
+    if (state == 1) {
+        LmLabelSrc src = {nullptr, d_logits, edge, invert ? 0xffu : 0u, d_binary};
+        return lm_label_batch_src(c, src, n_frames, d_labels, stream);
+    }
+    if (!d_binary) { lm_set_error("lm_label_batch_logits: this frame shape / threshold needs the two-pass path, which needs d_binary"); return LM_ERR_ARG; }
+    const int rc = lm_threshold(d_logits, d_binary, (int64_t)n_frames * g.W * g.H, thr, invert, stream);
+    if (rc) return rc;
+    return lm_label_batch(c, d_binary, n_frames, d_labels, stream);
+}
+
+extern "C" int lm_label_was_fused(LmCtx* c) { return c ? c->last_fused : 0; }
 
 extern "C" int lm_label_counts(LmCtx* c, int32_t* h_counts, void* stream)
 {
@@ -792,7 +842,7 @@ static int lm_run_events(LmStream* s, int want)
 extern "C" int lm_stream_run_logits(LmStream* s, const float* d_logits, int n_frames, int batch, uint8_t* d_binary, int32_t* d_labels, int thr,
                                     int do_match, int schedule, void* stream_wide, void* stream_match)
 {
-    if (!s || !d_logits || !d_binary || n_frames < 0 || batch <= 0 || batch > s->ctx->max_batch || schedule < 0 || schedule > 1) {
+    if (!s || !d_logits || n_frames < 0 || batch <= 0 || batch > s->ctx->max_batch || schedule < 0 || schedule > 1) {
         lm_set_error("lm_stream_run_logits: bad arguments (batch %d, context batch %d, schedule %d)", batch, s ? s->ctx->max_batch : 0, schedule);
         return LM_ERR_ARG;
     }
@@ -811,10 +861,8 @@ extern "C" int lm_stream_run_logits(LmStream* s, const float* d_logits, int n_fr
     int prev_n = 0;
     for (int k = 0, f0 = 0; f0 < n_frames; f0 += batch, k++) {
         const int n = (n_frames - f0 < batch) ? n_frames - f0 : batch;
-        int rc = lm_threshold(d_logits + (size_t)f0 * px, d_binary, (int64_t)n * (int64_t)px, thr, 1, stream_wide);
-        if (rc) return rc;
         if (gated && k >= 2) LM_HIP(hipStreamWaitEvent(sw, ev[3 * (k - 2) + 2], 0));       // the wide kernels of matching k-2 are through
-        rc = lm_label_batch(s->ctx, d_binary, n, d_labels, stream_wide);
+        int rc = lm_label_batch_logits(s->ctx, d_logits + (size_t)f0 * px, n, thr, 1, d_binary, d_labels, stream_wide);
         if (rc) return rc;
         if (gated) LM_HIP(hipEventRecord(ev[3 * k], sw));
         rc = lm_stream_push_labelled(s, n, stream_wide);

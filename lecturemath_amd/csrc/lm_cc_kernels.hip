@@ -303,6 +303,85 @@ __global__ void __launch_bounds__(256) lm_k_pack_rows(const uint8_t* __restrict_
     if (lane == 0) rowcnt[row] = running;
 }
 
+// K1' = K0' + K1 in one pass: fp32 logits -> bit mask, run starts, prefixes, runs per row; the {0, 255} frame is written only on
+// request.  (Separately the threshold kernel wrote 1 B/px that lm_k_pack_rows read straight back: 105 + 29 us per 64 frames at 1080p
+// for what is one 4 B/px read.)  A pixel is foreground when ((x >= edge) ? 255 : 0) ^ flip is non-zero (lm_k_threshold_cmp's output).
+// One wave per row; per block of 1024 pixels a lane loads the float4s j * 64 + lane, j = 0..3 (every load instruction of the wave is
+// 1 KB contiguous), the comparisons come back as wave ballots -- bit l of ballot (j, c) = component c of lane l's j-th float4 =
+// pixel 4 * (64 j + l) + c of the block -- and lane w < 16 interleaves the four ballots' 16-bit pieces into word w of the block.
+// W must be a multiple of 4 (16-byte rows).
+LM_DEV unsigned long long lm_spread16(unsigned long long x)       // bit i -> bit 4 i
+{
+    x = (x | (x << 24)) & 0x000000ff000000ffull;
+    x = (x | (x << 12)) & 0x000f000f000f000full;
+    x = (x | (x << 6)) & 0x0303030303030303ull;
+    x = (x | (x << 3)) & 0x1111111111111111ull;
+    return x;
+}
+
+__global__ void __launch_bounds__(256) lm_k_pack_rows_logits(const float* __restrict__ logits, float edge, unsigned flip, uint8_t* __restrict__ img,
+                                                             uint64_t* __restrict__ bits, uint64_t* __restrict__ starts, uint16_t* __restrict__ prefix,
+                                                             uint32_t* __restrict__ rowcnt, int W, int WW, long long R)
+{
+    const int lane = lm_lane();
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float4* src = (const float4*)(logits + row * W);
+    unsigned* dst = img ? (unsigned*)(img + row * W) : nullptr;
+    const int n4 = W >> 2;
+    const unsigned on = 255u ^ flip, off = flip;
+    const bool fg_hi = on != 0u, fg_lo = off != 0u;         // is a pixel at / above the edge foreground?  one below it?
+    unsigned running = 0;
+    unsigned long long carry = 0;
+    for (int w0 = 0; w0 < WW; w0 += 64) {                   // 64 words = 4096 px = 4 blocks per trip
+        unsigned long long bw = 0;
+#pragma unroll
+        for (int blk = 0; blk < 4; blk++) {
+            const int q0 = w0 * 16 + blk * 256;             // first float4 of the block
+            if (q0 >= n4) break;
+            float4 v[4];
+            bool ok[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int q = q0 + j * 64 + lane;
+                ok[j] = q < n4;
+                v[j] = ok[j] ? lm_ld_stream(src + q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            unsigned long long word = 0;
+            const int wj = lane >> 2, sh = 16 * (lane & 3);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool hx = v[j].x >= edge, hy = v[j].y >= edge, hz = v[j].z >= edge, hw = v[j].w >= edge;
+                if (dst && ok[j])
+                    __builtin_nontemporal_store((hx ? on : off) | ((hy ? on : off) << 8) | ((hz ? on : off) << 16) | ((hw ? on : off) << 24), dst + q0 + j * 64 + lane);
+                const unsigned long long b0 = __ballot(ok[j] && (hx ? fg_hi : fg_lo)), b1 = __ballot(ok[j] && (hy ? fg_hi : fg_lo)),
+                                         b2 = __ballot(ok[j] && (hz ? fg_hi : fg_lo)), b3 = __ballot(ok[j] && (hw ? fg_hi : fg_lo));
+                if (wj == j)
+                    word = lm_spread16((b0 >> sh) & 0xffffull) | (lm_spread16((b1 >> sh) & 0xffffull) << 1) | (lm_spread16((b2 >> sh) & 0xffffull) << 2) |
+                           (lm_spread16((b3 >> sh) & 0xffffull) << 3);
+            }
+            // lanes 0..15 hold the block's 16 words: word w0 + 16 blk + l belongs in lane 16 blk + l
+            const unsigned long long moved = __shfl(word, lane & 15);
+            if ((lane >> 4) == blk) bw = moved;
+        }
+        const int w = w0 + lane;
+        if (w >= WW) bw = 0;
+        unsigned long long prevtop = __shfl_up(bw >> 63, 1);
+        if (lane == 0) prevtop = carry;
+        const unsigned long long st = bw & ~((bw << 1) | prevtop);
+        const unsigned c = (unsigned)__popcll(st);
+        const unsigned incl = lm_wave_incl_scan(c);
+        if (w < WW) {
+            bits[row * WW + w] = bw;
+            starts[row * WW + w] = st;
+            prefix[row * WW + w] = (uint16_t)(running + incl - c);
+        }
+        carry = __shfl(bw >> 63, 63);
+        running += __shfl(incl, 63);
+    }
+    if (lane == 0) rowcnt[row] = running;
+}
+
 // K4a: one workgroup per band: the band's bit rows / run starts / prefixes (written by lm_k_pack_rows, L2-resident) go to LDS,
 // band-local run offsets, and the band's union-find forest in LDS.  Run ids are band-structured:
 //     gid = band * SLOT + (runs of the band before the run)          SLOT = worst-case runs of a band

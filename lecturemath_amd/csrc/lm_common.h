@@ -82,6 +82,7 @@ struct LmCtx {
     int32_t* frame_kept;     // [B]
     uint32_t* frame_cropwords;  // [B]
     int last_batch;          // frames in the most recent lm_label_batch
+    int last_fused;          // 1: that batch came through lm_k_pack_rows_logits (threshold fused into the row packing)
     // host-pointer convenience path (drop-in entry points): staging buffers
     uint8_t* stage_u8;
     int32_t* stage_i32;

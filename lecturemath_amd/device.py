@@ -94,6 +94,19 @@ class FrameLabeler:
         self.lib.check(self.lib.lm_label_counts(self.ctx, counts.ctypes.data, self.be.stream()))
         return labels, counts
 
+    def label_logits(self, logits, thr=128, invert=True, want_binary=False, want_labels=True):
+        """fp32 logits [B,H,W] -> (labels or None, counts, {0,255} frames or None): threshold (+ the worker's inversion) and labelling in
+        one pass over the logits (lm_label_batch_logits)."""
+        b = logits.shape[0]
+        assert tuple(logits.shape[1:]) == (self.height, self.width) and b <= self.max_batch
+        labels = self.be.empty((b, self.height, self.width), np.int32) if want_labels else None
+        binary = self.be.empty((b, self.height, self.width), np.uint8) if want_binary else None
+        self.lib.check(self.lib.lm_label_batch_logits(self.ctx, _lib.ptr(logits), b, thr, 1 if invert else 0, _lib.ptr(binary), _lib.ptr(labels),
+                                                      self.be.stream()))
+        counts = np.zeros(b, np.int32)
+        self.lib.check(self.lib.lm_label_counts(self.ctx, counts.ctypes.data, self.be.stream()))
+        return labels, counts, binary
+
     def stats(self, counts):
         """CC_AgeBoundaries arrays of every frame of the last batch: list of int32 [5, n] (mins_y, maxs_y, mins_x, maxs_x, counts)."""
         self.lib.check(self.lib.lm_cc_stats_batch(self.ctx, self.be.stream()))

@@ -102,6 +102,15 @@ def check_stream_run_logits(lib, n_frames=23, h=96, w=160, batch=5, schedule=0, 
         if second_stream and be.device:
             side = be.torch.cuda.Stream()
             st2 = side.cuda_stream
+        # the stream object is first filled from a DIFFERENT input and reset: records left behind by an earlier stream must not be read
+        # by the matching kernels of this one (they overlap the next batch's emission on the other queue)
+        other = synth.logits_from_binary(np.stack(list(synth.binary_stream(n_frames, h, w, seed=99, glyphs_per_add=6, erase_every=5, max_ext=16))), seed=5)
+        d_other = be.from_host(other)
+        lib.check(lib.lm_stream_run_logits(fs.handle, _lib.ptr(d_other), n_frames, batch, None, _lib.ptr(labels), 128, 1, schedule, st, st2))
+        if st2 is not st:
+            side.synchronize()
+        fs.result()
+        fs.reset()
         lib.check(lib.lm_stream_run_logits(fs.handle, _lib.ptr(d_logits), n_frames, batch, _lib.ptr(scratch), _lib.ptr(labels), 128, 1, schedule, st, st2))
         if st2 is not st:
             side.synchronize()
@@ -224,6 +233,39 @@ def check_stream_match_paths(lib, n_frames=80, max_gap=2, seed=11):
     for r in (r2, r3, r4):
         state_equal_oracle(r, r1)
     assert len(r1["unique_recs"]) > 30 and len(r1["active"]) < len(r1["unique_recs"])
+
+
+def check_label_logits_fused(lib, shapes=((3, 37, 68), (2, 9, 1028), (1, 5, 4100))):
+    """lm_label_batch_logits (threshold fused into the row packing: ballots of 1024-pixel blocks) == lm_threshold + lm_label_batch:
+    labels, counts, statistics and the {0, 255} frames, for row widths that end inside a block / a 64-pixel word / beyond one 4096-pixel
+    trip, both polarities, logits packed ulp by ulp around the threshold edge, +-inf and NaN; and the unfused fallback (width % 4 != 0)."""
+    rng = np.random.default_rng(31)
+    for (b, h, w) in tuple(shapes) + ((2, 21, 70),):
+        lab = device.FrameLabeler(w, h, b, lib)
+        try:
+            for thr, invert in ((128, True), (128, False), (77, True)):
+                centre = np.float32(np.log((thr / 255.0) / (1.0 - thr / 255.0)))
+                x = rng.normal(0, 2.5, (b, h, w)).astype(np.float32)
+                edge = (np.full(b * h * w, centre, np.float32).view(np.int32) + rng.integers(-40, 41, b * h * w).astype(np.int32)).view(np.float32)
+                pick = rng.random((b, h, w)) < 0.3
+                x[pick] = edge.reshape(b, h, w)[pick]
+                x.reshape(-1)[:6] = np.array([np.inf, -np.inf, np.nan, 0.0, -0.0, 104.0], np.float32)
+                dev = lab.be.from_host(x)
+                labels, counts, binary = lab.label_logits(dev, thr, invert, want_binary=True)
+                assert lib.lm_label_was_fused(lab.ctx) == (1 if w % 4 == 0 else 0)
+                got_l, got_b, got_st = lab.be.to_host(labels), lab.be.to_host(binary), lab.stats(counts)
+                ref_b = lab.be.empty((b, h, w), np.uint8)
+                lib.check(lib.lm_threshold(_lib.ptr(dev), _lib.ptr(ref_b), b * h * w, thr, 1 if invert else 0, lab.be.stream()))
+                ref_l, ref_counts = lab.label(ref_b)
+                ref_st = lab.stats(ref_counts)
+                assert (got_b == lab.be.to_host(ref_b)).all() and (got_l == lab.be.to_host(ref_l)).all() and (counts == ref_counts).all(), (b, h, w, thr, invert)
+                assert all((a == r).all() for a, r in zip(got_st, ref_st))
+                assert 0 < int((got_b == 255).sum()) < got_b.size
+                # without the byte frames
+                labels2, counts2, _ = lab.label_logits(dev, thr, invert, want_binary=False) if w % 4 == 0 else (labels, counts, None)
+                assert (lab.be.to_host(labels2) == got_l).all() and (counts2 == counts).all()
+        finally:
+            lab.close()
 
 
 def check_label_vs_oracle(lib, img):

@@ -191,6 +191,7 @@ def test_grouping_crowded_tiles_vs_oracle(hip_lib, oracle_built):
 def test_threshold_comparison_form(hip_lib):
     """x >= x* (the kernel that runs) == the sigmoid formula kernel, ulp by ulp around the edge of eight thresholds."""
     lm_checks.check_threshold_paths(hip_lib)
+    lm_checks.check_label_logits_fused(hip_lib, shapes=((3, 37, 68), (2, 9, 1028), (1, 5, 4100), (5, 1080, 1920), (2, 2160, 3840)))
 
 
 def test_stream_threshold_edges(hip_lib, oracle_built):

@@ -27,6 +27,7 @@ def test_threshold_golden(emu_lib):
 
 def test_threshold_comparison_form(emu_lib):
     lm_checks.check_threshold_paths(emu_lib)
+    lm_checks.check_label_logits_fused(emu_lib)
 
 
 def test_stream_vs_oracle_small(emu_lib, oracle_built):

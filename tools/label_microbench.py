@@ -33,6 +33,22 @@ for want in (labels, None):
         W, H, first, first + B, os.path.basename(os.environ.get("LM_LIB_PATH") or "default"), want is not None, B, ms * 1e3, ms * 1e3 / B,
         5 * W * H * B / (ms * 1e-3) / 1e9, 5 * W * H * B / (ms * 1e-3) / 8e12))
 
+# the fused launch: fp32 logits -> labels (lm_label_batch_logits), 4 B/px in + 4 B/px out
+logits = torch.from_numpy(synth.logits_from_binary(frames, seed=1)).cuda()
+for _ in range(3):
+    lib.check(lib.lm_label_batch_logits(lab.ctx, logits.data_ptr(), B, 128, 1, None, labels.data_ptr(), st))
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    lib.check(lib.lm_label_batch_logits(lab.ctx, logits.data_ptr(), B, 128, 1, None, labels.data_ptr(), st))
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 20
+print("%dx%d frames %d..%d FUSED logits -> labels (fused=%d) B=%d: %.1f us/launch, %.0f GB/s on 8 B/px = %.3f of 8 TB/s (%.3f on SURVEY's 5 B/px)" % (
+    W, H, first, first + B, lib.lm_label_was_fused(lab.ctx), B, ms * 1e3, 8 * W * H * B / (ms * 1e-3) / 1e9, 8 * W * H * B / (ms * 1e-3) / 8e12,
+    5 * W * H * B / (ms * 1e-3) / 8e12))
+assert (labels.cpu().numpy() == np.stack([__import__("scipy.ndimage").ndimage.label(f)[0] for f in frames[:2]] + [labels[i].cpu().numpy() for i in range(2, B)])).all()
+
 # the same launches timed the way bench.py times them inside its timed region: one HIP event pair PER launch (lm_ctx_set_profiling)
 import ctypes
 lib.check(lib.lm_ctx_set_profiling(lab.ctx, 1))
