@@ -155,7 +155,6 @@ def measure_e2e_rgb(a, lib, eng, H, W, n_frames):
     from lecturemath_amd import _lib, device, synth
     rgb = torch.from_numpy(np.stack(list(synth.whiteboard_stream(n_frames, H, W)))).cuda()
     logits = torch.empty((n_frames, H, W), dtype=torch.float32, device="cuda")
-    binary = torch.empty((n_frames, H, W), dtype=torch.uint8, device="cuda")
     clean = torch.empty((n_frames, H, W), dtype=torch.uint8, device="cuda")
     labels = torch.empty((min(a.batch, n_frames), H, W), dtype=torch.int32, device="cuda")
     fs = device.FrameStream(W, H, n_frames, 0.85, 0.85, 85, 20, max_batch=min(a.batch, n_frames), max_ccs=n_frames * 131072,
@@ -165,11 +164,8 @@ def measure_e2e_rgb(a, lib, eng, H, W, n_frames):
     def once():
         fs.reset()
         for i in range(n_frames):
-            lib.check(lib.lm_fcn_forward(eng.handle, rgb[i].data_ptr(), H, W, logits[i].data_ptr(), None, None, st))
-        lib.check(lib.lm_threshold_invert(logits.data_ptr(), binary.data_ptr(), n_frames * H * W, 128, st))
-        for f0 in range(0, n_frames, a.batch):
-            n = min(a.batch, n_frames - f0)
-            lib.check(lib.lm_stream_push(fs.handle, binary[f0:f0 + n].data_ptr(), n, labels.data_ptr(), st))
+            eng.forward_raw(rgb[i].data_ptr(), H, W, logits[i].data_ptr(), None, None, st)
+        lib.check(lib.lm_stream_run_logits(fs.handle, logits.data_ptr(), n_frames, min(a.batch, n_frames), None, labels.data_ptr(), 128, 1, 0, st, st))
         gr = device.Grouping(fs, max_gap=85, min_times=3, t_window=5, min_recall=0.5, img_threshold=0.5, reconstruct=True)
         gr.render(0, n_frames, clean)
         torch.cuda.synchronize()

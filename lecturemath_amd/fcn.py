@@ -342,6 +342,14 @@ class FcnEngine:
             raise _lib.LecturemathError(_lib.LM_ERR_STATE, "the planar engine's formats are fixed by load_state_dict (precision=...)")
         self.lib.check(self.lib.lm_fcn_set_layer_terms(self.handle, int(layer), terms))
 
+    def forward_raw(self, rgb_ptr, h, w, out_ptr, text_ptr=None, rec_ptr=None, stream=None):
+        """one forward pass on raw device addresses (uint8 [h,w,3] in; fp32 logit [h,w], text logit [h,w], rec [3,h,w] out, each optional)
+        on `stream` (a HIP stream handle; default: the backend's current stream)"""
+        fwd, hd = (self.lib.lm_fcn2_forward, self.handle2) if self.planar else (self.lib.lm_fcn_forward, self.handle)
+        if not hd:
+            raise _lib.LecturemathError(_lib.LM_ERR_STATE, "FcnEngine.forward before load_state_dict")
+        self.lib.check(fwd(hd, rgb_ptr, h, w, out_ptr, text_ptr, rec_ptr, self.be.stream() if stream is None else stream))
+
     def forward(self, rgb):
         """rgb: device (or host numpy) uint8 [H,W,3] -> device fp32 (logit [H,W], text logit [H,W], rec [3,H,W])."""
         if isinstance(rgb, np.ndarray):
@@ -350,8 +358,5 @@ class FcnEngine:
         out = self.be.empty((h, w), np.float32)
         text = self.be.empty((h, w), np.float32)
         rec = self.be.empty((3, h, w), np.float32)
-        fwd, hd = (self.lib.lm_fcn2_forward, self.handle2) if self.planar else (self.lib.lm_fcn_forward, self.handle)
-        if not hd:
-            raise _lib.LecturemathError(_lib.LM_ERR_STATE, "FcnEngine.forward before load_state_dict")
-        self.lib.check(fwd(hd, _lib.ptr(rgb), h, w, _lib.ptr(out), _lib.ptr(text), _lib.ptr(rec), self.be.stream()))
+        self.forward_raw(_lib.ptr(rgb), h, w, _lib.ptr(out), _lib.ptr(text), _lib.ptr(rec))
         return out, text, rec

@@ -19,7 +19,7 @@ def test_threshold_golden(emu_lib):
     g = np.load(os.path.join(lm_checks.GOLD, "g6_threshold.npz"))
     lab = device.FrameLabeler(96, 64, 1, emu_lib)
     out = lab.threshold_invert(g["logits"])
-    far = np.abs(g["logits"] - 0.01569) > 1e-4
+    far = np.abs(g["logits"] - 0.0078433) > 1e-4
     assert (out[far] == g["expected"][far]).all()
     assert int((out != g["expected"]).sum()) <= 2
     lab.close()
