@@ -4,5 +4,5 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 The product package (lecturemath_amd) never does; it fails loudly when its HIP library is missing.
 
 Parity status: pinned against outputs of the reference itself run in the build container
-(tests/golden/make_golden.py; tests/test_oracle_vs_reference.py).
+(tests/golden/make_golden.py; tests/test_oracle_golden.py, tests/test_reference_binding.py).
 """

@@ -5,7 +5,7 @@ finished CCStabilityEstimator.  Paths relative to /root/reference/ACCESS2021_rel
 names the method it follows in AccessMath/preprocessing/content/cc_stability_estimator.py.
 
 Parity status: pinned against the reference run in the build container
-(tests/golden/make_golden.py G4 fixtures; tests/test_oracle_vs_reference.py).
+(tests/golden/make_golden.py G4 fixtures; tests/test_oracle_golden.py, tests/test_reference_binding.py).
 
 Input `state` is the dict produced by oracle.cc.Stability.result():
     unique_recs      int32 [U,5]  (min_x, max_x, min_y, max_y, size) of each unique CC's first-seen mask
