@@ -98,8 +98,8 @@ __global__ void __launch_bounds__(256) lm_k_pair_overlap(const LmCcRec* __restri
 // G3: group images.  Item = (group, age segment); its image covers the group's box.  For every item the
 // host lists the members present in the segment with the number of frame entries they have in it.
 // Work unit = (item, 64x64 tile of its box): accumulate (crop bit) * count into an LDS int32 tile.
-//   pass A (lm_k_gimg_max)    per-item maximum of the accumulated mask
-//   pass B (lm_k_gimg_write)  recompute and write  ((double)v / (double)max >= thr) ? 255 : 0
+//   pass A (lm_k_gimg_max)    per-item maximum of the accumulated mask; items of ONE tile are thresholded and written here
+//   pass B (lm_k_gimg_write)  items of several tiles: recompute and write  ((double)v / (double)max >= thr) ? 255 : 0
 // ------------------------------------------------------------------------------------------------
 struct LmGimgItem {
     int32_t x0, y0, w, h;        // group box origin and size
@@ -149,10 +149,38 @@ LM_DEV void lm_gimg_accumulate(const LmGimgItem& it, const LmGimgUnit& un, const
     __syncthreads();
 }
 
+// The tile's pixels with (double)v / mx >= thr as bit rows of the item (two words per 64-px tile row).  s_mask holds the tile's sums.
+LM_DEV void lm_gimg_write_tile(const LmGimgItem& it, const LmGimgUnit& un, const int* s_mask, int item_max, double thr, uint32_t* __restrict__ bits)
+{
+    const double mx = (double)item_max;
+    // (double)v / mx >= thr is monotone in v: one exact integer bound per tile instead of a float64 division per pixel
+    int vmin = (int)(thr * mx);
+    if (vmin < 0) vmin = 0;
+    while (vmin > 0 && (double)(vmin - 1) / mx >= thr) vmin--;
+    while ((double)vmin / mx < thr) vmin++;
+    const int tw = (it.w - un.tx * LM_GT < LM_GT) ? it.w - un.tx * LM_GT : LM_GT;
+    const int th = (it.h - un.ty * LM_GT < LM_GT) ? it.h - un.ty * LM_GT : LM_GT;
+    const int bw = (it.w + 31) >> 5;
+    // a lane per pixel of a tile row (conflict-free LDS reads), the ballot is the row's two words
+    const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6), lane = lm_lane();
+    for (int yy = wave; yy < LM_GT; yy += nwaves) {         // every wave runs all its trips: ballots need whole waves
+        const bool on = yy < th && lane < tw && s_mask[yy * LM_GT + lane] >= vmin;
+        const unsigned long long m = __ballot(on);
+        if (yy < th && lane < 2 && un.tx * 2 + lane < bw)
+            bits[it.bits_off + (long long)(un.ty * LM_GT + yy) * bw + un.tx * 2 + lane] = (unsigned)(m >> (32 * lane));
+    }
+}
+
+// an item that is a single 64 x 64 tile: its maximum is the tile's, known to the workgroup that accumulates the tile
+LM_DEV bool lm_gimg_single_tile(const LmGimgItem& it) { return it.w <= LM_GT && it.h <= LM_GT; }
+
+// Pass 1: per-item maximum of the accumulated member masks (the reference's mask.max(), :628).  Items of one tile -- glyph-sized
+// groups, most of them -- are finished here: threshold and bit rows straight from the sums in LDS (round 2 accumulated every tile
+// twice, once for the maximum and once for the image: 2 x 17.8 ms per 10,000-frame stream).
 __global__ void __launch_bounds__(256) lm_k_gimg_max(const LmGimgItem* __restrict__ items, const LmGimgUnit* __restrict__ units,
                                                      const unsigned* __restrict__ n_units_p, const LmGimgMember* __restrict__ members,
                                                      const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
-                                                     int32_t* __restrict__ item_max)
+                                                     int32_t* __restrict__ item_max, double thr, uint32_t* __restrict__ bits)
 {
     __shared__ int s_mask[LM_GT * LM_GT];
     __shared__ int s_max;
@@ -166,7 +194,9 @@ __global__ void __launch_bounds__(256) lm_k_gimg_max(const LmGimgItem* __restric
         for (int i = threadIdx.x; i < LM_GT * LM_GT; i += blockDim.x) mx = s_mask[i] > mx ? s_mask[i] : mx;
         if (mx) atomicMax(&s_max, mx);
         __syncthreads();
-        if (threadIdx.x == 0 && s_max) atomicMax(&item_max[un.item], s_max);
+        const int tile_max = s_max;
+        if (threadIdx.x == 0 && tile_max) atomicMax(&item_max[un.item], tile_max);
+        if (lm_gimg_single_tile(it) && tile_max) lm_gimg_write_tile(it, un, s_mask, tile_max, thr, bits);
         __syncthreads();
     }
 }
@@ -184,27 +214,9 @@ __global__ void __launch_bounds__(256) lm_k_gimg_write(const LmGimgItem* __restr
     for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
         const LmGimgUnit un = units[u];
         const LmGimgItem it = items[un.item];
+        if (lm_gimg_single_tile(it) && item_max[un.item] > 0) continue;     // finished by lm_k_gimg_max (block-uniform)
         lm_gimg_accumulate(it, un, members, cc, crop, s_mask);
-        const double mx = (double)item_max[un.item];
-        // (double)v / mx >= thr is monotone in v: one exact integer bound per tile instead of a float64 division per pixel
-        int vmin = (int)(thr * mx);
-        if (vmin < 0) vmin = 0;
-        while (vmin > 0 && (double)(vmin - 1) / mx >= thr) vmin--;
-        while ((double)vmin / mx < thr) vmin++;
-        const int tw = (it.w - un.tx * LM_GT < LM_GT) ? it.w - un.tx * LM_GT : LM_GT;
-        const int th = (it.h - un.ty * LM_GT < LM_GT) ? it.h - un.ty * LM_GT : LM_GT;
-        // a 64-px tile row is two whole words of the item's row
-        const int bw = (it.w + 31) >> 5;
-        // a lane per pixel of a tile row (conflict-free LDS reads), the ballot is the row's two words
-        {
-            const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6), lane = lm_lane();
-            for (int yy = wave; yy < LM_GT; yy += nwaves) {         // every wave runs all its trips: ballots need whole waves
-                const bool on = yy < th && lane < tw && s_mask[yy * LM_GT + lane] >= vmin;
-                const unsigned long long m = __ballot(on);
-                if (yy < th && lane < 2 && un.tx * 2 + lane < bw)
-                    bits[it.bits_off + (long long)(un.ty * LM_GT + yy) * bw + un.tx * 2 + lane] = (unsigned)(m >> (32 * lane));
-            }
-        }
+        lm_gimg_write_tile(it, un, s_mask, item_max[un.item], thr, bits);
         __syncthreads();
     }
 }
@@ -1501,7 +1513,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
                            g->img_thr > 0.0 ? 0 : 1, d_units, d_nunits);
         tm.mark("  gimg: member + tile tables (device)", st, true);
         const unsigned nb = LM_HIP_EMULATED ? 2u : (unsigned)std::min<long long>(std::max<long long>(n_tiles, 1), 8192);
-        hipLaunchKernelGGL(lm_k_gimg_max, dim3(nb), dim3(256), 0, st, g->d_items, d_units, d_nunits, d_members, s->cc, s->crop, d_max);
+        hipLaunchKernelGGL(lm_k_gimg_max, dim3(nb), dim3(256), 0, st, g->d_items, d_units, d_nunits, d_members, s->cc, s->crop, d_max, g->img_thr, g->d_gbits);
         hipLaunchKernelGGL(lm_k_gimg_write, dim3(nb), dim3(256), 0, st, g->d_items, d_units, d_nunits, d_members, s->cc, s->crop, d_max, g->img_thr,
                            g->d_gbits);
         LM_HIP(hipGetLastError());
