@@ -245,6 +245,164 @@ def make_logits(torch, synth, F, H, W, seed, f0, f1, chunk=250):
     return logits
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# N > 1: configs[3] (the logits stream, strong scaling) and the RGB stream (FCN on every rank, weak scaling)
+# ----------------------------------------------------------------------------------------------------------------------
+def main_sharded(a, torch, dist, lib, world, rank, rehearse, logits, gen_s):
+    """One process per GPU.  Both workloads run through lecturemath_amd.sharded.ShardedStream: per-frame half on every rank in pieces,
+    matching on rank 0 as the pieces arrive, the matched stream handed to rank 1 for step 03 + reconstruction (so matching of step
+    i + 1 overlaps step 03 of step i).  `value` = configs[3]: the SAME 10,000-frame logits stream as N = 1, strong scaling -- bounded
+    by its sequential halves (printed as `amdahl`); `rgb_sharded` = RGB frames -> FCN -> ... on every rank, weak scaling."""
+    from lecturemath_amd import device, digests, fcn, sharded, synth
+    H, W, F, B = a.height, a.width, a.frames, a.batch
+    dev = "cpu" if rehearse else "cuda"
+    pieces = int(os.environ.get("LM_BENCH_PIECES", "4"))
+    s_wide = torch.cuda.Stream(priority=-1)
+    s_match, s_back = torch.cuda.Stream(priority=0), torch.cuda.Stream(priority=0)
+    labels = None if a.no_labels else torch.empty((B, H, W), dtype=torch.int32, device="cuda")
+
+    def run(sh, logits_of, n_steps, n_total, timed):
+        """n_steps steps; on the group rank every step ends with step 03 + all frames rendered.  Returns (seconds, info of the last step)"""
+        clean = torch.empty((B, H, W), dtype=torch.uint8, device="cuda") if rank == sh.group_rank else None
+        gr, rdone, info, marks = None, torch.cuda.Event(), None, []
+        if timed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            if gr is not None:                      # the previous step's tables lean on the stream object that is about to be reused
+                rdone.synchronize()
+                gr.close()
+                gr = None
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(s_wide):
+                e0.record(s_wide)
+                gs = sh.step(logits_of, labels=labels, stream_wide=s_wide.cuda_stream, stream_match=s_match.cuda_stream)
+                e1.record(s_wide)
+            marks.append((e0, e1))
+            if gs is not None:
+                with torch.cuda.stream(s_back):
+                    s_back.wait_stream(s_wide)
+                    e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e2.record(s_back)
+                    gr = device.Grouping(gs, max_gap=85, min_times=3, t_window=5, min_recall=0.5, img_threshold=0.5, reconstruct=True)
+                    for f0 in range(0, n_total, B):
+                        gr.render(f0, min(B, n_total - f0), clean[:min(B, n_total - f0)])
+                    e3.record(s_back)
+                    rdone.record(s_back)
+                    marks[-1] = marks[-1] + (e2, e3)
+                    info = {"scalars": [int(v) for v in gr.array("scalars")], "gs": gs, "gr": gr}
+        if gr is not None:
+            rdone.synchronize()
+        sh.finish()
+        torch.cuda.synchronize()
+        if timed:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if timed:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        per_step = {"front_and_matching_ms": round(sum(m[0].elapsed_time(m[1]) for m in marks) / max(len(marks), 1), 3)}
+        if marks and len(marks[-1]) == 4:
+            per_step["step03_and_render_ms"] = round(sum(m[2].elapsed_time(m[3]) for m in marks) / len(marks), 3)
+        return dt, info, per_step
+
+    def collect(obj, src):
+        box = [obj if rank == src else None]
+        dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+    # ---------------- configs[3]
+    sh = sharded.ShardedStream(W, H, F, B, lib=lib, pieces=pieces)
+    lib.check(lib.lm_ctx_set_profiling(sh.fs.labeler.ctx, 0))
+    run(sh, lambda lo, hi: logits[lo:hi], max(a.warmup, 0), F, False)
+    lib.check(lib.lm_ctx_set_profiling(sh.fs.labeler.ctx, 1))
+    dt, info, per_step = run(sh, lambda lo, hi: logits[lo:hi], a.steps, F, True)
+    ms, calls, nfr = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    lib.check(lib.lm_ctx_profile_read(sh.fs.labeler.ctx, ctypes.addressof(ms), ctypes.addressof(calls), ctypes.addressof(nfr)))
+    fused = bool(lib.lm_label_was_fused(sh.fs.labeler.ctx))
+    parity = None
+    if rank == sh.group_rank and info is not None:
+        dg = digests.from_device(info["gs"], info["gr"])
+        k1 = info["gs"].counters()
+        parity = {"digests": dg, "counters": {k: k1[k] for k in ("n_cc", "n_unique", "tempo_count")}, "n_groups": info["scalars"][2], "reference": None, "match": None}
+        gpath = os.path.join(ROOT, "tests", "golden", "g9_stream1080p_digests.json")
+        if os.path.exists(gpath) and (W, H, a.seed) == (1920, 1080, 20213):
+            ref = json.load(open(gpath)).get(str(F))
+            if ref:
+                keys = [k for k in dg if k in ref]
+                parity["reference"] = "tests/golden/g9_stream1080p_digests.json[%d]" % F
+                parity["match"] = bool(all(dg[k] == ref[k] for k in keys) and ref["tempo_count"] == k1["tempo_count"] and ref["n_cc"] == k1["n_cc"])
+        info["gr"].close()
+    steps_all = [collect(per_step, r) for r in range(world)]
+    parity = collect(parity, sh.group_rank)
+    sh.close()
+    del logits
+    torch.cuda.empty_cache()
+    seq0 = steps_all[0]["front_and_matching_ms"]
+    seq1 = steps_all[sh.group_rank].get("step03_and_render_ms", 0.0) + steps_all[sh.group_rank]["front_and_matching_ms"]
+    amdahl = {"rank0_front_plus_matching_ms_per_step": seq0, "group_rank_front_plus_step03_ms_per_step": round(seq1, 3),
+              "bound_frames_per_s": round(F / (max(seq0, seq1) * 1e-3), 1) if max(seq0, seq1) > 0 else None,
+              "note": "the temporal matching replays on rank 0 (first-match-wins against first-seen masks, cc_stability_estimator.py:90-123) and step 03 "
+                      "on rank %d: a step cannot be shorter than the longer of the two, however many ranks label" % sh.group_rank}
+
+    # ---------------- RGB frames -> FCN -> ... on every rank (weak scaling)
+    rgb_res = None
+    if a.e2e_frames > 0:
+        n_rank = a.e2e_frames
+        n_tot = n_rank * world
+        sd = synth.fcn_random_state_dict(synth.FCN_SHIPPED_WIDTHS, pixel_kernel=7, seed=0) if rank == 0 else None
+        sd = sharded.broadcast_state_dict(sd, src=0, device_name="cuda")          # ONE contiguous buffer over RCCL
+        eng = fcn.FcnEngine(synth.FCN_SHIPPED_WIDTHS, 7, 3, H, W, lib, precision=a.fcn_precision)
+        eng.load_state_dict({k: v.cpu() for k, v in sd.items()})
+        lo_r, hi_r = sharded.frame_range(n_tot, rank, world)
+        rgb = torch.from_numpy(np.stack([f for t, f in enumerate(synth.whiteboard_stream(n_tot, H, W)) if lo_r <= t < hi_r])).cuda()
+        lg = torch.empty((hi_r - lo_r, H, W), dtype=torch.float32, device="cuda")
+
+        def fcn_logits(lo, hi):
+            st = torch.cuda.current_stream().cuda_stream
+            for i in range(lo, hi):
+                eng.forward_raw(rgb[i].data_ptr(), H, W, lg[i].data_ptr(), None, None, st)
+            return lg[lo:hi]
+        sh2 = sharded.ShardedStream(W, H, n_tot, min(B, n_rank), lib=lib, pieces=pieces, max_ccs_per_frame=131072, max_words_per_frame=1 << 21)
+        run(sh2, fcn_logits, 1, n_tot, False)
+        dt2, info2, per2 = run(sh2, fcn_logits, 2, n_tot, True)
+        k2 = None
+        if rank == sh2.group_rank and info2 is not None:
+            k2 = dict(info2["gs"].counters(), n_groups=info2["scalars"][2])
+            info2["gr"].close()
+        k2 = collect(k2, sh2.group_rank)
+        sh2.close()
+        eng.close()
+        rgb_res = {"workload": "%d RGB %dx%d frames per rank (one evolving whiteboard of %d frames over %d ranks), resident in HBM: FCN (%s) -> threshold+invert -> "
+                               "label -> records on the rank; matching on rank 0, step 03 + reconstruction on rank %d" % (n_rank, W, H, n_tot, world, a.fcn_precision, sh2.group_rank),
+                   "value": round(n_tot * 2 / dt2, 2), "unit": "frames/s", "scaling": "weak", "frames_per_rank": n_rank, "steps": 2,
+                   "ms_per_frame_per_rank": round(dt2 / 2 / n_rank * 1e3, 3), "stream": {k: k2[k] for k in ("n_cc", "n_unique", "n_groups")} if k2 else None,
+                   "n1_reference": "e2e_rgb of the N = 1 line is the same pipeline on one rank"}
+
+    if rank == 0:
+        launch_ms = ms.value / max(calls.value, 1)
+        fpl = nfr.value / max(calls.value, 1)
+        bpp = (4 if fused else 1) + (4 if labels is not None else 0)
+        ach = bpp * W * H * fpl / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        out = {"metric": "frames/sec end-to-end binarize+CC+group @1080p", "value": round(F * a.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": "configs[3]: the configs[2] stream (ONE synthetic %dx%d binary-board stream of %d frames per step, fp32 logits in HBM) frame-range "
+                                      "sharded over %d ranks: threshold+label+records on the owning rank in %d pieces, temporal matching on rank 0 as the pieces arrive, "
+                                      "grouping (step 03) + all %d frames reconstructed on rank 1" % (W, H, F, world, pieces, F),
+                          "frames_per_step": F, "batch": B, "parallelism": "frame-range shards of one stream; point-to-point piece transfers to rank 0 (%s)" % ("gloo rehearsal on one GPU" if rehearse else "RCCL"),
+                          "stages_not_in_timed_region": ["fcn conv stack (see rgb_sharded)"]},
+               "roofline": {"bound": "hbm", "kernel": "labelling launches of rank 0", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launch_ms": round(launch_ms, 4), "launches": calls.value,
+                            "algorithmic_bytes_per_px": bpp},
+               "cpu_baseline": None, "parity": parity, "amdahl": amdahl, "per_rank_step_ms": steps_all, "rgb_sharded": rgb_res, "gen_seconds": round(gen_s, 2)}
+        print(json.dumps(out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     a = parse()
     if a.workload == "fcn":
@@ -279,6 +437,9 @@ def main():
     logits = make_logits(torch, synth, F, H, W, a.seed, f_lo, f_hi)
     torch.cuda.synchronize()
     gen_s = time.time() - t0
+
+    if world > 1:
+        return main_sharded(a, torch, dist, lib, world, rank, rehearse, logits, gen_s)
 
     # capacities of a stream (records 32 B, crop words 4 B; sized from the generator's densities with headroom -- a capacity
     # error is raised by the library, never silent)

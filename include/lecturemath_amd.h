@@ -145,6 +145,15 @@ int lm_stream_pack_size(LmStream* s, int first_frame, int n_frames, int64_t* h_b
 int lm_stream_pack(LmStream* s, int first_frame, int n_frames, void* d_buf, int64_t bytes, void* stream);
 int lm_stream_append_packed(LmStream* s, const void* d_buf, int64_t bytes, void* stream);
 
+/* Hand-off of a MATCHED stream (step 03 on a rank of its own): the unique index of every kept CC (cc_idx_per_frame,
+ * cc_stability_estimator.py:102,117) + {n_cc, n_unique, tempo_count, n_frames} as one flat DEVICE buffer of
+ * lm_stream_assign_bytes() bytes (32-byte aligned).  The receiver appends the packed block(s) of the same frames first
+ * (lm_stream_append_packed), then imports the assignment: the stream is then what the sender's was after matching, as far as
+ * lm_group_run reads it (the active list stays behind: step 03 does not use it). */
+int lm_stream_assign_bytes(LmStream* s, int64_t* bytes, void* stream);
+int lm_stream_export_assign(LmStream* s, void* d_out, int64_t bytes, void* stream);
+int lm_stream_import_assign(LmStream* s, const void* d_in, int64_t bytes, void* stream);
+
 /* Diagnostic: sizes of the last batch handed to the batched matcher (lm_match_batch.hip):
  * out5 = {in-batch sources, CC tiles, pairs against earlier uniques, pairs against in-batch sources, frames}. Synchronises. */
 int lm_stream_match_stats(LmStream* s, int64_t* out5, void* stream);

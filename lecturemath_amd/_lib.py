@@ -59,6 +59,9 @@ SIGNATURES = {
     "lm_stream_pack": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _i64, _vp]),
     "lm_stream_append_packed": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "lm_stream_match_stats": (ctypes.c_int, [_vp, _vp, _vp]),
+    "lm_stream_assign_bytes": (ctypes.c_int, [_vp, _vp, _vp]),
+    "lm_stream_export_assign": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
+    "lm_stream_import_assign": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "lm_frame_sums": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _vp, _vp]),
     "speaker_detection_handle_frame": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     "regionCumulativeDistribution": (None, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, _vp]),

@@ -1268,4 +1268,65 @@ extern "C" int lm_stream_append_packed(LmStream* s, const void* d_buf, int64_t b
     return LM_OK;
 }
 
+// Hand-off of a MATCHED stream to another rank (step 03 on a rank of its own): the packed block carries records and crops, this
+// carries what the temporal matching added -- the unique index of every kept CC (cc_idx_per_frame, cc_stability_estimator.py:102,117)
+// and the counters.  d_out: int32 [n_cc] + 4 x int64 {n_cc, n_unique, tempo_count, n_frames} (d_out must hold lm_stream_assign_bytes).
+__global__ void __launch_bounds__(256) lm_k_assign_tail(const LmCounters* __restrict__ cnt, long long* __restrict__ tail)
+{
+    if (threadIdx.x == 0) { tail[0] = cnt->n_cc; tail[1] = cnt->n_uniq; tail[2] = (long long)cnt->tempo_count; tail[3] = cnt->n_matched; }
+}
+
+__global__ void __launch_bounds__(256) lm_k_assign_apply(const long long* __restrict__ tail, LmCounters* __restrict__ cnt)
+{
+    if (threadIdx.x == 0) { cnt->n_uniq = (int)tail[1]; cnt->tempo_count = (unsigned long long)tail[2]; cnt->n_matched = (int)tail[3]; }
+}
+
+static inline size_t lm_assign_bytes(long long n_cc) { return (((size_t)n_cc * 4 + 31) & ~(size_t)31) + 32; }
+
+extern "C" int lm_stream_assign_bytes(LmStream* s, int64_t* bytes, void* stream)
+{
+    if (!s || !bytes) { lm_set_error("lm_stream_assign_bytes: bad arguments"); return LM_ERR_ARG; }
+    LmCounters h;
+    LM_HIP(hipMemcpyAsync(&h, s->counters, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    LM_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (h.error) { lm_set_error("lm_stream_assign_bytes: stream capacity exceeded on device"); return h.error; }
+    *bytes = (int64_t)lm_assign_bytes(h.n_cc);
+    return LM_OK;
+}
+
+extern "C" int lm_stream_export_assign(LmStream* s, void* d_out, int64_t bytes, void* stream)
+{
+    if (!s || !d_out || bytes < 32 || (((uintptr_t)d_out) & 31)) { lm_set_error("lm_stream_export_assign: bad arguments"); return LM_ERR_ARG; }
+    if (s->frames_matched != s->frames_pushed) { lm_set_error("lm_stream_export_assign: %d frames are unmatched", s->frames_pushed - s->frames_matched); return LM_ERR_STATE; }
+    hipStream_t st = (hipStream_t)stream;
+    const long long n_cc = (long long)((bytes - 32) / 4);       // the caller sized the buffer with lm_stream_assign_bytes
+    LM_HIP(hipMemcpyAsync(d_out, s->assign, (size_t)(bytes - 32), hipMemcpyDeviceToDevice, st));
+    (void)n_cc;
+    hipLaunchKernelGGL(lm_k_assign_tail, dim3(1), dim3(64), 0, st, s->counters, (long long*)((char*)d_out + bytes - 32));
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+// the stream must hold exactly the frames the assignment belongs to (appended with lm_stream_append_packed), all of them unmatched
+extern "C" int lm_stream_import_assign(LmStream* s, const void* d_in, int64_t bytes, void* stream)
+{
+    if (!s || !d_in || bytes < 32 || (((uintptr_t)d_in) & 31)) { lm_set_error("lm_stream_import_assign: bad arguments"); return LM_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    long long tail[4];
+    LmCounters h;
+    LM_HIP(hipMemcpyAsync(tail, (const char*)d_in + bytes - 32, 32, hipMemcpyDeviceToHost, st));
+    LM_HIP(hipMemcpyAsync(&h, s->counters, sizeof(h), hipMemcpyDeviceToHost, st));
+    LM_HIP(hipStreamSynchronize(st));
+    if (tail[0] != h.n_cc || tail[3] != s->frames_pushed || (size_t)bytes != lm_assign_bytes(tail[0]) || s->frames_matched != 0 || tail[1] > s->cap_uniq) {
+        lm_set_error("lm_stream_import_assign: the assignment (%lld CCs, %lld frames) does not belong to this stream (%lld CCs, %d frames, %d matched)",
+                     tail[0], tail[3], h.n_cc, s->frames_pushed, s->frames_matched);
+        return LM_ERR_ARG;
+    }
+    LM_HIP(hipMemcpyAsync(s->assign, d_in, (size_t)h.n_cc * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(lm_k_assign_apply, dim3(1), dim3(64), 0, st, (const long long*)((const char*)d_in + bytes - 32), s->counters);
+    LM_HIP(hipGetLastError());
+    s->frames_matched = s->frames_pushed;
+    return LM_OK;
+}
+
 #include "lm_legacy.hip"

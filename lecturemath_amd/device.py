@@ -228,6 +228,18 @@ class FrameStream:
         """Append a packed block (device uint8 buffer from pack(), possibly received from another rank) behind the last frame."""
         self.lib.check(self.lib.lm_stream_append_packed(self.handle, _lib.ptr(buf), int(buf.shape[0]), self.be.stream()))
 
+    def export_assign(self):
+        """What the temporal matching added to the records, as one flat device uint8 buffer (lm_stream_export_assign): the hand-off of
+        a matched stream to the rank that runs step 03, together with pack(0, n_frames)."""
+        nb = ctypes.c_int64(0)
+        self.lib.check(self.lib.lm_stream_assign_bytes(self.handle, ctypes.addressof(nb), self.be.stream()))
+        buf = self.be.empty((int(nb.value),), np.uint8)
+        self.lib.check(self.lib.lm_stream_export_assign(self.handle, _lib.ptr(buf), int(nb.value), self.be.stream()))
+        return buf
+
+    def import_assign(self, buf):
+        self.lib.check(self.lib.lm_stream_import_assign(self.handle, _lib.ptr(buf), int(buf.shape[0]), self.be.stream()))
+
     def counters(self):
         k = np.zeros(7, np.int64)
         self.lib.check(self.lib.lm_stream_counters(self.handle, k.ctypes.data, self.be.stream()))

@@ -121,3 +121,159 @@ def run_stream_sharded(my_frames_dev, n_frames_total, width, height, min_recall=
     finally:
         if fs is not None:
             fs.close()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the pipelined form: pieces, matching on rank 0, step 03 on rank 1
+# ----------------------------------------------------------------------------------------------------------------------
+def piece_bounds(n, pieces):
+    """[lo, hi) of `pieces` nearly equal consecutive pieces of n frames (empty ones dropped)"""
+    out = []
+    for c in range(pieces):
+        lo, hi = n * c // pieces, n * (c + 1) // pieces
+        if hi > lo:
+            out.append((lo, hi))
+    return out
+
+
+class _Wire:
+    """point-to-point transfers of flat uint8 device buffers: device to device over RCCL ("nccl"), staged through the host under
+    gloo (CPU tests, the one-GPU rehearsal).  Sends are asynchronous; `drain` waits for them (buffers stay referenced until then)."""
+
+    def __init__(self, be):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.be = torch, dist, be
+        self.nccl = dist.get_backend() == "nccl"
+        self.pending = []
+
+    def _wire_tensor(self, buf):
+        t = buf if hasattr(buf, "data_ptr") else self.torch.from_numpy(np.ascontiguousarray(buf))
+        return t if (self.nccl or not t.is_cuda) else t.cpu()
+
+    def send(self, buf, dst, failed=False):
+        """size header (-1: the sender failed, nothing follows) + payload"""
+        dev = "cuda" if self.nccl else "cpu"
+        if failed:
+            self.pending.append((self.dist.isend(self.torch.tensor([-1], dtype=self.torch.int64, device=dev), dst=dst), None))
+            return
+        t = self._wire_tensor(buf)
+        head = self.torch.tensor([t.numel()], dtype=self.torch.int64, device=dev)
+        self.pending.append((self.dist.isend(head, dst=dst), head))
+        self.pending.append((self.dist.isend(t, dst=dst), t))
+
+    def recv(self, src):
+        dev = "cuda" if self.nccl else "cpu"
+        head = self.torch.zeros(1, dtype=self.torch.int64, device=dev)
+        self.dist.recv(head, src=src)
+        n = int(head.item())
+        if n < 0:
+            raise RuntimeError("rank %d reported a failure in its share of the stream" % src)
+        rb = self.torch.empty(n, dtype=self.torch.uint8, device=dev)
+        self.dist.recv(rb, src=src)
+        if self.nccl:
+            return rb
+        if self.be.device:
+            return rb.cuda()
+        out = self.be.empty((n,), np.uint8)
+        out[:] = rb.numpy()
+        return out
+
+    def drain(self):
+        for w, _keep in self.pending:
+            w.wait()
+        self.pending = []
+
+
+class ShardedStream:
+    """ONE stream of n_frames per step over the ranks of the process group, pipelined (SURVEY.md 8(e) + what measuring it showed:
+    the sequential half is not small -- at 10,000 1080p frames the matching replay is ~140 ms and step 03 ~105 ms of a ~230 ms step):
+      * every rank runs the per-frame half (threshold -> label -> records / crops) of its contiguous frame range in `pieces` pieces and
+        sends each piece to rank 0 as soon as it is packed (lm_stream_pack), asynchronously;
+      * rank 0 matches its own pieces as it produces them, then appends and matches the other ranks' pieces in frame order
+        (first-match-wins against first-seen masks is sequential, cc_stability_estimator.py:90-123) while they still label later ones;
+      * the matched stream (records + crops + assignment) goes to `group_rank` (rank 1 when there is one), which runs step 03 and the
+        reconstruction while the other ranks are already in the next step.
+    step() returns the matched whole-stream FrameStream on group_rank and None elsewhere.  A rank that fails sends a failure header
+    for its remaining pieces, so rank 0 raises instead of waiting for ever."""
+
+    def __init__(self, width, height, n_frames, batch, lib=None, pieces=4, min_recall=0.85, min_precision=0.85, max_gap=85, min_pixels=20,
+                 max_ccs_per_frame=4096, max_words_per_frame=None, group_on_second_rank=True):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank, self.world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+        self.W, self.H, self.F, self.B, self.pieces = width, height, n_frames, batch, max(1, pieces)
+        self.lo, self.hi = frame_range(n_frames, self.rank, self.world)
+        self.group_rank = 1 if (self.world > 1 and group_on_second_rank) else 0
+        words = max_words_per_frame or max(1 << 17, (width * height) // 16)
+
+        def make(frames):
+            frames = max(frames, 1)
+            return device.FrameStream(width, height, frames, min_recall, min_precision, max_gap, min_pixels, max_batch=batch,
+                                      max_ccs=frames * max_ccs_per_frame, max_crop_words=frames * words, lib=lib)
+        self.fs = make(n_frames if self.rank == 0 else self.hi - self.lo)           # rank 0: the whole stream (it matches it)
+        self.gs = make(n_frames) if (self.rank == self.group_rank and self.rank != 0) else None
+        self.lib, self.be = self.fs.lib, self.fs.be
+        self.wire = _Wire(self.be) if self.world > 1 else None
+
+    def close(self):
+        for s in (self.fs, self.gs):
+            if s is not None:
+                s.close()
+        self.fs = self.gs = None
+
+    def step(self, logits_of, labels=None, stream_wide=None, stream_match=None, schedule=1):
+        """logits_of(lo, hi) -> device fp32 [hi - lo, H, W]: the logits of frames lo..hi of THIS rank's range (0-based in the range).
+        labels: optional device int32 [batch, H, W] receiving the label image of every batch in turn."""
+        from . import _lib
+        fs, lib = self.fs, self.lib
+        ws = self.be.stream() if stream_wide is None else stream_wide
+        ms = ws if stream_match is None else stream_match
+        if self.wire:
+            self.wire.drain()                   # the previous step's sends
+        fs.reset()
+        mine = piece_bounds(self.hi - self.lo, self.pieces)
+        k = 0
+        try:
+            for k, (a, b) in enumerate(mine):
+                lg = logits_of(a, b)
+                lib.check(lib.lm_stream_run_logits(fs.handle, _lib.ptr(lg), b - a, self.B, None, _lib.ptr(labels), 128, 1 if self.rank == 0 else 0,
+                                                   schedule, ws, ms if self.rank == 0 else ws))
+                if self.rank != 0:
+                    self.wire.send(fs.pack(a, b - a), 0)
+        except Exception:
+            if self.rank != 0:
+                for _ in range(len(mine) - k):
+                    self.wire.send(None, 0, failed=True)
+            raise
+        if self.rank == 0:
+            if ms != ws:
+                self._join(ms, ws)
+            for r in range(1, self.world):
+                rlo, rhi = frame_range(self.F, r, self.world)
+                for a, b in piece_bounds(rhi - rlo, self.pieces):
+                    fs.append_packed(self.wire.recv(r))
+                    fs.match(b - a)
+            if self.group_rank != 0:
+                self.wire.send(fs.pack(0, self.F), self.group_rank)
+                self.wire.send(fs.export_assign(), self.group_rank)
+                return None
+            return fs
+        if self.rank == self.group_rank:
+            self.gs.reset()
+            self.gs.append_packed(self.wire.recv(0))
+            self.gs.import_assign(self.wire.recv(0))
+            return self.gs
+        return None
+
+    def _join(self, side, main):
+        """the work queued on the matching stream precedes what follows on the main one"""
+        if self.be.device:
+            t = self.be.torch
+            ev = t.cuda.Event()
+            ev.record(t.cuda.ExternalStream(side))
+            t.cuda.ExternalStream(main).wait_event(ev)
+
+    def finish(self):
+        if self.wire:
+            self.wire.drain()

@@ -39,6 +39,27 @@ def _worker(rank, world, port, emu_path, out_dir):
     got = sharded.broadcast_state_dict(sd, src=0)
     ref = ofcn.random_state_dict((8,) * 18, pixel_kernel=3, seed=3)
     assert all(torch.equal(got[k], ref[k]) for k in ref) and len(got) == len(ref)
+    # the pipelined form: pieces sent as they are packed, matching on rank 0, the matched stream handed to rank 1 for step 03; two steps
+    logits = synth.logits_from_binary(frames, seed=2)
+    sh = sharded.ShardedStream(160, 96, len(frames), 4, lib=lib, pieces=3, max_gap=5)
+    assert sh.group_rank == 1
+    for step in range(2):
+        gs = sh.step(lambda a, b: np.ascontiguousarray(logits[f0 + a:f0 + b]))
+        assert (gs is not None) == (rank == 1)
+        if rank == 1:
+            single = device.FrameStream(160, 96, len(frames), 0.85, 0.85, 5, 20, max_batch=4, lib=lib)
+            single.push(frames)
+            a, b = gs.read(), single.read()
+            for key in ("rec", "frame_off", "crop_off"):
+                assert (a[key] == b[key]).all(), key
+            assert (a["crop"][:a["n_crop_words"]] == b["crop"][:b["n_crop_words"]]).all() and a["tempo_count"] == b["tempo_count"] and a["n_unique"] == b["n_unique"]
+            ga, gb = device.Grouping(gs, max_gap=5).result(), device.Grouping(single, max_gap=5).result()
+            assert ga["cc_groups"] == gb["cc_groups"] and ga["group_ages"] == gb["group_ages"]
+            assert all((x == y).all() for x, y in zip(ga["clean_binary"], gb["clean_binary"]))
+            single.close()
+            open(os.path.join(out_dir, "ok_pipelined_%d" % step), "w").write("ok")
+    sh.finish()
+    sh.close()
     if rank == 0:
         o = occ.Stability(160, 96, 0.85, 0.85, 5)
         for f in frames:
@@ -67,4 +88,4 @@ def test_frame_range():
 
 def test_sharded_stream_two_ranks(emu_lib, oracle_built, tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), emu_lib.path, str(tmp_path)), nprocs=2, join=True)
-    assert (tmp_path / "ok").exists()
+    assert (tmp_path / "ok").exists() and (tmp_path / "ok_pipelined_0").exists() and (tmp_path / "ok_pipelined_1").exists()

@@ -46,6 +46,27 @@ def _worker(rank, world, port, out_dir):
     got = sharded.broadcast_state_dict(sd, src=0, device_name="cuda")
     ref = ofcn.random_state_dict((8,) * 18, pixel_kernel=3, seed=3)
     assert len(got) == len(ref) and all(torch.equal(got[k].cpu(), ref[k]) for k in ref)
+    # the pipelined form (bench.py --gpus N): pieces to rank 0 as they are packed, matching on rank 0, the MATCHED stream handed to rank 1
+    # (lm_stream_pack + lm_stream_export_assign -> lm_stream_append_packed + lm_stream_import_assign), step 03 there; two steps
+    logits = torch.from_numpy(synth.logits_from_binary(frames[f0:f1], seed=4)).cuda()
+    sh = sharded.ShardedStream(w, h, n, 32, lib=lib, pieces=3)
+    for step in range(2):
+        gs = sh.step(lambda a, b: logits[a:b])
+        assert (gs is not None) == (rank == 1)
+        if rank == 1:
+            single = device.FrameStream(w, h, n, 0.85, 0.85, 85, 20, max_batch=32, lib=lib)
+            single.push(torch.from_numpy(frames).cuda())
+            a, b = gs.read(), single.read()
+            for key in ("rec", "frame_off", "crop_off"):
+                assert (a[key] == b[key]).all(), key
+            assert (a["crop"][:a["n_crop_words"]] == b["crop"][:b["n_crop_words"]]).all() and a["tempo_count"] == b["tempo_count"]
+            ga, gb = device.Grouping(gs), device.Grouping(single)
+            assert digests.from_device(gs, ga) == digests.from_device(single, gb)
+            assert bool((ga.render(0, n) == gb.render(0, n)).all())
+            ga.close(); gb.close(); single.close()
+            open(os.path.join(out_dir, "ok_pipelined_%d" % step), "w").write("ok")
+    sh.finish()
+    sh.close()
     if rank == 0:
         single = device.FrameStream(w, h, n, 0.85, 0.85, 85, 20, max_batch=32, lib=lib)
         single.push(torch.from_numpy(frames).cuda())
@@ -65,4 +86,4 @@ def _worker(rank, world, port, out_dir):
 
 def test_sharded_stream_two_processes_on_one_gpu(hip_lib, tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    assert (tmp_path / "ok").exists()
+    assert (tmp_path / "ok").exists() and (tmp_path / "ok_pipelined_0").exists() and (tmp_path / "ok_pipelined_1").exists()
