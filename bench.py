@@ -93,9 +93,19 @@ def fcn_flops(widths, pk, kk, h, w):
 # ----------------------------------------------------------------------------------------------------------------------
 # configs[1]: FCN-LectureNet inference at 1080p, measured in this process
 # ----------------------------------------------------------------------------------------------------------------------
+MAX_FCN_PIXELS = 2.5e6       # FCN_LectureNet.MAX_PIXELS (FCN_lecturenet.py:430-437): larger frames are LANCZOS-halved first
+
+
+def fcn_frame_size(H, W):
+    while W * H > MAX_FCN_PIXELS:
+        W, H = int(W / 2), int(H / 2)
+    return H, W
+
+
 def measure_fcn(a, lib, H, W, n_frames, with_oracle):
     import torch
     from lecturemath_amd import fcn, synth
+    H, W = fcn_frame_size(H, W)      # configs[4]: the network always runs at <= 2.5 MP
     widths, pk = synth.FCN_SHIPPED_WIDTHS, 7
     sd = synth.fcn_random_state_dict(widths, pixel_kernel=pk, seed=0)
     eng = fcn.FcnEngine(widths, pk, 3, H, W, lib, precision=a.fcn_precision)
@@ -153,9 +163,18 @@ def measure_e2e_rgb(a, lib, eng, H, W, n_frames):
     reconstructed.  Random-init weights: the binarization is whatever the network emits (CC counts are reported)."""
     import torch
     from lecturemath_amd import _lib, device, synth
+    fh, fw = fcn_frame_size(H, W)
+    big = (fh, fw) != (H, W)
+    if big:
+        n_frames = min(n_frames, 32)
     rgb = torch.from_numpy(np.stack(list(synth.whiteboard_stream(n_frames, H, W)))).cuda()
-    logits = torch.empty((n_frames, H, W), dtype=torch.float32, device="cuda")
+    logits = torch.empty((n_frames, fh, fw), dtype=torch.float32, device="cuda")
     clean = torch.empty((n_frames, H, W), dtype=torch.uint8, device="cuda")
+    if big:         # configs[4]: LANCZOS halving -> network -> threshold -> NEAREST enlargement -> CC pipeline at the frame's own size
+        from lecturemath_amd import resize
+        rs = resize.DeviceResizer(lib)
+        small = torch.empty((fh, fw), dtype=torch.uint8, device="cuda")
+        binary = torch.empty((n_frames, H, W), dtype=torch.uint8, device="cuda")
     labels = torch.empty((min(a.batch, n_frames), H, W), dtype=torch.int32, device="cuda")
     fs = device.FrameStream(W, H, n_frames, 0.85, 0.85, 85, 20, max_batch=min(a.batch, n_frames), max_ccs=n_frames * 131072,
                             max_crop_words=n_frames * (1 << 21), lib=lib)
@@ -163,9 +182,19 @@ def measure_e2e_rgb(a, lib, eng, H, W, n_frames):
 
     def once():
         fs.reset()
-        for i in range(n_frames):
-            eng.forward_raw(rgb[i].data_ptr(), H, W, logits[i].data_ptr(), None, None, st)
-        lib.check(lib.lm_stream_run_logits(fs.handle, logits.data_ptr(), n_frames, min(a.batch, n_frames), None, labels.data_ptr(), 128, 1, 0, st, st))
+        if big:
+            for i in range(n_frames):
+                half = rs.lanczos(rgb[i], fw, fh)
+                eng.forward_raw(half.data_ptr(), fh, fw, logits[i].data_ptr(), None, None, st)
+                lib.check(lib.lm_threshold_invert(logits[i].data_ptr(), small.data_ptr(), fh * fw, 128, st))
+                lib.check(lib.lm_upsample_nearest_u8(small.data_ptr(), fh, fw, 1, binary[i].data_ptr(), H, W, st))
+            for f0 in range(0, n_frames, a.batch):
+                n = min(a.batch, n_frames - f0)
+                lib.check(lib.lm_stream_push(fs.handle, binary[f0:f0 + n].data_ptr(), n, labels.data_ptr(), st))
+        else:
+            for i in range(n_frames):
+                eng.forward_raw(rgb[i].data_ptr(), H, W, logits[i].data_ptr(), None, None, st)
+            lib.check(lib.lm_stream_run_logits(fs.handle, logits.data_ptr(), n_frames, min(a.batch, n_frames), None, labels.data_ptr(), 128, 1, 0, st, st))
         gr = device.Grouping(fs, max_gap=85, min_times=3, t_window=5, min_recall=0.5, img_threshold=0.5, reconstruct=True)
         gr.render(0, n_frames, clean)
         torch.cuda.synchronize()
@@ -181,8 +210,9 @@ def measure_e2e_rgb(a, lib, eng, H, W, n_frames):
             sc = once()
         dt = (time.perf_counter() - t0) / reps
         k = fs.counters()
-        return {"workload": "%d RGB %dx%d frames of one evolving synthetic whiteboard, resident in HBM: FCN (%s) -> threshold+invert -> label -> records -> "
-                            "matching -> step 03 -> %d reconstructed frames" % (n_frames, W, H, a.fcn_precision, n_frames),
+        return {"workload": "%d RGB %dx%d frames of one evolving synthetic whiteboard, resident in HBM: %sFCN (%s)%s -> threshold+invert -> %slabel -> records -> "
+                            "matching -> step 03 -> %d reconstructed frames" % (n_frames, W, H, "LANCZOS 1/2 (device) -> " if big else "", a.fcn_precision,
+                                                                                " at %dx%d" % (fw, fh) if big else "", "NEAREST x2 (device) -> " if big else "", n_frames),
                 "frames": n_frames, "value": round(n_frames / dt, 2), "unit": "frames/s", "ms_per_frame": round(dt / n_frames * 1e3, 3),
                 "stream": {"n_cc": k["n_cc"], "n_unique": k["n_unique"], "n_groups": int(sc[2])}}
     except _lib.LecturemathError as e:

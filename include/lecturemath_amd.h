@@ -267,6 +267,16 @@ int lm_fcn_set_layer_terms(LmFcn* f, int layer, int terms);
  * binarization logit (no sigmoid), d_text [h*w] text-mask logit, d_rec [3][h*w] tanh reconstruction. */
 int lm_fcn_forward(LmFcn* f, const uint8_t* d_rgb, int h, int w, float* d_out, float* d_text, float* d_rec, void* stream);
 
+/* Frame pre / post-processing of binarize()'s > 2.5 MP branch on the device (csrc/lm_resize.hip):
+ * PIL.Image.resize(..., LANCZOS) (FCN_lecturenet.py:434-437; Pillow's two-pass 8-bit resampling with 22-bit fixed-point taps --
+ * the taps and their bounds per output column / row are DEVICE tables computed by lecturemath_amd/resize.py) and
+ * cv2.resize(..., INTER_NEAREST) back to the frame's size (:481-486).  channels: 1 or 3 (interleaved).  d_tmp: in_h * out_w *
+ * channels bytes of scratch. */
+int lm_resample_rgb8(const uint8_t* d_in, int in_h, int in_w, int channels, uint8_t* d_tmp, uint8_t* d_out, int out_h, int out_w,
+                     const int32_t* d_bounds_h, const int32_t* d_kk_h, int ksize_h, const int32_t* d_bounds_v, const int32_t* d_kk_v,
+                     int ksize_v, void* stream);
+int lm_upsample_nearest_u8(const uint8_t* d_in, int in_h, int in_w, int channels, uint8_t* d_out, int out_h, int out_w, void* stream);
+
 /* ----------------------------------------------------------------------------------------------------
  * Second FCN engine (csrc/lm_fcn2.hip): the same forward pass for the shipped topology (3x3 encoder / decoder, 7x7 pixel
  * branch, every width a multiple of 16) on planar f16 activations and one gather-GEMM kernel, operand format per layer.

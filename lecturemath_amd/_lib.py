@@ -84,6 +84,9 @@ SIGNATURES = {
                                         ctypes.c_int]),
     "lm_fcn_set_layer_terms": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "lm_fcn_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "lm_resample_rgb8": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp,
+                                        ctypes.c_int, _vp]),
+    "lm_upsample_nearest_u8": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "lm_fcn2_create": (_vp, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
     "lm_fcn2_destroy": (None, [_vp]),
     "lm_fcn2_set_layer": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int, _vp, _i64, ctypes.c_int, _vp, ctypes.c_int]),

@@ -1330,3 +1330,4 @@ extern "C" int lm_stream_import_assign(LmStream* s, const void* d_in, int64_t by
 }
 
 #include "lm_legacy.hip"
+#include "lm_resize.hip"

@@ -60,36 +60,74 @@ class FCN_LectureNet:
         """Extension: uint8 RGB [H,W,3] (numpy or device tensor) -> device fp32 (logit, text logit, reconstruction)."""
         return self._get_engine(int(rgb_u8.shape[0]), int(rgb_u8.shape[1])).forward(rgb_u8)
 
+    def _resizer(self):
+        if getattr(self, "_rs", None) is None:
+            from lecturemath_amd import resize
+            self._rs = resize.DeviceResizer()
+        return self._rs
+
+    def _halve_on_device(self, rgb_dev, width, height):
+        """:434-437 -- `while width * height > MAX_PIXELS: resize((int(width / 2), int(height / 2)), LANCZOS)` on the device
+        (Pillow's two-pass fixed-point resampling, lecturemath_amd/resize.py)"""
+        while width * height > FCN_LectureNet.MAX_PIXELS:
+            width, height = int(width / 2), int(height / 2)
+            rgb_dev = self._resizer().lanczos(rgb_dev, width, height)
+        return rgb_dev, width, height
+
     def binarize_frames_device(self, rgb_frames, binary_threshold=128):
         """Extension for whole videos: uint8 RGB [n,H,W,3] (numpy or device tensor) -> device uint8 [n,H,W], the worker's inverted
-        binary (ink = 255; :452-467 + FCN_lecturenet_binarizer.py:54); nothing leaves the device."""
+        binary (ink = 255; :452-467 + FCN_lecturenet_binarizer.py:54); nothing leaves the device.  Frames above 2.5 MP go through the
+        reference's resize branch (:434-437 LANCZOS halving, :481-486 INTER_NEAREST back) on the device as well."""
         n, h, w = int(rgb_frames.shape[0]), int(rgb_frames.shape[1]), int(rgb_frames.shape[2])
-        eng = self._get_engine(h, w)
+        big = w * h > FCN_LectureNet.MAX_PIXELS
+        nw, nh = w, h
+        while nw * nh > FCN_LectureNet.MAX_PIXELS:
+            nw, nh = int(nw / 2), int(nh / 2)
+        eng = self._get_engine(nh, nw)
         lib, be = eng.lib, eng.be
         out = be.empty((n, h, w), np.uint8)
+        small = be.empty((nh, nw), np.uint8) if big else None
         for i in range(n):
-            logits, _, _ = eng.forward(rgb_frames[i])
+            frame = rgb_frames[i] if not isinstance(rgb_frames, np.ndarray) else be.from_host(rgb_frames[i])
+            if big:
+                frame, _, _ = self._halve_on_device(frame, w, h)
+            logits, _, _ = eng.forward(frame)
             dst = out[i] if be.device else out[i:i + 1]
-            lib.check(lib.lm_threshold_invert(_lib.ptr(logits), _lib.ptr(dst), h * w, int(binary_threshold), be.stream()))
+            if big:
+                lib.check(lib.lm_threshold_invert(_lib.ptr(logits), _lib.ptr(small), nh * nw, int(binary_threshold), be.stream()))
+                lib.check(lib.lm_upsample_nearest_u8(_lib.ptr(small), nh, nw, 1, _lib.ptr(dst), h, w, be.stream()))
+            else:
+                lib.check(lib.lm_threshold_invert(_lib.ptr(logits), _lib.ptr(dst), h * w, int(binary_threshold), be.stream()))
         return out
 
     def binarize(self, PIL_image, return_others=False, force_binary=False, binary_treshold=128, apply_sigmoid=True):
         o_width, o_height = PIL_image.size
+        rgb_full = np.asarray(PIL_image.convert("RGB"), dtype=np.uint8)
+        eng0_be = None
         width, height = o_width, o_height
-        while width * height > FCN_LectureNet.MAX_PIXELS:
-            PIL_image = PIL_image.resize((int(width / 2), int(height / 2)), PIL.Image.LANCZOS)
-            width, height = PIL_image.size
-        rgb = np.asarray(PIL_image.convert("RGB"), dtype=np.uint8)
+        if width * height > FCN_LectureNet.MAX_PIXELS:
+            # the whole > 2.5 MP branch on the device: one upload of the frame, LANCZOS halving(s), network, threshold, NEAREST enlargement
+            from lecturemath_amd.device import Backend
+            eng0_be = Backend(_lib.load())
+            rgb, width, height = self._halve_on_device(eng0_be.from_host(rgb_full), width, height)
+        else:
+            rgb = rgb_full
         eng = self._get_engine(height, width)
         out, text, rec = eng.forward(rgb)
         lib, be = eng.lib, eng.be
         n = height * width
+        resized = o_width != width
+        if resized and not force_binary:
+            raise NotImplementedError("INTER_CUBIC upsampling of non-binary outputs (:487-492) is not implemented")
+
+        def enlarge(dev_u8):
+            return self._resizer().nearest(dev_u8, o_width, o_height) if resized else dev_u8
 
         def post(logits):
             if force_binary and apply_sigmoid:
                 dst = be.empty((height, width), np.uint8)
                 lib.check(lib.lm_threshold(_lib.ptr(logits), _lib.ptr(dst), n, int(binary_treshold), 0, be.stream()))
-                return be.to_host(dst)
+                return be.to_host(enlarge(dst))
             v = be.to_host(logits)
             if apply_sigmoid:
                 v = (1.0 / (1.0 + np.exp(-v, dtype=np.float32))).astype(np.float32)
@@ -97,22 +135,15 @@ class FCN_LectureNet:
             if force_binary:
                 img[img >= binary_treshold] = 255
                 img[img < binary_treshold] = 0
-            return img
+            return be.to_host(enlarge(be.from_host(img))) if resized else img
 
         binary = post(out)
         text_mask = rec_img = None
         if return_others:
             text_mask = post(text)
             rec_img = self.from_img_space_to_cv2(be.to_host(rec))
-        if o_width != width:
-            if not force_binary:
-                raise NotImplementedError("INTER_CUBIC upsampling of non-binary outputs (:487-492) is not implemented")
-            ys = (np.arange(o_height) * height) // o_height      # INTER_NEAREST
-            xs = (np.arange(o_width) * width) // o_width
-            binary = binary[ys][:, xs]
-            if return_others:
-                text_mask = text_mask[ys][:, xs]
-                rec_img = rec_img[ys][:, xs]
+            if resized:
+                rec_img = be.to_host(self._resizer().nearest(be.from_host(rec_img), o_width, o_height))
         return (binary, text_mask, rec_img) if return_others else binary
 
     def from_img_space_to_cv2(self, image):

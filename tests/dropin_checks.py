@@ -416,6 +416,25 @@ def check_overlap_golden(lib):
         assert np.float64(r).view(np.int64) == g["recall"][k].view(np.int64) and np.float64(p).view(np.int64) == g["precision"][k].view(np.int64), k
 
 
+def check_resize_golden(lib):
+    """lm_resample_rgb8 (Pillow's LANCZOS, FCN_lecturenet.py:434-437) against images Pillow itself resized (G6b, recorded in the build
+    container: halvings of even / odd sizes, a 3:1 reduction, an enlargement, a one-axis change; RGB and single channel), byte for
+    byte; lm_upsample_nearest_u8 (:481-486) against the index formula."""
+    from lecturemath_amd import resize
+    g = np.load(os.path.join(lm_checks.GOLD, "g6b_lanczos.npz"))
+    rs = resize.DeviceResizer(lib)
+    for i, (h, w, oh, ow) in enumerate(g["cases"]):
+        got = rs.be.to_host(rs.lanczos(g["in%d" % i], int(ow), int(oh)))
+        assert got.shape == (oh, ow, 3) and (got == g["out%d" % i]).all(), i
+        one = rs.be.to_host(rs.lanczos(np.ascontiguousarray(g["in%d" % i][:, :, 2]), int(ow), int(oh)))
+        assert (one == g["out%d" % i][:, :, 2]).all(), i
+    a = g["in1"]
+    for (oh, ow) in ((2 * a.shape[0], 2 * a.shape[1]), (3 * a.shape[0], 4 * a.shape[1])):
+        ys, xs = (np.arange(oh) * a.shape[0]) // oh, (np.arange(ow) * a.shape[1]) // ow
+        assert (rs.be.to_host(rs.nearest(a, ow, oh)) == a[ys][:, xs]).all()
+        assert (rs.be.to_host(rs.nearest(np.ascontiguousarray(a[:, :, 0]), ow, oh)) == a[:, :, 0][ys][:, xs]).all()
+
+
 def check_fcn_4k_resize_branch(lib, shipped=False):
     """binarize() on a 3840x2160 frame (> 2.5 MP, FCN_lecturenet.py:435-437,481-494): PIL LANCZOS halving, FCN at 1080p,
     NEAREST x2 back -- against the oracle's torch forward on the same halved image.  Tiny network by default (the branch is
@@ -440,6 +459,9 @@ def check_fcn_4k_resize_branch(lib, shipped=False):
     binary, text_mask, rec_img = net.cuda().binarize(pil, return_others=True, force_binary=True)
     assert binary.shape == (2160, 3840) and rec_img.shape == (2160, 3840, 3)
     half = np.asarray(pil.resize((1920, 1080), PIL.Image.LANCZOS))
+    from lecturemath_amd import resize
+    rs = resize.DeviceResizer(lib)
+    assert (rs.be.to_host(rs.lanczos(rgb, 1920, 1080)) == half).all()      # the device's LANCZOS halving of the 4K frame == Pillow's
     with torch.no_grad():
         o, t, r = ofcn.forward(sd, ofcn.prepare_image(half))
     exp = ((torch.sigmoid(o)[0, 0].numpy() * 255).astype(np.uint8) >= 128).astype(np.uint8) * 255

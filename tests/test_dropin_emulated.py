@@ -32,6 +32,10 @@ def test_steps_02_03_short_gap(emu_lib):
     dropin_checks.check_steps_02_03(emu_lib, "short_gap_jitter")
 
 
+def test_resize_golden(emu_lib):
+    dropin_checks.check_resize_golden(emu_lib)
+
+
 def test_fcn_class(emu_lib):
     dropin_checks.check_fcn_class(emu_lib, worker=False)       # the worker: test_step01_entry_points below
 

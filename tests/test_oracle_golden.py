@@ -143,3 +143,11 @@ def test_g8_step05(name):
         assert (np.packbits(kf[..., 0] == 255, axis=2) == g["keyframes_%d" % k]).all()
         flat = [(s, *t) for s, lst in enumerate(cc_times) for t in lst]
         assert (np.asarray(flat, np.float64).reshape(-1, 6) == g["times_%d" % k]).all()
+
+
+def test_g6b_lanczos():
+    """oracle/resize.py (numpy restatement of Pillow's LANCZOS for 8-bit images) against images resized by Pillow itself"""
+    from oracle import resize
+    g = np.load(os.path.join(GOLD, "g6b_lanczos.npz"))
+    for i, (h, w, oh, ow) in enumerate(g["cases"]):
+        assert (resize.resize_lanczos(g["in%d" % i], int(ow), int(oh)) == g["out%d" % i]).all(), i
