@@ -139,6 +139,10 @@ def measure_fcn(a, lib, H, W, n_frames, with_oracle):
             res["layer_formats"] = {str(k): ("f16 hi+lo split, 3 MFMAs per product" if v["terms"] == 3 else "f16, 1 MFMA per product")
                                     for k, v in sorted(eng.recipes.items())}
             res["layer_formats_source"] = "profiles/r03_fcn_layer_precision.json"
+            ex = eng.executed_gflop(H, W)
+            res.update({"executed_gflop_per_frame": round(ex, 1), "executed_tflops": round(ex / gpu_ms, 2),
+                        "frac_of_peak_executed": round(ex / gpu_ms / MFMA_F16_PEAK_TFLOPS, 4),
+                        "mfma_per_product": "3 in the six full-resolution layers, 1 below"})
         else:
             k = FCN_MFMA_PER_PRODUCT[a.fcn_precision]
             res.update({"mfma_per_product": k, "executed_tflops": round(k * tflops, 2)})
@@ -237,7 +241,7 @@ def main_fcn(a):
            "roofline": {"bound": "mfma", "kernel": "lm_fcn_forward[conv stack]", "achieved": tfl, "peak": peak, "unit": "TFLOP/s",
                         "frac": round(tfl / peak, 4), "traffic": None, "launch_ms": res["ms_per_frame"],
                         "algorithmic_tflops": res["algorithmic_tflops"],
-                        "note": "achieved counts executed MFMA flops (%d per algorithmic flop)" % (1 if fp32 else res["mfma_per_product"])},
+                        "note": "achieved counts executed MFMA flops (%s per algorithmic flop)" % (1 if fp32 else res["mfma_per_product"])},
            "cpu_baseline": res.get("cpu_baseline"), "fcn": res}
     print(json.dumps(out))
 

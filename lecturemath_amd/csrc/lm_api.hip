@@ -278,7 +278,8 @@ struct LmLabelSrc {
     const float* logits; float edge; unsigned flip; uint8_t* d_binary_out;
 };
 
-static int lm_label_launch(LmCtx* c, const LmLabelSrc& src, int f0, int n, int32_t* d_labels, hipStream_t st)
+// phase: 0 = the whole sequence, 1 = the row packing only, 2 = everything behind it
+static int lm_label_launch(LmCtx* c, const LmLabelSrc& src, int f0, int n, int32_t* d_labels, hipStream_t st, int phase = 0)
 {
     const uint8_t* d_binary = src.d_binary;
     const LmGeom g = c->g;
@@ -288,12 +289,15 @@ static int lm_label_launch(LmCtx* c, const LmLabelSrc& src, int f0, int n, int32
     const unsigned long long magic_ww = ((1ull << 40) / (unsigned)g.WW) + 1;
     const long long R = (long long)n * g.H;
     const size_t px = (size_t)g.W * g.H, r0 = (size_t)f0 * g.H, w0 = r0 * g.WW, b0 = (size_t)f0 * nbands, c0 = (size_t)f0 * g.cap, cw0 = (size_t)f0 * capw;
+    if (phase == 2) goto rest;
     if (src.logits)
         hipLaunchKernelGGL(lm_k_pack_rows_logits, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, src.logits + f0 * px, src.edge, src.flip,
                            src.d_binary_out ? src.d_binary_out + f0 * px : nullptr, c->bits + w0, c->starts + w0, c->prefix + w0, c->rowcnt + r0, g.W, g.WW, R);
     else
         hipLaunchKernelGGL(lm_k_pack_rows, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, d_binary + f0 * px, c->bits + w0, c->starts + w0, c->prefix + w0,
                            c->rowcnt + r0, g.W, g.WW, R);
+    if (phase == 1) { LM_HIP(hipGetLastError()); return LM_OK; }
+rest:
     static const int band_threads = [] { const char* e = getenv("LM_BAND_THREADS"); const int v = e ? atoi(e) : 512; return (v == 128 || v == 256 || v == 512) ? v : 512; }();
     hipLaunchKernelGGL(lm_k_band, dim3(nbands, n), dim3(band_threads), band_smem, st, c->bits + w0, c->starts + w0, c->prefix + w0, c->rowcnt + r0,
                        c->rowoff + r0, c->band_runs + b0, c->parent + c0, c->band_fallback + b0, g.H, g.WW, slot, g.cap, lm_debug_band_phases(), magic_ww,
@@ -353,15 +357,28 @@ static int lm_label_batch_src(LmCtx* c, const LmLabelSrc& src, int n_frames, int
         if (rc) return rc;
     } else {
         hipStream_t aux = (hipStream_t)c->aux_stream;
+        // Two parts are STAGGERED: the second part starts when the first has packed its rows, so its packing (bandwidth bound) runs under
+        // the first part's band / seam / numbering kernels (latency bound) and the first part's label writer under the second's middle.
+        // Started together the halves ran in step -- both packings, both middles, both writers -- and nothing overlapped.
+        static const int stagger = [] { const char* e = getenv("LM_LABEL_STAGGER"); return e ? atoi(e) : 0; }();
+        int rc = LM_OK;
+        const int n0 = n_frames / parts + (n_frames % parts ? 1 : 0);
+        const bool stag = stagger && parts == 2;
+        if (stag) rc = lm_label_launch(c, src, 0, n0, d_labels, st, 1);
+        if (rc) return rc;
         LM_HIP(hipEventRecord((hipEvent_t)c->ev_fork, st));
         LM_HIP(hipStreamWaitEvent(aux, (hipEvent_t)c->ev_fork, 0));
         // from here on the second queue holds work: whatever fails below, it is joined back into the caller's stream before the
         // call returns (both queues touch the context's tables and d_binary)
-        int rc = LM_OK;
-        for (int k = 0, f0 = 0; k < parts && rc == LM_OK; k++) {
-            const int n = n_frames / parts + (k < n_frames % parts ? 1 : 0);
-            rc = lm_label_launch(c, src, f0, n, d_labels, (k & 1) ? aux : st);
-            f0 += n;
+        if (stag) {
+            rc = lm_label_launch(c, src, n0, n_frames - n0, d_labels, aux, 0);
+            if (rc == LM_OK) rc = lm_label_launch(c, src, 0, n0, d_labels, st, 2);
+        } else {
+            for (int k = 0, f0 = 0; k < parts && rc == LM_OK; k++) {
+                const int n = n_frames / parts + (k < n_frames % parts ? 1 : 0);
+                rc = lm_label_launch(c, src, f0, n, d_labels, (k & 1) ? aux : st);
+                f0 += n;
+            }
         }
         const hipError_t e1 = hipEventRecord((hipEvent_t)c->ev_join, aux);
         const hipError_t e2 = (e1 == hipSuccess) ? hipStreamWaitEvent(st, (hipEvent_t)c->ev_join, 0) : e1;

@@ -242,7 +242,25 @@ class FcnEngine:
                                                       bias.ctypes.data, bias.size))
             self.recipes[layer] = {"kh": int(desc[0]), "kw": int(desc[1]), "terms": int(desc[2]), "mt": int(desc[3]), "chunks": int(desc[5]),
                                    "planes_per_chunk": int(desc[6]), "groups": int(desc[7]), "slices": int(desc[8]), "patterns": int(desc[9]),
-                                   "lds_bytes": int(need)}
+                                   "lds_bytes": int(need), "cout": int(desc[12]), "epilogue": int(desc[4]), "first_tensor": int(desc[13])}
+
+    def executed_gflop(self, h, w):
+        """MFMA flops the planar engine EXECUTES for one h x w frame (whole 16 x 16 tiles, whole 32-deep slices, three products per
+        operand pair in the split-format layers), as opposed to the network's algorithmic flops"""
+        from . import fcn2 as f2
+        level_of = {f2.T_X0P: 0, f2.T_MID: 5, f2.T_XUP: 0, f2.T_DP: 0, f2.T_P1: 0, f2.T_P2: 0}
+        for n in range(5):
+            level_of[f2.T_PRE0 + n] = n
+            level_of[f2.T_POOL0 + n] = n + 1
+            level_of[f2.T_UPT0 + n] = 4 - n
+        for n in range(4):
+            level_of[f2.T_CU0 + n] = 4 - n
+        total = 0.0
+        for r in self.recipes.values():
+            lv = level_of[r["first_tensor"]]
+            tiles = (((h >> lv) + 15) // 16) * (((w >> lv) + 15) // 16)
+            total += 2.0 * tiles * 256 * r["cout"] * r["slices"] * 32 * r["terms"] * (4 if r["epilogue"] == f2.EPI_TC else 1)
+        return total / 1e9
 
     def load_state_dict(self, sd):
         if self.planar:

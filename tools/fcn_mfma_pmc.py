@@ -18,7 +18,7 @@ for v in d.values():
 tot_b = tot_g = 0.0
 for name, a in agg.items():
     a["mfma_util"] = round(a["mfma_busy_cycles"] / (1024.0 * a["gui_active"] / 8.0), 4) if a["gui_active"] else 0.0
-    if "mfma" in name:
+    if "mfma" in name or "lm_k_g2" in name:
         tot_b += a["mfma_busy_cycles"]
         tot_g += a["gui_active"]
 out = {"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -- python3 bench.py --workload fcn --steps 2 --warmup 1",
