@@ -62,7 +62,9 @@ LM_DEV void lm_vmwait(int n)
 
 #define LM_G2_EPI_PO 0      // planar-octet output (+ optional lo planes, + optional 2x2 max-pooled copy), GELU or none
 #define LM_G2_EPI_T 1       // fp32 [pixel][TS] rows of the head row convolutions (lm_k_vsum2_*), no activation
-#define LM_G2_EPI_TC 2      // transposed 2x2 / stride 2: blockIdx.z = dy * 2 + dx, output pixel (2y + dy, 2x + dx), planar octets
+#define LM_G2_EPI_TC 2      // transposed 2x2 / stride 2, one (dy, dx) parity per workgroup: output pixel (2y + dy, 2x + dx), planar octets
+#define LM_G2_EPI_TC2 3     // the same with BOTH dx of a 32-channel block in one workgroup (tile pair 0 = dx 0, pair 1 = dx 1): a lane writes the
+                            // two neighbouring output slots (32 contiguous bytes) instead of 16 bytes at a 32-byte stride; kernel template EPI_TC
 
 struct LmG2Args {
     const char* arena;              // base of the engine's activation arena
@@ -82,6 +84,7 @@ struct LmG2Args {
     int tiles_x, tiles_y, cblocks;  // pixel tiles, channel blocks of MT * 16 outputs
     int H, W;                       // output grid of this launch (bounds of the stores; the input grid for EPI_TC)
     int act;                        // LM_ACT_GELU or LM_ACT_NONE
+    int tc_merged;                  // EPI_TC: 1 = LM_G2_EPI_TC2 (parity = dy, tile pair q = dx)
     // EPI_PO / EPI_TC output tensor
     char* out_hi; char* out_lo;     // plane 0 of the hi / lo parts (lo may be null)
     long long out_plane;            // bytes per plane
@@ -289,15 +292,17 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a, const long l
             }
         }
     } else {
-        const int cb = cby * (MT * 16);                  // first channel of the workgroup
+        const bool merged = (EPI == LM_G2_EPI_TC) && a.tc_merged;
+        const int cb = merged ? cby * 32 : cby * (MT * 16);                  // first channel of the workgroup
         const bool gelu = a.act == LM_ACT_GELU;
-        const int dy = par >> 1, dx = par & 1;
+        const int dy = merged ? par : (par >> 1), dx = par & 1;
         const int sc = (EPI == LM_G2_EPI_TC) ? 2 : 1;
         // pairs of tiles: the host packs tile 2q with the channels 32q + 8kg + (0..3) in rows 4kg + (0..3) and tile 2q + 1 with
         // 32q + 8kg + 4 + (0..3), so a lane holds one whole octet of its pixel: one 16-byte store per part
 #pragma unroll
         for (int q = 0; q < MT / 2; q++) {
-            const int ch = cb + 32 * q + 8 * kg;
+            const int ch = cb + (merged ? 0 : 32 * q) + 8 * kg;
+            const int dxq = merged ? q : dx;
             const float4 b0 = *(const float4*)(t_bias + ch), b1 = *(const float4*)(t_bias + ch + 4);
             const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
             const long long oplane = (long long)(ch >> 3) * a.out_plane;
@@ -316,7 +321,7 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a, const long l
                 lm_h8 hi, lo;
 #pragma unroll
                 for (int j = 0; j < 8; j++) { hi[j] = (_Float16)v[n][j]; lo[j] = (_Float16)(v[n][j] - (float)hi[j]); }
-                const long long so = oplane + ((long long)(sc * y + dy + a.halo_out) * a.Wp_out + sc * x + dx + a.halo_out) * 16;
+                const long long so = oplane + ((long long)(sc * y + dy + a.halo_out) * a.Wp_out + sc * x + dxq + a.halo_out) * 16;
                 *(lm_h8*)(a.out_hi + so) = hi;
                 if (a.out_lo) *(lm_h8*)(a.out_lo + so) = lo;
             }
@@ -341,47 +346,56 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a, const long l
                 }
             }
         }
-        if constexpr (MT & 1) {         // the unpaired last tile: channels in row order, a lane holds half an octet (8-byte stores)
+        if constexpr (MT & 1) {
+            // The unpaired last tile: channels in row order, so a lane holds HALF an octet (4 channels of its pixel) and its partner lane
+            // ^ 16 the other half.  They swap halves (one shuffle per value) and both assemble the whole octet; the even k-group's lane
+            // stores the hi parts, the odd one the lo parts -- 16-byte stores of whole slots instead of 8-byte halves at a 16-byte stride.
             constexpr int m = MT - 1;
             const int ch = cb + 16 * m + 4 * kg;
             const float4 b0 = *(const float4*)(t_bias + ch);
             const float bb[4] = {b0.x, b0.y, b0.z, b0.w};
-            const long long oplane = (long long)(ch >> 3) * a.out_plane + (kg & 1) * 8;
-            float v[NT][4];
+            const bool oddg = kg & 1;
+            const long long oplane = (long long)((cb + 16 * m) / 8 + (kg >> 1)) * a.out_plane;
+            float v[NT][8];
 #pragma unroll
-            for (int n = 0; n < NT; n++)
+            for (int n = 0; n < NT; n++) {
+                float own[4], oth[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const float t = acc[m][n][j] + bb[j];
-                    v[n][j] = gelu ? lm_gelu(t) : t;
+                    own[j] = gelu ? lm_gelu(t) : t;
+                    oth[j] = __shfl_xor(own[j], 16);
                 }
+#pragma unroll
+                for (int j = 0; j < 4; j++) { v[n][j] = oddg ? oth[j] : own[j]; v[n][4 + j] = oddg ? own[j] : oth[j]; }
+            }
 #pragma unroll
             for (int n = 0; n < NT; n++) {
                 const int y = y0 + n;
                 if (y >= a.H || x >= a.W) continue;
-                lm_h4 hi, lo;
+                lm_h8 hi, lo;
 #pragma unroll
-                for (int j = 0; j < 4; j++) { hi[j] = (_Float16)v[n][j]; lo[j] = (_Float16)(v[n][j] - (float)hi[j]); }
+                for (int j = 0; j < 8; j++) { hi[j] = (_Float16)v[n][j]; lo[j] = (_Float16)(v[n][j] - (float)hi[j]); }
                 const long long so = oplane + ((long long)(sc * y + dy + a.halo_out) * a.Wp_out + sc * x + dx + a.halo_out) * 16;
-                *(lm_h4*)(a.out_hi + so) = hi;
-                if (a.out_lo) *(lm_h4*)(a.out_lo + so) = lo;
+                if (!oddg) *(lm_h8*)(a.out_hi + so) = hi;
+                else if (a.out_lo) *(lm_h8*)(a.out_lo + so) = lo;
             }
             if constexpr (EPI == LM_G2_EPI_PO) {
                 if (a.pool_hi) {
 #pragma unroll
                     for (int n = 0; n < NT; n += 2) {
-                        lm_h4 ph, pl;
+                        lm_h8 ph, pl;
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
+                        for (int j = 0; j < 8; j++) {
                             const float m2 = fmaxf(v[n][j], v[n + 1][j]);
                             const float m4 = fmaxf(m2, __shfl_xor(m2, 1));
                             ph[j] = (_Float16)m4; pl[j] = (_Float16)(m4 - (float)ph[j]);
                         }
                         const int py = (y0 + n) >> 1, px = x >> 1;
                         if (!(col & 1) && py < (a.H >> 1) && px < (a.W >> 1)) {
-                            const long long so = (long long)(ch >> 3) * a.pool_plane + (kg & 1) * 8 + ((long long)(py + a.halo_pool) * a.Wp_pool + px + a.halo_pool) * 16;
-                            *(lm_h4*)(a.pool_hi + so) = ph;
-                            if (a.pool_lo) *(lm_h4*)(a.pool_lo + so) = pl;
+                            const long long so = (long long)((cb + 16 * m) / 8 + (kg >> 1)) * a.pool_plane + ((long long)(py + a.halo_pool) * a.Wp_pool + px + a.halo_pool) * 16;
+                            if (!oddg) *(lm_h8*)(a.pool_hi + so) = ph;
+                            else if (a.pool_lo) *(lm_h8*)(a.pool_lo + so) = pl;
                         }
                     }
                 }
@@ -662,7 +676,8 @@ static int lm_g2_launch(const LmF2Layer& l, const LmG2Args& a, dim3 grid, size_t
         if (l.mt == 2) return lm_g2_launch_terms<3, 3, LM_G2_EPI_PO, 2>(l.terms, a, grid, smem, st);
         if (l.mt == 3) return lm_g2_launch_terms<3, 3, LM_G2_EPI_PO, 3>(l.terms, a, grid, smem, st);
         if (l.mt == 4) return lm_g2_launch_terms<3, 3, LM_G2_EPI_PO, 4>(l.terms, a, grid, smem, st);
-    } else if (shape == 11 && l.epi == LM_G2_EPI_TC) {
+    } else if (shape == 11 && (l.epi == LM_G2_EPI_TC || l.epi == LM_G2_EPI_TC2)) {
+        if (l.epi == LM_G2_EPI_TC2 && l.mt != 4) { lm_set_error("lm_fcn2: the merged transposed convolution runs four channel tiles per workgroup"); return LM_ERR_ARG; }
         if (l.mt == 1) return lm_g2_launch_terms<1, 1, LM_G2_EPI_TC, 1>(l.terms, a, grid, smem, st);
         if (l.mt == 2) return lm_g2_launch_terms<1, 1, LM_G2_EPI_TC, 2>(l.terms, a, grid, smem, st);
         if (l.mt == 3) return lm_g2_launch_terms<1, 1, LM_G2_EPI_TC, 3>(l.terms, a, grid, smem, st);
@@ -695,7 +710,7 @@ static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor*
     if (out) {
         a.out_hi = f->arena + out->off; a.out_lo = out->lo ? a.out_hi + (long long)out->c8 * out->plane : nullptr;
         a.out_plane = out->plane; a.Wp_out = out->Wp; a.halo_out = out->halo;
-        if (l.cout != out->c8 * 8) { lm_set_error("lm_fcn2_forward: layer %d has %d outputs for a tensor of %d channels", li, l.cout, out->c8 * 8); return LM_ERR_STATE; }
+        if (l.cout != out->c8 * 8 * (l.epi == LM_G2_EPI_TC2 ? 2 : 1)) { lm_set_error("lm_fcn2_forward: layer %d has %d outputs for a tensor of %d channels", li, l.cout, out->c8 * 8); return LM_ERR_STATE; }
     }
     if (pool) { a.pool_hi = f->arena + pool->off; a.pool_lo = pool->lo ? a.pool_hi + (long long)pool->c8 * pool->plane : nullptr; a.pool_plane = pool->plane; a.Wp_pool = pool->Wp; a.halo_pool = pool->halo; }
     a.tout = tout; a.ts = ts; a.tn = tn;
@@ -715,7 +730,8 @@ static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor*
     const int blocks = l.cout / (16 * l.mt);
     if (blocks * 16 * l.mt != l.cout) { lm_set_error("lm_fcn2_forward: layer %d: %d outputs are not whole blocks of %d tiles", li, l.cout, l.mt); return LM_ERR_STATE; }
     a.cblocks = blocks;
-    return lm_g2_launch(l, a, dim3((unsigned)tiles * blocks * (l.epi == LM_G2_EPI_TC ? 4 : 1)), smem, st);
+    a.tc_merged = l.epi == LM_G2_EPI_TC2 ? 1 : 0;
+    return lm_g2_launch(l, a, dim3((unsigned)tiles * blocks * (l.epi == LM_G2_EPI_TC ? 4 : (l.epi == LM_G2_EPI_TC2 ? 2 : 1))), smem, st);
 }
 
 extern "C" int lm_fcn2_forward(LmFcn2* f, const uint8_t* d_rgb, int h, int w, float* d_out, float* d_text, float* d_rec, void* stream)

@@ -204,10 +204,19 @@ class FcnEngine:
             bt = _np(sd["transposed_conv_%d.bias" % lvl]).astype(np.float32)
             wt, bt = fold_bn(wt, bt, sd, "upsample_block_%d.0" % lvl, 1)
             src = f2.T_MID if i == 0 else f2.T_CU0 + i - 1
-            w4 = [np.ascontiguousarray(wt[:, :, dy, dx].T)[:, :, None, None] for dy in (0, 1) for dx in (0, 1)]
-            co = 4 if (tin // 8) % 4 == 0 else 2
-            chunks = f2.conv_chunks([(src, tin // 8)], 1, 1, co)
-            recipes[L_UPT + i] = (f2.build(w4, chunks, 1, 1, T(L_UPT + i), f2.pick_mt(u, tiles(lvl)), f2.EPI_TC), bt)
+            n8 = tin // 8
+            co = 8 if n8 % 8 == 0 else (4 if n8 % 4 == 0 else 2)
+            chunks = f2.conv_chunks([(src, n8)], 1, 1, co)
+            if u % 32 == 0:
+                # both dx of a 32-channel block in one workgroup: per dy a virtual output axis [block][dx][32 channels]
+                w2 = []
+                for dy in (0, 1):
+                    wd = [np.ascontiguousarray(wt[:, :, dy, dx].T) for dx in (0, 1)]             # [u][tin]
+                    w2.append(np.concatenate([wd[dx][b * 32:(b + 1) * 32] for b in range(u // 32) for dx in (0, 1)])[:, :, None, None])
+                recipes[L_UPT + i] = (f2.build(w2, chunks, 1, 1, T(L_UPT + i), 4, f2.EPI_TC2), bt)
+            else:
+                w4 = [np.ascontiguousarray(wt[:, :, dy, dx].T)[:, :, None, None] for dy in (0, 1) for dx in (0, 1)]
+                recipes[L_UPT + i] = (f2.build(w4, chunks, 1, 1, T(L_UPT + i), f2.pick_mt(u, tiles(lvl)), f2.EPI_TC), bt)
             w, b = conv_bn("conv_up_block_%d" % lvl)                                      # input = cat(up, skip_pre)
             recipes[L_UPC + i] = (f2.conv_layer(w, [(f2.T_UPT0 + i, u // 8), (f2.T_PRE0 + lvl - 1, skip // 8)], T(L_UPC + i), tiles(lvl - 1)), b)
         # heads
@@ -259,7 +268,7 @@ class FcnEngine:
         for r in self.recipes.values():
             lv = level_of[r["first_tensor"]]
             tiles = (((h >> lv) + 15) // 16) * (((w >> lv) + 15) // 16)
-            total += 2.0 * tiles * 256 * r["cout"] * r["slices"] * 32 * r["terms"] * (4 if r["epilogue"] == f2.EPI_TC else 1)
+            total += 2.0 * tiles * 256 * r["cout"] * r["slices"] * 32 * r["terms"] * (4 if r["epilogue"] == f2.EPI_TC else (2 if r["epilogue"] == f2.EPI_TC2 else 1))
         return total / 1e9
 
     def load_state_dict(self, sd):

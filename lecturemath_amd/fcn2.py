@@ -10,7 +10,7 @@ fetched as weight GROUPS.  A pair plane (network input, diff) holds {c0 c1 c2 0 
 """
 import numpy as np
 
-EPI_PO, EPI_T, EPI_TC = 0, 1, 2
+EPI_PO, EPI_T, EPI_TC, EPI_TC2 = 0, 1, 2, 3
 T_X0P, T_PRE0, T_POOL0, T_MID, T_UPT0, T_CU0, T_XUP, T_DP, T_P1, T_P2, N_TENSORS = 0, 1, 6, 11, 12, 17, 21, 22, 23, 24, 25
 LDS_TWO_WORKGROUPS = 80 * 1024        # a workgroup's LDS for two of them to share a CU's 160 KB
 

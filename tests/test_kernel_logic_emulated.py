@@ -156,7 +156,7 @@ def test_fcn_golden_tiny(emu_lib, precision):
     assert lm_checks.check_fcn_golden(emu_lib, "k7_70x94", precision=precision) < 1e-4
 
 
-PLANAR_TINY_WIDTHS = (16, 32, 16, 16, 16, 32, 16, 16, 16, 16, 16, 16, 16, 48, 16, 32, 32, 16)       # channel blocks of 1, 2 and 3 tiles
+PLANAR_TINY_WIDTHS = (16, 32, 16, 16, 16, 32, 32, 16, 16, 16, 16, 16, 16, 48, 16, 32, 32, 16)       # channel blocks of 1, 2 and 3 tiles; one merged-dx transposed conv
 
 
 @pytest.mark.parametrize("precision,tol", [("mixed", 1e-4), ("planar-f16x3", 1e-5)])
