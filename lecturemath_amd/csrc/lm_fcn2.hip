@@ -346,56 +346,48 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a, const long l
                 }
             }
         }
-        if constexpr (MT & 1) {
-            // The unpaired last tile: channels in row order, so a lane holds HALF an octet (4 channels of its pixel) and its partner lane
-            // ^ 16 the other half.  They swap halves (one shuffle per value) and both assemble the whole octet; the even k-group's lane
-            // stores the hi parts, the odd one the lo parts -- 16-byte stores of whole slots instead of 8-byte halves at a 16-byte stride.
+        if constexpr (MT & 1) {         // the unpaired last tile: channels in row order, a lane holds half an octet (8-byte stores).  Measured: swapping
+                                        // halves with the partner lane (^ 16) for whole-slot stores cost more in shuffles than it saved (+5..15 % on the MT = 3 layers)
             constexpr int m = MT - 1;
             const int ch = cb + 16 * m + 4 * kg;
             const float4 b0 = *(const float4*)(t_bias + ch);
             const float bb[4] = {b0.x, b0.y, b0.z, b0.w};
-            const bool oddg = kg & 1;
-            const long long oplane = (long long)((cb + 16 * m) / 8 + (kg >> 1)) * a.out_plane;
-            float v[NT][8];
+            const long long oplane = (long long)(ch >> 3) * a.out_plane + (kg & 1) * 8;
+            float v[NT][4];
 #pragma unroll
-            for (int n = 0; n < NT; n++) {
-                float own[4], oth[4];
+            for (int n = 0; n < NT; n++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const float t = acc[m][n][j] + bb[j];
-                    own[j] = gelu ? lm_gelu(t) : t;
-                    oth[j] = __shfl_xor(own[j], 16);
+                    v[n][j] = gelu ? lm_gelu(t) : t;
                 }
-#pragma unroll
-                for (int j = 0; j < 4; j++) { v[n][j] = oddg ? oth[j] : own[j]; v[n][4 + j] = oddg ? own[j] : oth[j]; }
-            }
 #pragma unroll
             for (int n = 0; n < NT; n++) {
                 const int y = y0 + n;
                 if (y >= a.H || x >= a.W) continue;
-                lm_h8 hi, lo;
+                lm_h4 hi, lo;
 #pragma unroll
-                for (int j = 0; j < 8; j++) { hi[j] = (_Float16)v[n][j]; lo[j] = (_Float16)(v[n][j] - (float)hi[j]); }
+                for (int j = 0; j < 4; j++) { hi[j] = (_Float16)v[n][j]; lo[j] = (_Float16)(v[n][j] - (float)hi[j]); }
                 const long long so = oplane + ((long long)(sc * y + dy + a.halo_out) * a.Wp_out + sc * x + dx + a.halo_out) * 16;
-                if (!oddg) *(lm_h8*)(a.out_hi + so) = hi;
-                else if (a.out_lo) *(lm_h8*)(a.out_lo + so) = lo;
+                *(lm_h4*)(a.out_hi + so) = hi;
+                if (a.out_lo) *(lm_h4*)(a.out_lo + so) = lo;
             }
             if constexpr (EPI == LM_G2_EPI_PO) {
                 if (a.pool_hi) {
 #pragma unroll
                     for (int n = 0; n < NT; n += 2) {
-                        lm_h8 ph, pl;
+                        lm_h4 ph, pl;
 #pragma unroll
-                        for (int j = 0; j < 8; j++) {
+                        for (int j = 0; j < 4; j++) {
                             const float m2 = fmaxf(v[n][j], v[n + 1][j]);
                             const float m4 = fmaxf(m2, __shfl_xor(m2, 1));
                             ph[j] = (_Float16)m4; pl[j] = (_Float16)(m4 - (float)ph[j]);
                         }
                         const int py = (y0 + n) >> 1, px = x >> 1;
                         if (!(col & 1) && py < (a.H >> 1) && px < (a.W >> 1)) {
-                            const long long so = (long long)((cb + 16 * m) / 8 + (kg >> 1)) * a.pool_plane + ((long long)(py + a.halo_pool) * a.Wp_pool + px + a.halo_pool) * 16;
-                            if (!oddg) *(lm_h8*)(a.pool_hi + so) = ph;
-                            else if (a.pool_lo) *(lm_h8*)(a.pool_lo + so) = pl;
+                            const long long so = (long long)(ch >> 3) * a.pool_plane + (kg & 1) * 8 + ((long long)(py + a.halo_pool) * a.Wp_pool + px + a.halo_pool) * 16;
+                            *(lm_h4*)(a.pool_hi + so) = ph;
+                            if (a.pool_lo) *(lm_h4*)(a.pool_lo + so) = pl;
                         }
                     }
                 }
