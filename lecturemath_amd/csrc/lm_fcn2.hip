@@ -253,10 +253,12 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a, const long l
                 const uint2 d2 = dsc[sl + 2];
                 const int p2 = pat(d2);
                 load(dn, pn, sl + 1, f1);
-                mma(f0);
+                LM_SCHED_BARRIER();         // the requests stay IN FRONT of the MFMAs they hide behind (left alone, the scheduler sank them to the
+                mma(f0);                    // end of the MFMA block, right before the wait for them)
                 dn = dsc[sl + 3];
                 pn = pat(dn);
                 if (sl + 2 < ns) load(d2, p2, sl + 2, f0);
+                LM_SCHED_BARRIER();
                 mma(f1);
             }
             if (sl < ns) mma(f0);
