@@ -50,10 +50,11 @@ def broadcast_state_dict(sd, src=0, device_name=None):
     return out
 
 
-def gather_blocks(buf, dst=0, be=None):
+def gather_blocks(buf, dst=0, be=None, failed=False):
     """Every rank passes its packed block (flat uint8 buffer on the device; numpy with the emulated library).  Rank `dst`
     returns the list of all ranks' blocks in rank order (its own block is not copied), the others return None.  Sizes travel
-    in one all_gather, payloads point to point (send / recv) -- device to device over RCCL."""
+    in one all_gather, payloads point to point (send / recv) -- device to device over RCCL.  A rank whose local work failed
+    passes failed=True (any small buffer): it still takes part in the size exchange, and every rank raises after it."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -63,7 +64,10 @@ def gather_blocks(buf, dst=0, be=None):
     if on_device and not nccl:
         t = t.cpu()                                   # gloo rehearsal on a GPU box: stage through the host
     sizes = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([t.numel()], dtype=torch.int64, device=t.device))
+    dist.all_gather(sizes, torch.tensor([-1 if failed else t.numel()], dtype=torch.int64, device=t.device))
+    bad = [r for r in range(world) if int(sizes[r].item()) < 0]
+    if bad:         # every rank learns it in the same collective: nobody is left waiting in a send / recv
+        raise RuntimeError("rank(s) %s failed before the gather of their block" % bad)
     if rank != dst:
         dist.send(t, dst=dst)
         return None
@@ -100,16 +104,24 @@ def run_stream_sharded(my_frames_dev, n_frames_total, width, height, min_recall=
     fs = device.FrameStream(width, height, n_frames_total if full else max(n, 1), min_recall, min_precision, max_gap, min_pixels,
                             max_batch=max_batch, max_ccs=max_ccs, max_crop_words=max_crop_words, lib=lib)
     try:
-        if n:
-            if full:
-                fs.push(my_frames_dev)            # rank 0 matches its own block while the others still label theirs
-            else:
-                fs.push_records(my_frames_dev)
-        block = fs.pack(0, n) if not full else None
-        if full:
-            blocks = gather_blocks(fs.be.empty((32,), np.uint8), dst=0, be=fs.be)
-        else:
-            gather_blocks(block, dst=0, be=fs.be)
+        block, err = None, None
+        try:
+            if n:
+                if full:
+                    fs.push(my_frames_dev)            # rank 0 matches its own block while the others still label theirs
+                else:
+                    fs.push_records(my_frames_dev)
+            block = fs.pack(0, n) if not full else None
+        except Exception as e:                    # a capacity error, a bad block: the other ranks must not wait for this one
+            err = e
+        dummy = fs.be.empty((32,), np.uint8)
+        try:
+            blocks = gather_blocks(dummy if (full or err is not None) else block, dst=0, be=fs.be, failed=err is not None)
+        except RuntimeError:
+            if err is not None:
+                raise err
+            raise
+        if not full:
             return None
         for r in range(1, world):
             fs.append_packed(blocks[r])
@@ -215,6 +227,7 @@ class ShardedStream:
         self.gs = make(n_frames) if (self.rank == self.group_rank and self.rank != 0) else None
         self.lib, self.be = self.fs.lib, self.fs.be
         self.wire = _Wire(self.be) if self.world > 1 else None
+        self.failed = False
 
     def close(self):
         for s in (self.fs, self.gs):
@@ -229,6 +242,8 @@ class ShardedStream:
         fs, lib = self.fs, self.lib
         ws = self.be.stream() if stream_wide is None else stream_wide
         ms = ws if stream_match is None else stream_match
+        if self.failed:
+            raise RuntimeError("this ShardedStream failed in an earlier step")
         if self.wire:
             self.wire.drain()                   # the previous step's sends
         fs.reset()
@@ -245,6 +260,7 @@ class ShardedStream:
             if self.rank != 0:
                 for _ in range(len(mine) - k):
                     self.wire.send(None, 0, failed=True)
+                self.failed = True              # rank 0 stops receiving at the first failure header: the rest is never waited for
             raise
         if self.rank == 0:
             if ms != ws:
@@ -275,5 +291,5 @@ class ShardedStream:
             t.cuda.ExternalStream(main).wait_event(ev)
 
     def finish(self):
-        if self.wire:
+        if self.wire and not self.failed:
             self.wire.drain()

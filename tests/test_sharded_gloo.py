@@ -89,3 +89,47 @@ def test_frame_range():
 def test_sharded_stream_two_ranks(emu_lib, oracle_built, tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), emu_lib.path, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok").exists() and (tmp_path / "ok_pipelined_0").exists() and (tmp_path / "ok_pipelined_1").exists()
+
+
+def _failing_worker(rank, world, port, emu_path, out_dir):
+    """rank 1 fails in its share of the work: nobody may be left waiting (the gather used to hang rank 0)"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lecturemath_amd import _lib, sharded, synth
+    lib = _lib.load(emu_path)
+    # (1) the one-transfer gather: the failing rank still takes part in the size exchange, every rank raises
+    raised = False
+    try:
+        sharded.gather_blocks(np.zeros(32, np.uint8), dst=0, failed=(rank == 1))
+    except RuntimeError as e:
+        raised = "failed before the gather" in str(e)
+    assert raised
+    # (2) the pipelined form: rank 1's producer raises on its second piece; rank 0 sees the failure header instead of a payload
+    frames = np.stack(list(synth.binary_stream(12, 96, 160, seed=8, glyphs_per_add=4, max_ext=16)))
+    logits = synth.logits_from_binary(frames, seed=2)
+    f0, f1 = sharded.frame_range(len(frames), rank, world)
+    sh = sharded.ShardedStream(160, 96, len(frames), 4, lib=lib, pieces=3, max_gap=5)
+    calls = [0]
+
+    def produce(a, b):
+        calls[0] += 1
+        if rank == 1 and calls[0] == 2:
+            raise ValueError("frame source broke")
+        return np.ascontiguousarray(logits[f0 + a:f0 + b])
+    try:
+        sh.step(produce)
+        outcome = "returned"
+    except ValueError:
+        outcome = "producer error"
+    except RuntimeError as e:
+        outcome = "peer failure" if "reported a failure" in str(e) else "other: %s" % e
+    assert outcome == ("peer failure" if rank == 0 else "producer error"), outcome
+    sh.finish()
+    open(os.path.join(out_dir, "failed_ok_%d" % rank), "w").write(outcome)
+    dist.destroy_process_group()
+
+
+def test_sharded_failure_does_not_hang(emu_lib, tmp_path):
+    mp.spawn(_failing_worker, args=(2, _free_port(), emu_lib.path, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "failed_ok_0").exists() and (tmp_path / "failed_ok_1").exists()
