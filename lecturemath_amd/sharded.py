@@ -207,7 +207,7 @@ class ShardedStream:
       * the matched stream (records + crops + assignment) goes to `group_rank` (rank 1 when there is one), which runs step 03 and the
         reconstruction while the other ranks are already in the next step.
     step() returns the matched whole-stream FrameStream on group_rank and None elsewhere.  A rank that fails sends a failure header
-    for its remaining pieces, so rank 0 raises instead of waiting for ever."""
+    in place of the piece it could not produce, so rank 0 raises instead of waiting for ever."""
 
     def __init__(self, width, height, n_frames, batch, lib=None, pieces=4, min_recall=0.85, min_precision=0.85, max_gap=85, min_pixels=20,
                  max_ccs_per_frame=4096, max_words_per_frame=None, group_on_second_rank=True):
@@ -258,9 +258,11 @@ class ShardedStream:
                     self.wire.send(fs.pack(a, b - a), 0)
         except Exception:
             if self.rank != 0:
-                for _ in range(len(mine) - k):
-                    self.wire.send(None, 0, failed=True)
-                self.failed = True              # rank 0 stops receiving at the first failure header: the rest is never waited for
+                # ONE failure header in place of the piece that could not be produced: rank 0 receives the pieces sent so far, then the
+                # header, and raises there; waiting for exactly these sends keeps the connection up until it has seen them
+                self.wire.send(None, 0, failed=True)
+                self.wire.drain()
+                self.failed = True
             raise
         if self.rank == 0:
             if ms != ws:
