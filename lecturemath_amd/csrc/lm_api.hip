@@ -148,7 +148,7 @@ extern "C" void lm_ctx_destroy(LmCtx* c)
     if (!c) return;
     lm_profile_free(c);
     void* ptrs[] = {c->bits, c->starts, c->prefix, c->rowoff, c->rowcnt, c->band_runs, c->band_base, c->band_roots, c->band_fallback, c->parent, c->final_label,
-                    c->n_labels, c->rootbits, c->wordprefix, c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x, c->st_count, c->kept_label,
+                    c->n_labels, c->rootbits, c->wordprefix, c->mid_sync, c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x, c->st_count, c->kept_label,
                     c->kept_cropoff, c->frame_kept, c->frame_cropwords, c->stage_u8, c->stage_i32, c->stage_f32};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -200,6 +200,7 @@ extern "C" LmCtx* lm_ctx_create(int width, int height, int max_batch)
     rc |= lm_alloc(&c->kept_cropoff, BC);
     rc |= lm_alloc(&c->frame_kept, (size_t)max_batch);
     rc |= lm_alloc(&c->frame_cropwords, (size_t)max_batch);
+    rc |= lm_alloc(&c->mid_sync, 2 * (1 + 2 * (size_t)max_batch));
     if (rc != LM_OK) {
         lm_ctx_destroy(c);
         return nullptr;
@@ -302,12 +303,25 @@ rest:
     hipLaunchKernelGGL(lm_k_band, dim3(nbands, n), dim3(band_threads), band_smem, st, c->bits + w0, c->starts + w0, c->prefix + w0, c->rowcnt + r0,
                        c->rowoff + r0, c->band_runs + b0, c->parent + c0, c->band_fallback + b0, g.H, g.WW, slot, g.cap, lm_debug_band_phases(), magic_ww,
                        c->band_rows, f0 == 0 ? lm_debug_band_stamps(nbands, n) : nullptr);
+    static const int fused_middle = [] { const char* e = getenv("LM_LABEL_FUSED_MIDDLE"); return e ? atoi(e) : LM_LABEL_FUSED_MIDDLE_DEFAULT; }();
+#if !LM_HIP_EMULATED
+    if (fused_middle) {
+        // seam unions, flatten + flags, numbering in one launch with two per-frame rendezvous (lm_k_middle); one counter set per queue
+        unsigned* sync = c->mid_sync + (size_t)(f0 ? 1 : 0) * (1 + 2 * (size_t)c->max_batch);
+        LM_HIP(hipMemsetAsync(sync, 0, (1 + 2 * (size_t)n) * sizeof(unsigned), st));
+        hipLaunchKernelGGL(lm_k_middle, dim3((unsigned)nbands * n), dim3(256), 0, st, c->bits + w0, c->starts + w0, c->prefix + w0, c->rowoff + r0,
+                           c->band_fallback + b0, c->parent + c0, c->band_runs + b0, c->rootbits + cw0, c->wordprefix + cw0, c->band_roots + b0,
+                           c->band_base + b0, c->n_labels + f0, c->final_label + c0, g.WW, g.H, g.cap, c->band_rows, slot, capw, nbands, sync, 0u, 0u);
+    } else
+#endif
+    {
     hipLaunchKernelGGL(lm_k_seam_union, dim3(nbands, n), dim3(256), 0, st, c->bits + w0, c->starts + w0, c->prefix + w0, c->rowoff + r0,
                        c->band_fallback + b0, c->parent + c0, g.WW, g.H, g.cap, c->band_rows);
     hipLaunchKernelGGL(lm_k_flatten_flag, dim3(nbands, n), dim3(256), 0, st, c->parent + c0, c->band_runs + b0, c->rootbits + cw0, c->wordprefix + cw0,
                        c->band_roots + b0, slot, g.cap, capw);
     hipLaunchKernelGGL(lm_k_apply_labels, dim3(nbands, n), dim3(256), 0, st, c->parent + c0, c->band_runs + b0, c->rootbits + cw0, c->wordprefix + cw0,
                        c->band_roots + b0, c->band_base + b0, c->n_labels + f0, c->final_label + c0, slot, g.cap, capw);
+    }
     if (d_labels) {
         const unsigned Q = (unsigned)(g.W + 3) / 4;
         const unsigned long long magic_q = ((1ull << 40) / Q) + 1;       // lm_fastdiv: exact for H * Q < 2^24

@@ -485,12 +485,10 @@ __global__ void __launch_bounds__(512) lm_k_band(const uint64_t* __restrict__ bi
 
 // K4b: seam rows between bands (device-scope atomics in L2), and -- for the rare bands whose forest did not fit the LDS
 // (very dense frames) -- all of the band's own contacts as well.  One block per (band, frame).
-__global__ void __launch_bounds__(256) lm_k_seam_union(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
-                                                       const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
-                                                       const uint8_t* __restrict__ band_fallback, int32_t* __restrict__ parent,
-                                                       int WW, int H, int cap, int brows)
+LM_DEV void lm_seam_body(int b, int band, int nbands, const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
+                         const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
+                         const uint8_t* __restrict__ band_fallback, int32_t* __restrict__ parent, int WW, int H, int cap, int brows)
 {
-    const int b = blockIdx.y, band = blockIdx.x;
     const int y0 = band * brows;
     const int y1 = (y0 + brows < H) ? y0 + brows : H;
     const long long row0 = (long long)b * H + y0;
@@ -511,11 +509,19 @@ __global__ void __launch_bounds__(256) lm_k_seam_union(const uint64_t* __restric
     __syncthreads();
     const int ncontact = s_ncontact < LM_SEAM_CAP ? s_ncontact : LM_SEAM_CAP;
     for (int i = threadIdx.x; i < ncontact; i += blockDim.x) lm_union(par, s_contact[i].x, s_contact[i].y);
-    if (band_fallback[b * gridDim.x + band])
+    if (band_fallback[b * nbands + band])
         for (int cell = threadIdx.x; cell < (y1 - y0 - 1) * WW; cell += blockDim.x) {
             const int r = cell / WW, w = cell - r * WW;
             lm_cell_contacts(bits, starts, prefix, rowoff, row0 + 1 + r, w, WW, [&](int a, int c) { lm_union(par, a, c); });
         }
+}
+
+__global__ void __launch_bounds__(256) lm_k_seam_union(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
+                                                       const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
+                                                       const uint8_t* __restrict__ band_fallback, int32_t* __restrict__ parent,
+                                                       int WW, int H, int cap, int brows)
+{
+    lm_seam_body(blockIdx.y, blockIdx.x, gridDim.x, bits, starts, prefix, rowoff, band_fallback, parent, WW, H, cap, brows);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -527,12 +533,11 @@ __global__ void __launch_bounds__(256) lm_k_seam_union(const uint64_t* __restric
 // ------------------------------------------------------------------------------------------------
 // K5a: one block per (band, frame): flatten, root flags (one ballot per 64 runs), and -- since the block sees all of its
 // band's flags -- the exclusive popcount prefix of the band's 64-run words and the band's root count.
-__global__ void __launch_bounds__(256) lm_k_flatten_flag(int32_t* __restrict__ parent, const int32_t* __restrict__ band_runs,
-                                                          unsigned long long* __restrict__ rootbits, uint32_t* __restrict__ wordprefix,
-                                                          uint32_t* __restrict__ band_roots, int slot, int cap, int capw)
+LM_DEV void lm_flatten_body(int b, int band, int nbands, int32_t* __restrict__ parent, const int32_t* __restrict__ band_runs,
+                            unsigned long long* __restrict__ rootbits, uint32_t* __restrict__ wordprefix, uint32_t* __restrict__ band_roots,
+                            int slot, int cap, int capw)
 {
-    const int b = blockIdx.y, band = blockIdx.x;
-    const int n = band_runs[b * gridDim.x + band];
+    const int n = band_runs[b * nbands + band];
     int32_t* par = parent + (long long)b * cap;
     unsigned long long* rb = rootbits + (long long)b * capw + (band * slot >> 6);
     uint32_t* wp = wordprefix + (long long)b * capw + (band * slot >> 6);
@@ -575,19 +580,23 @@ __global__ void __launch_bounds__(256) lm_k_flatten_flag(int32_t* __restrict__ p
         if (myword * 64 < n) wp[myword] = carry + ex;
         carry += tot;
     }
-    if (threadIdx.x == 0) band_roots[b * gridDim.x + band] = carry;
+    if (threadIdx.x == 0) band_roots[b * nbands + band] = carry;
+}
+
+__global__ void __launch_bounds__(256) lm_k_flatten_flag(int32_t* __restrict__ parent, const int32_t* __restrict__ band_runs,
+                                                          unsigned long long* __restrict__ rootbits, uint32_t* __restrict__ wordprefix,
+                                                          uint32_t* __restrict__ band_roots, int slot, int cap, int capw)
+{
+    lm_flatten_body(blockIdx.y, blockIdx.x, gridDim.x, parent, band_runs, rootbits, wordprefix, band_roots, slot, cap, capw);
 }
 
 // K5b: final[i] = (roots in the bands above) + (roots before the run's root inside its band) + 1.  One block per
 // (band, frame); the band bases are a 64-wide scan of the per-band root counts; block 0 of a frame also writes n_labels.
-__global__ void __launch_bounds__(256) lm_k_apply_labels(const int32_t* __restrict__ parent, const int32_t* __restrict__ band_runs,
-                                                         const unsigned long long* __restrict__ rootbits,
-                                                         const uint32_t* __restrict__ wordprefix, const uint32_t* __restrict__ band_roots,
-                                                         uint32_t* __restrict__ band_base, int32_t* __restrict__ n_labels,
-                                                         int32_t* __restrict__ final_label, int slot, int cap, int capw)
+LM_DEV void lm_apply_body(int b, int band, int nbands, const int32_t* parent, const int32_t* __restrict__ band_runs, const unsigned long long* rootbits,
+                          const uint32_t* wordprefix, const uint32_t* band_roots, uint32_t* __restrict__ band_base, int32_t* __restrict__ n_labels,
+                          int32_t* __restrict__ final_label, int slot, int cap, int capw)
 {
     __shared__ unsigned s_base[1024];
-    const int b = blockIdx.y, band = blockIdx.x, nbands = gridDim.x;
     // exclusive scan of the frame's band root counts (nbands <= 1024), redundantly per block: a few hundred loads from L2
     unsigned carry = 0;
     for (int base = 0; base < nbands; base += 256) {
@@ -627,6 +636,62 @@ __global__ void __launch_bounds__(256) lm_k_apply_labels(const int32_t* __restri
         }
     }
 }
+
+__global__ void __launch_bounds__(256) lm_k_apply_labels(const int32_t* __restrict__ parent, const int32_t* __restrict__ band_runs,
+                                                         const unsigned long long* __restrict__ rootbits,
+                                                         const uint32_t* __restrict__ wordprefix, const uint32_t* __restrict__ band_roots,
+                                                         uint32_t* __restrict__ band_base, int32_t* __restrict__ n_labels,
+                                                         int32_t* __restrict__ final_label, int slot, int cap, int capw)
+{
+    lm_apply_body(blockIdx.y, blockIdx.x, gridDim.x, parent, band_runs, rootbits, wordprefix, band_roots, band_base, n_labels, final_label, slot, cap, capw);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4b + K5a + K5b as ONE launch ("per-frame pipelined middle"): a workgroup per (band, frame) runs its seam unions, waits
+// until the frame's other bands have done theirs, flattens and flags its band, waits again (the numbering needs every band's root
+// count and root flags), and numbers its runs.  The two waits are per-FRAME arrival counters in HBM -- three grid-wide kernel
+// boundaries become two 34-workgroup rendezvous that other frames' workgroups compute under.  Hand-off per MI355X_MICROARCH.md
+// ("Valid forms"): every wave's stores drained + workgroup barrier (__syncthreads), lane 0: agent-scope release, drain, relaxed
+// agent-scope arrival; then one relaxed poll loop, one agent-scope acquire, drain, workgroup barrier, plain loads.
+// Workgroups take (frame, band) from a ticket counter in arrival order, so a waiting workgroup only ever waits for workgroups that
+// have started -- no assumption on dispatch order or residency.  Counters are never reset: the host passes the launch's base
+// values (cumulative tickets / arrivals of the earlier launches on the same counter set).  GPU builds only: the CPU emulator runs
+// workgroups one after another and keeps the three launches.
+// ------------------------------------------------------------------------------------------------
+#if !LM_HIP_EMULATED
+LM_DEV void lm_frame_rendezvous(unsigned* counter, unsigned target)
+{
+    __syncthreads();                    // every wave: its stores are drained (s_waitcnt vmcnt(0)) and it has reached this point
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) lm_k_middle(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts, const uint16_t* __restrict__ prefix,
+                                                   const uint32_t* __restrict__ rowoff, const uint8_t* __restrict__ band_fallback, int32_t* parent,
+                                                   const int32_t* __restrict__ band_runs, unsigned long long* rootbits, uint32_t* wordprefix,
+                                                   uint32_t* band_roots, uint32_t* __restrict__ band_base, int32_t* __restrict__ n_labels,
+                                                   int32_t* __restrict__ final_label, int WW, int H, int cap, int brows, int slot, int capw, int nbands,
+                                                   unsigned* __restrict__ sync, unsigned ticket_base, unsigned arrive_base)
+{
+    // sync[0]: tickets; sync[1 + 2 * frame + phase]: arrivals of the frame's workgroups at rendezvous `phase`
+    __shared__ unsigned s_ticket;
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base;
+    __syncthreads();
+    const int b = (int)(s_ticket / (unsigned)nbands), band = (int)(s_ticket - (unsigned)b * nbands);
+    lm_seam_body(b, band, nbands, bits, starts, prefix, rowoff, band_fallback, parent, WW, H, cap, brows);
+    lm_frame_rendezvous(sync + 1 + 2 * b, arrive_base + (unsigned)nbands);
+    lm_flatten_body(b, band, nbands, parent, band_runs, rootbits, wordprefix, band_roots, slot, cap, capw);
+    lm_frame_rendezvous(sync + 2 + 2 * b, arrive_base + (unsigned)nbands);
+    lm_apply_body(b, band, nbands, parent, band_runs, rootbits, wordprefix, band_roots, band_base, n_labels, final_label, slot, cap, capw);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // K6: write the int32 label image (4 B/px, the only HBM write of the labelling).  One thread handles LM_WL_Q quads

@@ -63,6 +63,7 @@ struct LmCtx {
     uint32_t* band_base;     // [B][nbands] labels (roots) in the bands above
     uint32_t* band_roots;    // [B][nbands] roots per band
     uint8_t* band_fallback;  // [B][nbands] 1 = forest too large for LDS, unions done in L2
+    unsigned* mid_sync;      // [2 queues][1 + 2 * B] ticket + per-frame arrival counters of lm_k_middle
     int nbands, slot;        // bands of band_rows rows; slot = id space per band (worst-case runs, multiple of 64)
     int band_rows;           // 32 up to 2048 px wide, 16 above (lm_cc_kernels.hip)
     int32_t* parent;         // [B][cap]
@@ -97,6 +98,7 @@ struct LmCtx {
     void* ev_join;
 };
 
+#define LM_LABEL_FUSED_MIDDLE_DEFAULT 0     // 1: lm_k_middle (one launch, per-frame rendezvous) instead of seam / flatten / apply launches; env LM_LABEL_FUSED_MIDDLE overrides
 #define LM_LABEL_PARTS 2        // parts a batch is labelled in (env LM_LABEL_PARTS overrides: 1..8)
 #define LM_LABEL_PART_MIN 8     // ... as long as every part has at least this many frames
 
