@@ -171,6 +171,64 @@ LM_DEV void lm_gimg_write_tile(const LmGimgItem& it, const LmGimgUnit& un, const
     }
 }
 
+// ---- tiles with ONE member (most of them: 1.7 members per visited tile on the 10,000-frame stream): the tile's sums are count x (the
+// member's pixels), so there is nothing to accumulate -- the maximum is `count` if the member has a pixel in the tile, and the image is the
+// member's bit rows, shifted from the crop's absolute 32-px column alignment to the tile's, when count passes the threshold.
+// does the member own a pixel inside the tile?  (every thread calls; result through s_hit)
+LM_DEV void lm_gimg_single_hit(const LmGimgItem& it, const LmGimgUnit& un, const LmCcRec& r, const uint32_t* __restrict__ crop, int* s_hit)
+{
+    const int X0 = it.x0 + un.tx * LM_GT, Y0 = it.y0 + un.ty * LM_GT;
+    const int wx0 = r.min_x >> 5, nw = (r.max_x >> 5) - wx0 + 1;
+    const int ya = r.min_y > Y0 ? r.min_y : Y0, yb = r.max_y < Y0 + LM_GT - 1 ? r.max_y : Y0 + LM_GT - 1;
+    const int ja = (X0 >> 5) > wx0 ? (X0 >> 5) - wx0 : 0;
+    const int jb = ((X0 + LM_GT - 1) >> 5) - wx0 < nw - 1 ? ((X0 + LM_GT - 1) >> 5) - wx0 : nw - 1;
+    const int tw = jb - ja + 1, total = (tw > 0 && yb >= ya) ? tw * (yb - ya + 1) : 0;
+    bool hit = false;
+    for (int idx = threadIdx.x; idx < total && !hit; idx += blockDim.x) {
+        const int rr = idx / tw, j = ja + (idx - rr * tw);
+        unsigned wbits = crop[r.crop_off + (unsigned long long)((ya + rr - r.min_y) * nw + j)];
+        const int xw = (wx0 + j) * 32;              // frame column of the word's bit 0: keep the bits with X0 <= x < X0 + 64
+        if (xw < X0) wbits &= (X0 - xw >= 32) ? 0u : (0xffffffffu << (X0 - xw));
+        if (xw + 31 >= X0 + LM_GT) wbits &= (xw >= X0 + LM_GT) ? 0u : (0xffffffffu >> (xw + 32 - (X0 + LM_GT)));
+        hit = wbits != 0u;
+    }
+    if (hit) *s_hit = 1;
+}
+
+// the member's pixels as the tile's bit rows (the words outside the member's rows stay cleared)
+LM_DEV void lm_gimg_single_write(const LmGimgItem& it, const LmGimgUnit& un, const LmCcRec& r, const uint32_t* __restrict__ crop, uint32_t* __restrict__ bits)
+{
+    const int X0 = it.x0 + un.tx * LM_GT, Y0 = it.y0 + un.ty * LM_GT;
+    const int wx0 = r.min_x >> 5, nw = (r.max_x >> 5) - wx0 + 1;
+    const int tw = (it.w - un.tx * LM_GT < LM_GT) ? it.w - un.tx * LM_GT : LM_GT;
+    const int th = (it.h - un.ty * LM_GT < LM_GT) ? it.h - un.ty * LM_GT : LM_GT;
+    const int bw = (it.w + 31) >> 5;
+    for (int t = threadIdx.x; t < 2 * LM_GT; t += blockDim.x) {
+        const int yy = t >> 1, k = t & 1, y = Y0 + yy;
+        if (yy >= th || un.tx * 2 + k >= bw || y < r.min_y || y > r.max_y) continue;
+        const int xa = X0 + 32 * k;                 // frame column of the output word's bit 0
+        const int c0 = (xa >> 5) - wx0, sh = xa & 31;
+        const uint32_t* row = crop + r.crop_off + (unsigned long long)(y - r.min_y) * nw;
+        const unsigned lo = (c0 >= 0 && c0 < nw) ? row[c0] : 0u;
+        const unsigned hi = (sh && c0 + 1 >= 0 && c0 + 1 < nw) ? row[c0 + 1] : 0u;
+        unsigned w = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+        const int valid = tw - 32 * k;              // columns of this word inside the item
+        if (valid < 32) w &= valid <= 0 ? 0u : ((1u << valid) - 1u);
+        if (w) bits[it.bits_off + (long long)(un.ty * LM_GT + yy) * bw + un.tx * 2 + k] = w;
+    }
+}
+
+// the exact integer bound of ((double)v / mx >= thr), as lm_gimg_write_tile computes it
+LM_DEV int lm_gimg_vmin(int item_max, double thr)
+{
+    const double mx = (double)item_max;
+    int vmin = (int)(thr * mx);
+    if (vmin < 0) vmin = 0;
+    while (vmin > 0 && (double)(vmin - 1) / mx >= thr) vmin--;
+    while ((double)vmin / mx < thr) vmin++;
+    return vmin;
+}
+
 // an item that is a single 64 x 64 tile: its maximum is the tile's, known to the workgroup that accumulates the tile
 LM_DEV bool lm_gimg_single_tile(const LmGimgItem& it) { return it.w <= LM_GT && it.h <= LM_GT; }
 
@@ -189,6 +247,18 @@ __global__ void __launch_bounds__(256) lm_k_gimg_max(const LmGimgItem* __restric
         const LmGimgUnit un = units[u];
         const LmGimgItem it = items[un.item];
         if (threadIdx.x == 0) s_max = 0;
+        if (un.mem_cnt == 1 && thr > 0.0) {             // one member: its count, if it owns a pixel of the tile (block-uniform branch)
+            const LmGimgMember mem = members[un.mem_off];
+            const LmCcRec r = cc[mem.cc];
+            __syncthreads();
+            lm_gimg_single_hit(it, un, r, crop, &s_max);
+            __syncthreads();
+            const int tile_max = s_max ? mem.count : 0;
+            if (threadIdx.x == 0 && tile_max) atomicMax(&item_max[un.item], tile_max);
+            if (lm_gimg_single_tile(it) && tile_max && tile_max >= lm_gimg_vmin(tile_max, thr)) lm_gimg_single_write(it, un, r, crop, bits);
+            __syncthreads();
+            continue;
+        }
         lm_gimg_accumulate(it, un, members, cc, crop, s_mask);
         int mx = 0;
         for (int i = threadIdx.x; i < LM_GT * LM_GT; i += blockDim.x) mx = s_mask[i] > mx ? s_mask[i] : mx;
@@ -215,6 +285,11 @@ __global__ void __launch_bounds__(256) lm_k_gimg_write(const LmGimgItem* __restr
         const LmGimgUnit un = units[u];
         const LmGimgItem it = items[un.item];
         if (lm_gimg_single_tile(it) && item_max[un.item] > 0) continue;     // finished by lm_k_gimg_max (block-uniform)
+        if (un.mem_cnt == 1 && thr > 0.0 && item_max[un.item] > 0) {        // one member: copy its bit rows if its count passes
+            const LmGimgMember mem = members[un.mem_off];
+            if (mem.count >= lm_gimg_vmin(item_max[un.item], thr)) lm_gimg_single_write(it, un, cc[mem.cc], crop, bits);
+            continue;
+        }
         lm_gimg_accumulate(it, un, members, cc, crop, s_mask);
         lm_gimg_write_tile(it, un, s_mask, item_max[un.item], thr, bits);
         __syncthreads();
