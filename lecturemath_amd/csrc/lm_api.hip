@@ -620,8 +620,11 @@ extern "C" int lm_stream_reset(LmStream* s, void* stream)
     LM_HIP(hipMemsetAsync(s->best, 0xff, (size_t)s->ctx->g.cap * sizeof(unsigned long long), (hipStream_t)stream));
     LM_HIP(hipMemsetAsync(s->frame_cc_off, 0, sizeof(long long), (hipStream_t)stream));
     LM_HIP(hipMemsetAsync(s->chash, 0, (size_t)s->cap_cc * sizeof(uint32_t), (hipStream_t)stream));     // lm_k_emit adds into it
+    // the twin table is empty between batches (lm_k_mb_twin_final clears what its batch inserted); a batch cut short by an error leaves entries behind
+    if (s->mb) LM_HIP(hipMemsetAsync(s->mb->ttab, 0xff, (size_t)LM_MB_TTAB * sizeof(unsigned long long), (hipStream_t)stream));
     s->frames_pushed = 0;
     s->frames_matched = 0;
+    s->tempo_B = 0;
     return LM_OK;
 }
 
@@ -726,8 +729,22 @@ static void lm_launch_match(LmStream* s, int f, hipStream_t st)
 // Matches frames [f0, f0 + n) (all emitted already) in chunks of at most LM_MB_MAX_FRAMES frames.
 // ev_pre (optional): recorded on `st` in front of the last chunk's replay kernel, i.e. when the wide kernels of the matching
 // (twin detection, joins, pair evaluation) have been issued and only the single-workgroup replay, finish and tempo_count remain
-static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st, hipEvent_t ev_pre = nullptr)
+// defer_tempo: the tempo_count kernel of the LAST chunk (a wide launch that only adds to a counter) is not launched here but in front
+// of the next call's kernels, or by lm_flush_tempo: in the gated schedule it would run beside the next batch's labelling launches,
+// deferred it runs beside that batch's record emission instead.  It reads the active list as the replay left it and the tile
+// table of its batch: both are untouched until the next batch's lm_k_mb_nt, which the same queue runs after it.
+static void lm_flush_tempo(LmStream* s, hipStream_t st)
 {
+    if (s->tempo_B <= 0) return;
+    const LmMatchBatch mb = *s->mb;
+    hipLaunchKernelGGL(lm_k_mb_tempo, dim3(LM_HIP_EMULATED ? 2 : 1024), dim3(256), 0, st, s->cc, s->frame_cc_off, s->tempo_f0, s->tempo_B, s->active_box,
+                       s->active_cc, s->active_last, s->counters, mb, s->max_gap);
+    s->tempo_B = 0;
+}
+
+static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st, hipEvent_t ev_pre = nullptr, bool defer_tempo = false)
+{
+    if (!s->match_per_frame) lm_flush_tempo(s, st);
     if (s->match_per_frame) {
         for (int i = 0; i < n; i++) lm_launch_match(s, f0 + i, st);
         return;
@@ -740,7 +757,6 @@ static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st, h
         s->last_match_frames = B;
         const int twins = (s->min_recall <= 1.0 && s->min_precision <= 1.0) ? 1 : 0;     // the twin rule needs "identical crops are accepted"; otherwise twin[] stays 0
         if (twins) {
-            (void)hipMemsetAsync(mb.ttab, 0xff, (size_t)LM_MB_TTAB * sizeof(unsigned long long), st);
             const dim3 gc(LM_HIP_EMULATED ? 2 : 256);
             hipLaunchKernelGGL(lm_k_mb_twin_insert, gc, dim3(256), 0, st, s->cc, s->chash, s->frame_cc_off, f, B, s->counters, mb);
             hipLaunchKernelGGL(lm_k_mb_twin_probe, gc, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->counters, mb, s->max_gap);
@@ -766,8 +782,10 @@ static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st, h
         hipLaunchKernelGGL(lm_k_mb_resolve, dim3(1), dim3(LM_MB_RT), LM_MB_RESOLVE_SMEM, st, s->cc, s->frame_cc_off, f, B, s->active, s->active_cc,
                            s->active_box, s->active_last, s->counters, s->assign, mb, s->max_gap, s->cap_uniq);
         hipLaunchKernelGGL(lm_k_mb_finish, dim3(160), dim3(256), 0, st, s->frame_cc_off, f, B, s->active, s->counters, s->assign, mb);
-        hipLaunchKernelGGL(lm_k_mb_tempo, gt, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->active_last,
-                           s->counters, mb, s->max_gap);
+        if (defer_tempo && done + B >= n) { s->tempo_f0 = f; s->tempo_B = B; }
+        else
+            hipLaunchKernelGGL(lm_k_mb_tempo, gt, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->active_last,
+                               s->counters, mb, s->max_gap);
         done += B;
     }
 }
@@ -785,7 +803,7 @@ static int lm_stream_emit_batch(LmStream* s, int B, void* stream)
                        s->min_pixels);
     hipLaunchKernelGGL(lm_k_batch_offsets, dim3(1), dim3(1024), 0, st, c->frame_kept, c->frame_cropwords, B, s->counters,
                        s->frame_cc_off, s->batch_cc_base, s->batch_word_base, s->cap_cc, s->cap_words, s->cap_frames);
-    hipLaunchKernelGGL(lm_k_emit, dim3(LM_HIP_EMULATED ? 2 : 320, B), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff, c->final_label,
+    hipLaunchKernelGGL(lm_k_emit, dim3(LM_HIP_EMULATED ? 2 : LM_EMIT_GRID, B), dim3(256), 0, st, c->bits, c->starts, c->prefix, c->rowoff, c->final_label,
                        c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x, c->st_count, c->kept_label, c->kept_cropoff,
                        c->frame_kept, c->frame_cropwords, s->batch_cc_base, s->batch_word_base, s->cc, s->crop, s->chash, s->frames_pushed, g.WW,
                        g.H, g.cap);
@@ -911,7 +929,7 @@ extern "C" int lm_stream_run_logits(LmStream* s, const float* d_logits, int n_fr
             LM_HIP(hipEventRecord(ev[3 * k + 1], sw));
             if (k >= 1) {               // matching of batch k-1 starts when batch k has been labelled (which implies its records are in)
                 LM_HIP(hipStreamWaitEvent(sm, ev[3 * k], 0));
-                lm_launch_match_frames(s, s->frames_matched, prev_n, sm, ev[3 * (k - 1) + 2]);
+                lm_launch_match_frames(s, s->frames_matched, prev_n, sm, ev[3 * (k - 1) + 2], true);
                 s->frames_matched += prev_n;
             }
         }
@@ -922,6 +940,7 @@ extern "C" int lm_stream_run_logits(LmStream* s, const float* d_logits, int n_fr
         lm_launch_match_frames(s, s->frames_matched, prev_n, sm, ev[3 * (nb - 1) + 2]);
         s->frames_matched += prev_n;
     }
+    lm_flush_tempo(s, sm);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }

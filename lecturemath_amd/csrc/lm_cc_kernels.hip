@@ -799,9 +799,10 @@ __global__ void __launch_bounds__(256) lm_k_stats_init(int32_t* __restrict__ st_
 // hash table (ds atomics), then every (tile, label) pair costs at most five device-scope atomics.
 #define LM_ST_SLOTS 512
 #ifndef LM_ST_ROWS
-#define LM_ST_ROWS 64      // tile rows (multiple of 64; a thread takes one 64-px word in every 64th row).  128 rows measured: 95.5 vs 97.9 us per 64 frames -- the cost is in the pieces, not in the per-tile table set-up
+#define LM_ST_ROWS 128     // tile rows (multiple of 64; a thread takes one 64-px word in every 64th row of the tile, all loaded together).  Per 64 dense 1080p frames: 64 rows 88.5 us, 128 rows 84.0, 256 rows 96.4
 #endif
 #define LM_ST_WORDS 4
+#define LM_ST_PRE 4        // final labels fetched ahead per cell
 
 __global__ void __launch_bounds__(256) lm_k_stats(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
                                                   const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
@@ -819,56 +820,128 @@ __global__ void __launch_bounds__(256) lm_k_stats(const uint64_t* __restrict__ b
     }
     __syncthreads();
     const int w = blockIdx.x * LM_ST_WORDS + (int)(threadIdx.x & 3);
-    for (int rr = 0; rr < LM_ST_ROWS / 64; rr++) {          // a thread's cells: one 64-px word in every 64th row of the tile
-    const int y = blockIdx.y * LM_ST_ROWS + rr * 64 + (int)(threadIdx.x >> 2);
-    if (y < H && w < WW) {
-        const long long row = (long long)b * H + y;
-        const long long gid = row * WW + w;
-        unsigned long long rem = bits[gid];
-        if (rem) {
-            const unsigned long long s = starts[gid];
-            const int32_t* fin = final_label + foff;
-            int id = (int)rowoff[row] + (int)prefix[gid] - 1;
-            const bool next_cont = (w + 1 < WW) ? (bits[gid + 1] & 1ull) : false;
-            while (rem) {
-                int lo = __ffsll((long long)rem) - 1;
-                unsigned long long t = ~(rem >> lo);           // zeros where the piece continues
-                int len = t ? (__ffsll((long long)t) - 1) : 64;
-                if (len > 64 - lo) len = 64 - lo;
-                int hi = lo + len - 1;
-                const bool is_start = (s >> lo) & 1ull;
-                id += is_start ? 1 : 0;
-                const int lab = fin[id];                       // 1-based
-                const bool ends = (hi < 63) || !next_cont;
-                int slot = (int)(((unsigned)lab * 2654435761u) >> 23) & (LM_ST_SLOTS - 1);
-                bool placed = false;
-                for (int tries = 0; tries < 24; tries++) {
-                    int k = atomicCAS(&s_key[slot], 0, lab);
-                    if (k == 0 || k == lab) { placed = true; break; }
-                    slot = (slot + 1) & (LM_ST_SLOTS - 1);
+    const int32_t* fin = final_label + foff;
+    const int lane = lm_lane();
+    // Round 3.  (1) The run-table loads of a non-empty cell are issued together and the final labels of its first LM_ST_PRE
+    // pieces in one batch (pieces of a word have consecutive run ids) instead of one dependent load per piece.  (2) Consecutive
+    // pieces of one label are combined in registers.  (3) The LDS table is updated in wave-synchronous rounds: late in a lecture
+    // most ink belongs to a few large components, so most lanes of a wave report to the SAME slot, and 64 atomics on one LDS
+    // address are served one after the other.  Per round the lanes that share the label of the first reporting lane (twice) add
+    // their counts up in registers and send one atomic; a slot that already holds the label is found by a plain (broadcast) read,
+    // and the box only moves for pieces on the component's rim (looked at before the atomic, as before).
+    // (4) A thread's LM_ST_CELLS cells (one 64-px word in every 64th row of the tile) are loaded together, phase by phase: the
+    // kernel's time was rounds of workgroups x a chain of five dependent memory latencies, not arithmetic.
+    constexpr int NC = LM_ST_ROWS / 64;
+    unsigned long long firsts[NC], lasts[NC], sbits[NC];
+    int id0[NC], labs[NC][LM_ST_PRE];
+    bool next_cont[NC];
+    long long gidc[NC], rowc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int y = blockIdx.y * LM_ST_ROWS + c * 64 + (int)(threadIdx.x >> 2);
+        gidc[c] = -1; firsts[c] = 0; lasts[c] = 0; sbits[c] = 0; id0[c] = 0; next_cont[c] = false;
+        rowc[c] = (long long)b * H + y;
+        if (y < H && w < WW) gidc[c] = rowc[c] * WW + w;
+    }
+    unsigned long long remc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) remc[c] = gidc[c] >= 0 ? bits[gidc[c]] : 0ull;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        if (remc[c]) {
+            sbits[c] = starts[gidc[c]];
+            id0[c] = (int)rowoff[rowc[c]] + (int)prefix[gidc[c]] - 1;
+            next_cont[c] = (w + 1 < WW) ? (bits[gidc[c] + 1] & 1ull) : false;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        int npieces = 0;
+        if (remc[c]) {
+            firsts[c] = remc[c] & ~(remc[c] << 1);         // first / last pixel of every piece of the word
+            lasts[c] = remc[c] & ~(remc[c] >> 1);
+            // run id of the first piece (idbase + 1 if it starts in this word, idbase if it continues from the left) and the
+            // number of pieces: one per run start, plus the continuing one
+            const int first_start = (int)((sbits[c] >> (__ffsll((long long)remc[c]) - 1)) & 1ull);
+            id0[c] += first_start;
+            npieces = __popcll(sbits[c]) + 1 - first_start;
+        }
+#pragma unroll
+        for (int z = 0; z < LM_ST_PRE; z++) labs[c][z] = (z < npieces) ? fin[id0[c] + z] : 0;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+    const int y = blockIdx.y * LM_ST_ROWS + c * 64 + (int)(threadIdx.x >> 2);
+    const unsigned long long s = sbits[c];
+    int q = 0;
+    int nxt = 0;                // label of the next piece (0: none left)
+    if (firsts[c]) nxt = labs[c][0];
+    while (__ballot(nxt != 0)) {
+        // ---- per lane: gather the pieces up to the next change of label
+        const int lab = nxt;
+        int cnt = 0, mnx = 0x7fffffff, mxx = -1;
+        bool has_start = false;
+        while (nxt != 0 && nxt == lab) {
+            const int lo = __ffsll((long long)firsts[c]) - 1, hi = __ffsll((long long)lasts[c]) - 1;
+            firsts[c] &= firsts[c] - 1; lasts[c] &= lasts[c] - 1;
+            cnt += hi - lo + 1;
+            if ((s >> lo) & 1ull) { has_start = true; if (w * 64 + lo < mnx) mnx = w * 64 + lo; }
+            if (hi < 63 || !next_cont[c]) mxx = w * 64 + hi;        // pieces come left to right
+            q++;
+            nxt = 0;
+            if (firsts[c]) {
+                if (q < LM_ST_PRE) {
+                    nxt = labs[c][0];
+#pragma unroll
+                    for (int z = 1; z < LM_ST_PRE; z++) nxt = (q == z) ? labs[c][z] : nxt;
+                } else {
+                    nxt = fin[id0[c] + q];                            // 1-based
                 }
-                if (placed) {
-                    // a large component owns most pieces of a tile: the box only moves for the few pieces on its rim, so look
-                    // before the atomic (a stale value only costs an atomic that changes nothing)
-                    atomicAdd(&s_cnt[slot], len);
-                    if (is_start) {
-                        if (w * 64 + lo < s_mnx[slot]) atomicMin(&s_mnx[slot], w * 64 + lo);
-                        if (y < s_mny[slot]) atomicMin(&s_mny[slot], y);
-                        if (y > s_mxy[slot]) atomicMax(&s_mxy[slot], y);
-                    }
-                    if (ends && w * 64 + hi > s_mxx[slot]) atomicMax(&s_mxx[slot], w * 64 + hi);
-                } else {      // table full (very dense tile): straight to L2
-                    const long long cc = foff + lab - 1;
-                    atomicAdd(&st_count[cc], len);
-                    if (is_start) {
-                        atomicMin(&st_min_x[cc], w * 64 + lo);
-                        atomicMin(&st_min_y[cc], y);
-                        atomicMax(&st_max_y[cc], y);
-                    }
-                    if (ends) atomicMax(&st_max_x[cc], w * 64 + hi);
-                }
-                rem &= ~(lm_lowmask_incl(hi));
             }
+        }
+        // ---- the wave reports (lab, cnt, box) of its lanes
+        const bool valid = lab != 0;
+        int slot = (int)(((unsigned)lab * 2654435761u) >> 23) & (LM_ST_SLOTS - 1);
+        bool placed = false;
+        if (valid) {
+            for (int tries = 0; tries < 24; tries++) {
+                int k = s_key[slot];
+                if (k == 0) k = atomicCAS(&s_key[slot], 0, lab);
+                if (k == 0 || k == lab) { placed = true; break; }
+                slot = (slot + 1) & (LM_ST_SLOTS - 1);
+            }
+        }
+        bool counted = !valid;
+        unsigned long long todo = __ballot(valid && placed);
+        for (int round = 0; round < 2 && todo; round++) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int ll = __shfl(lab, leader);
+            const bool mine = valid && placed && lab == ll;
+            const unsigned long long same = __ballot(mine);
+            if (__popcll(same) >= 4) {
+                const int sum = lm_wave_sum(mine ? cnt : 0);
+                if (lane == leader) atomicAdd(&s_cnt[slot], sum);
+                counted = counted || mine;
+            }
+            todo &= ~same;
+        }
+        if (valid && placed) {
+            if (!counted) atomicAdd(&s_cnt[slot], cnt);
+            if (has_start) {
+                if (mnx < s_mnx[slot]) atomicMin(&s_mnx[slot], mnx);
+                if (y < s_mny[slot]) atomicMin(&s_mny[slot], y);
+                if (y > s_mxy[slot]) atomicMax(&s_mxy[slot], y);
+            }
+            if (mxx >= 0 && mxx > s_mxx[slot]) atomicMax(&s_mxx[slot], mxx);
+        } else if (valid) {      // table full (very dense tile): straight to L2
+            const long long cc = foff + lab - 1;
+            atomicAdd(&st_count[cc], cnt);
+            if (has_start) {
+                atomicMin(&st_min_x[cc], mnx);
+                atomicMin(&st_min_y[cc], y);
+                atomicMax(&st_max_y[cc], y);
+            }
+            if (mxx >= 0) atomicMax(&st_max_x[cc], mxx);
         }
     }
     }
@@ -965,6 +1038,8 @@ __global__ void __launch_bounds__(256) lm_k_ab_finish(const int32_t* age_bits, c
 // Crop of a CC = its pixels as bit rows aligned to ABSOLUTE 32-pixel columns of the frame:
 // words (min_x>>5 .. max_x>>5) for each row min_y..max_y, so two crops AND together without shifts.
 // ------------------------------------------------------------------------------------------------
+#define LM_SEL_ITEMS 4       // labels per thread and pass: their loads are in flight together, one block scan per 4096 labels
+
 __global__ void __launch_bounds__(1024) lm_k_select(const int32_t* __restrict__ st_min_y, const int32_t* __restrict__ st_max_y,
                                                     const int32_t* __restrict__ st_min_x, const int32_t* __restrict__ st_max_x,
                                                     const int32_t* __restrict__ st_count, const int32_t* __restrict__ n_labels,
@@ -972,30 +1047,58 @@ __global__ void __launch_bounds__(1024) lm_k_select(const int32_t* __restrict__ 
                                                     int32_t* __restrict__ frame_kept, uint32_t* __restrict__ frame_cropwords,
                                                     int cap, int min_pixels)
 {
+    __shared__ unsigned long long s_wsum[16];
+    __shared__ unsigned long long s_tot;
     const int b = blockIdx.x;
     const long long off = (long long)b * cap;
     const int n = n_labels[b];
-    unsigned kcarry = 0, wcarry = 0;
-    for (int base = 0; base < n; base += 1024) {
-        int i = base + (int)threadIdx.x;
-        unsigned keep = 0, words = 0;
-        if (i < n && st_count[off + i] >= min_pixels) {
-            keep = 1;
-            unsigned nw = (unsigned)((st_max_x[off + i] >> 5) - (st_min_x[off + i] >> 5) + 1);
-            words = nw * (unsigned)(st_max_y[off + i] - st_min_y[off + i] + 1);
+    const int lane = lm_lane(), wid = (int)(threadIdx.x >> 6);
+    // kept count (high 24 bits) and crop words (low 40 bits; a frame's crop words fit 32) scanned as one 64-bit value
+    unsigned long long carry = 0;
+    for (int base = 0; base < n; base += 1024 * LM_SEL_ITEMS) {
+        int cnt[LM_SEL_ITEMS], mnx[LM_SEL_ITEMS], mxx[LM_SEL_ITEMS], mny[LM_SEL_ITEMS], mxy[LM_SEL_ITEMS];
+#pragma unroll
+        for (int k = 0; k < LM_SEL_ITEMS; k++) {
+            const int i = base + (int)threadIdx.x * LM_SEL_ITEMS + k;
+            const bool in = i < n;
+            cnt[k] = in ? st_count[off + i] : -1;
+            mnx[k] = in ? st_min_x[off + i] : 0; mxx[k] = in ? st_max_x[off + i] : 0;
+            mny[k] = in ? st_min_y[off + i] : 0; mxy[k] = in ? st_max_y[off + i] : 0;
         }
-        unsigned ktot, wtot;
-        unsigned kex = lm_block_excl_scan<1024>(keep, &ktot);
-        unsigned wex = lm_block_excl_scan<1024>(words, &wtot);
-        if (keep) {
-            kept_label[off + kcarry + kex] = i;
-            kept_cropoff[off + kcarry + kex] = wcarry + wex;
+        unsigned long long v[LM_SEL_ITEMS], mine = 0;
+#pragma unroll
+        for (int k = 0; k < LM_SEL_ITEMS; k++) {
+            v[k] = 0;
+            if (cnt[k] >= min_pixels && cnt[k] >= 0) {
+                const unsigned nw = (unsigned)((mxx[k] >> 5) - (mnx[k] >> 5) + 1);
+                v[k] = (1ull << 40) | (unsigned long long)(nw * (unsigned)(mxy[k] - mny[k] + 1));
+            }
+            mine += v[k];
         }
-        kcarry += ktot;
-        wcarry += wtot;
+        const unsigned long long incl = lm_wave_incl_scan(mine);
+        __syncthreads();            // s_wsum free again
+        if (lane == 63) s_wsum[wid] = incl;
+        __syncthreads();
+        if (wid == 0) {
+            const unsigned long long t = (lane < 16) ? s_wsum[lane] : 0ull;
+            const unsigned long long ti = lm_wave_incl_scan(t);
+            if (lane < 16) s_wsum[lane] = ti - t;
+            if (lane == 15) s_tot = ti;
+        }
+        __syncthreads();
+        unsigned long long o = carry + s_wsum[wid] + incl - mine;
+#pragma unroll
+        for (int k = 0; k < LM_SEL_ITEMS; k++) {
+            if (v[k]) {
+                kept_label[off + (long long)(o >> 40)] = base + (int)threadIdx.x * LM_SEL_ITEMS + k;
+                kept_cropoff[off + (long long)(o >> 40)] = (uint32_t)(o & ((1ull << 40) - 1ull));
+            }
+            o += v[k];
+        }
+        carry += s_tot;
     }
     if (threadIdx.x == 0) {
-        frame_kept[b] = (int32_t)kcarry;
-        frame_cropwords[b] = wcarry;
+        frame_kept[b] = (int32_t)(carry >> 40);
+        frame_cropwords[b] = (uint32_t)(carry & ((1ull << 40) - 1ull));
     }
 }

@@ -75,7 +75,7 @@ struct LmMatchBatch {
     int32_t* newpos;            // active position source k was given when it became a unique, else -1
     int32_t* n_src;             // [1]
     unsigned long long* ttab;   // [LM_MB_TTAB] twin table: key32 << 32 | smallest batch-relative cc index with that key
-    uint32_t* tkey;             // [cap_cc] per global cc: key32 of (box, size, crop); later: non-twins before this CC (lm_k_mb_nt)
+    uint32_t* tkey;             // [cap_cc] per global cc: key32 of (box, size, crop) (lm_k_mb_twin_insert); then the twin-table slot of that key (lm_k_mb_twin_probe)
     uint8_t* twin;              // [cap_cc] per global cc: 1 = exact twin of an earlier CC of the batch
     uint32_t* big[2];           // [cap_big] pairs whose pixel intersection is left to a whole workgroup (lm_k_mb_eval_big)
     unsigned* n_big;            // [2] their number (zeroed by lm_k_mb_twin_insert / lm_k_mb_nt)
@@ -486,9 +486,14 @@ __global__ void __launch_bounds__(256) lm_k_mb_twin_probe(const LmCcRec* __restr
         if (enabled) {
             const unsigned key = mb.tkey[C0 + i];
             for (unsigned probe = 0; probe < LM_MB_TTAB; probe++) {
-                const unsigned long long e = mb.ttab[(key + probe) & (LM_MB_TTAB - 1)];
+                const unsigned slot = (key + probe) & (LM_MB_TTAB - 1);
+                const unsigned long long e = mb.ttab[slot];
                 if (e == ~0ull) break;
-                if ((unsigned)(e >> 32) == key) { root = (long long)(unsigned)e; break; }
+                if ((unsigned)(e >> 32) == key) {
+                    root = (long long)(unsigned)e;
+                    mb.tkey[C0 + i] = slot;         // the entry this CC's key lives in: emptied again by lm_k_mb_twin_final
+                    break;
+                }
             }
             if (root >= 0 && root < i) {
                 const LmCcRec r = cc[C0 + i], q = cc[C0 + root];
@@ -523,11 +528,21 @@ LM_DEV long long lm_cc_of_word_search(const LmCcRec* __restrict__ cc, long long 
     return lo;
 }
 
-// one lane per crop word of the batch: a candidate whose word differs from its root's is not a twin
+// one lane per crop word of the batch: a candidate whose word differs from its root's is not a twin.
+// Round 3: a workgroup takes a contiguous range of the batch's crop words, finds the record of its first word with a 256-way
+// search over the ascending crop offsets (three rounds at most) and stages offsets, candidate roots and the roots' crop offsets
+// of the next LM_TW_WIN records in LDS; before, every wave ran a 17-step binary search over the records in L2 and three more
+// dependent loads per word (184 vector loads per wave, 79 us per 64 dense frames).
+#define LM_TW_WIN 256
+#define LM_TW_UNR 4
+
 __global__ void __launch_bounds__(256) lm_k_mb_twin_cmp(const LmCcRec* __restrict__ cc, const uint32_t* __restrict__ crop,
                                                         const long long* __restrict__ frame_cc_off, int f0, int B,
                                                         LmCounters* __restrict__ cnt, LmMatchBatch mb)
 {
+    __shared__ unsigned long long s_off[LM_TW_WIN + 1], s_roff[LM_TW_WIN];
+    __shared__ int s_root[LM_TW_WIN];
+    __shared__ int s_cnt4[4], s_any;
     if (cnt->error) return;
     const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
     const long long n = C1 - C0;
@@ -538,16 +553,68 @@ __global__ void __launch_bounds__(256) lm_k_mb_twin_cmp(const LmCcRec* __restric
     const LmCcRec last = cc[C1 - 1];
     const unsigned long long W1 = last.crop_off + (unsigned long long)((last.max_x >> 5) - (last.min_x >> 5) + 1) *
                                                       (unsigned long long)(last.max_y - last.min_y + 1);
-    const int lane = lm_lane();
-    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
-    for (unsigned long long w0 = W0 + wave * 64ull; w0 < W1; w0 += nwaves * 64ull) {
-        const long long k0 = lm_cc_of_word_search(cc, C0, n, w0);
-        const unsigned long long w = w0 + (unsigned long long)lane;
-        if (w >= W1) continue;
-        const long long k = lm_cc_of_word(cc, C0, n, w, k0);
-        const int32_t root = mb.troot[C0 + k];
-        if (root < 0) continue;
-        if (crop[w] != crop[cc[root].crop_off + (w - cc[C0 + k].crop_off)]) mb.twin[C0 + k] = 0;
+    constexpr unsigned long long STEP = 256ull * LM_TW_UNR;
+    const unsigned long long per = (((W1 - W0 + gridDim.x - 1) / gridDim.x + STEP - 1) / STEP) * STEP;
+    const unsigned long long wb0 = W0 + (unsigned long long)blockIdx.x * per;
+    if (wb0 >= W1) return;              // uniform in the workgroup
+    const unsigned long long wb1 = (W1 - wb0 < per) ? W1 : wb0 + per;
+    const int tid = (int)threadIdx.x, lane = lm_lane();
+    // largest k with crop_off <= wb0
+    long long klo = 0;
+    for (long long len = n; len > 1;) {
+        const long long stride = (len + 255) >> 8;
+        const bool in = (long long)tid * stride < len;
+        const unsigned long long bal = __ballot(in && cc[C0 + klo + tid * stride].crop_off <= wb0);
+        __syncthreads();
+        if (lane == 0) s_cnt4[tid >> 6] = (int)__popcll(bal);
+        __syncthreads();
+        const int c = s_cnt4[0] + s_cnt4[1] + s_cnt4[2] + s_cnt4[3];       // >= 1
+        klo += (c - 1) * stride;
+        len = (len - (c - 1) * stride < stride) ? len - (c - 1) * stride : stride;
+    }
+    for (unsigned long long cur = wb0; cur < wb1;) {
+        const int nwin = (n - klo < LM_TW_WIN) ? (int)(n - klo) : LM_TW_WIN;
+        __syncthreads();        // the previous window has been read
+        if (tid == 0) s_any = 0;
+        __syncthreads();
+        if (tid < nwin) {
+            const int32_t root = mb.troot[C0 + klo + tid];
+            s_off[tid] = cc[C0 + klo + tid].crop_off;
+            s_root[tid] = root;
+            s_roff[tid] = root >= 0 ? cc[root].crop_off : 0ull;
+            if (root >= 0) s_any = 1;
+        }
+        if (tid == 0) s_off[nwin] = (klo + nwin < n) ? cc[C0 + klo + nwin].crop_off : W1;
+        __syncthreads();
+        const unsigned long long wend = s_off[nwin] < wb1 ? s_off[nwin] : wb1;
+        if (s_any) {
+            for (unsigned long long w0 = cur + (unsigned long long)(tid & ~63) * LM_TW_UNR; w0 < wend; w0 += STEP) {
+                int jj[LM_TW_UNR];
+                unsigned mine[LM_TW_UNR], theirs[LM_TW_UNR];
+#pragma unroll
+                for (int u = 0; u < LM_TW_UNR; u++) {
+                    const unsigned long long w = w0 + (unsigned long long)(u * 64 + lane);
+                    jj[u] = -1; mine[u] = 0; theirs[u] = 0;
+                    if (w < wend) {
+                        int lo = 0, hi = nwin;          // largest j with s_off[j] <= w
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (s_off[mid] <= w) lo = mid; else hi = mid;
+                        }
+                        if (s_root[lo] >= 0) {
+                            jj[u] = lo;
+                            mine[u] = crop[w];
+                            theirs[u] = crop[s_roff[lo] + (w - s_off[lo])];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < LM_TW_UNR; u++)
+                    if (jj[u] >= 0 && mine[u] != theirs[u]) mb.twin[C0 + klo + jj[u]] = 0;
+            }
+        }
+        cur = wend;
+        klo += nwin;
     }
 }
 
@@ -556,10 +623,27 @@ __global__ void __launch_bounds__(256) lm_k_mb_twin_final(const LmCcRec* __restr
 {
     if (cnt->error) return;
     const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
-    for (long long i = C0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < C1; i += (long long)gridDim.x * blockDim.x) {
-        if (mb.twin[i]) continue;
-        mb.troot[i] = -1;
-        atomicAdd(&mb.nt_cnt[cc[i].frame - f0], 1);
+    const int lane = lm_lane();
+    // The twin table is left empty for the next batch: every CC clears the entry of its key (lm_k_mb_twin_probe left the slot in
+    // tkey[]; every inserted key was found there).  A 2 MB memset per batch cost 41 us -- 6.5 ms per 10,000-frame stream.
+    if ((C1 - C0) * 2 <= LM_MB_TTAB)
+        for (long long i = C0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < C1; i += (long long)gridDim.x * blockDim.x)
+            mb.ttab[mb.tkey[i] & (LM_MB_TTAB - 1)] = ~0ull;
+    // The counters of a batch share two cache lines: one atomic per CC serialised in one L2 channel (106 us per 64 dense
+    // frames).  Records are in frame order, so the 64 CCs of a wave belong to one or two frames: one atomic per (wave, frame).
+    for (long long base = C0 + ((long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u)); base < C1; base += (long long)gridDim.x * blockDim.x) {
+        const long long i = base + lane;
+        const bool nt = i < C1 && !mb.twin[i];
+        int fb = -1;
+        if (nt) { mb.troot[i] = -1; fb = cc[i].frame - f0; }
+        unsigned long long todo = __ballot(nt);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int fl = __shfl(fb, leader);
+            const unsigned long long same = __ballot(nt && fb == fl);
+            if (lane == leader) atomicAdd(&mb.nt_cnt[fl], (int)__popcll(same));
+            todo &= ~same;
+        }
     }
 }
 
@@ -916,13 +1000,17 @@ __global__ void __launch_bounds__(256) lm_k_mb_finish(const long long* __restric
 // left it -- entries that died inside the batch are still there, entries that were dead before it were dropped by the
 // prologue.  One 64-bit atomic per workgroup.
 // ------------------------------------------------------------------------------------------------
+// sources filtered per round by lm_k_mb_tempo: 1024 (24 KB of LDS) instead of the joins' 4096 (96 KB with the birth / last-match
+// pairs: two workgroups per CU, and a batch's ~700 tiles took two rounds)
+#define LM_MB_TCHUNK 1024
+
 __global__ void __launch_bounds__(256) lm_k_mb_tempo(const LmCcRec* __restrict__ cc, const long long* __restrict__ frame_cc_off, int f0, int B,
                                                      const unsigned long long* __restrict__ active_box, const int32_t* __restrict__ active_cc,
                                                      const int32_t* __restrict__ active_last, LmCounters* __restrict__ cnt, LmMatchBatch mb,
                                                      int max_gap)
 {
-    __shared__ unsigned long long s_sbox[LM_MB_CHUNK];
-    __shared__ int2 s_sinfo[LM_MB_CHUNK];               // (birth frame, last match)
+    __shared__ unsigned long long s_sbox[LM_MB_TCHUNK];
+    __shared__ int2 s_sinfo[LM_MB_TCHUNK];               // (birth frame, last match)
     __shared__ int s_ub[4];
     __shared__ int s_nsurv;
     __shared__ unsigned long long s_sum;
@@ -953,12 +1041,12 @@ __global__ void __launch_bounds__(256) lm_k_mb_tempo(const LmCcRec* __restrict__
         __syncthreads();
         const unsigned long long ubox = (unsigned long long)(unsigned short)s_ub[0] | ((unsigned long long)(unsigned short)s_ub[1] << 16) |
                                         ((unsigned long long)(unsigned short)s_ub[2] << 32) | ((unsigned long long)(unsigned short)s_ub[3] << 48);
-        for (int base = 0; base < nA; base += LM_MB_CHUNK) {
+        for (int base = 0; base < nA; base += LM_MB_TCHUNK) {
             __syncthreads();
             if (threadIdx.x == 0) s_nsurv = 0;
             __syncthreads();
 #pragma unroll 4
-            for (int k = 0; k < LM_MB_CHUNK / 256; k++) {
+            for (int k = 0; k < LM_MB_TCHUNK / 256; k++) {
                 const int i = base + k * 256 + (int)threadIdx.x;
                 if (i < nA) {
                     const unsigned long long sb = active_box[i];

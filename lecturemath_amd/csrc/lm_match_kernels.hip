@@ -57,9 +57,33 @@ LM_DEV unsigned lm_mix32(unsigned h) { h ^= h >> 16; h *= 0x7feb352du; h ^= h >>
 // E2: emit kept-CC records and their bit crops; grid.y = frame in batch.
 // Work is distributed over the CROP WORDS of the frame, not over its CCs: after an hour of lecture most of the ink belongs to
 // a few large components (crops of 10^4..10^5 words) next to hundreds of glyph-sized ones, and a wave per CC left the GPU to
-// one wave.  A wave takes 64 consecutive words of the frame's crop space; lane 0's word is located in the ascending
-// kept_cropoff[] by binary search, the other lanes walk forward from there (a CC has at least a few words).
+// one wave.
+// Round 3: a workgroup takes a CONTIGUOUS range of the frame's crop words.  Before, every wave located its 64 words on its own --
+// a binary search over kept_cropoff[] in L2 (10 dependent loads), then label -> box -> image word -> run tables -> final labels,
+// ~16 dependent memory latencies for one word per lane (155 us per 64 dense 1080p frames, the waves parked 82 % of their time).
+// Now the workgroup finds its first CC with a 256-way search (two rounds), stages the descriptors of the next LM_EM_WIN kept CCs in
+// LDS once (offset, label, box), and every thread handles LM_EM_UNR words whose loads are issued together, phase by phase:
+// image words, then run tables, then the final labels of the pieces (consecutive run ids: one batch of loads, not a chain).
 // ------------------------------------------------------------------------------------------------
+#define LM_EM_WIN 256       // kept CCs whose descriptors a workgroup stages per window
+#ifndef LM_EM_UNR
+#define LM_EM_UNR 4         // crop words per thread and pass
+#endif
+#define LM_EM_PRE 4         // final labels fetched ahead per crop word (its pieces have consecutive run ids)
+#ifndef LM_EMIT_GRID
+#define LM_EMIT_GRID 128   // workgroups per frame (1024 crop words per workgroup and pass: a dense 1080p frame has ~80 k)
+#endif
+
+// number of leading entries t = 0 .. 255 whose flag is set (flags are a prefix: the probed table ascends); every thread calls
+LM_DEV int lm_em_count256(bool flag, int* s_cnt4)
+{
+    const unsigned long long bal = __ballot(flag);
+    __syncthreads();            // s_cnt4 free again
+    if (lm_lane() == 0) s_cnt4[threadIdx.x >> 6] = (int)__popcll(bal);
+    __syncthreads();
+    return s_cnt4[0] + s_cnt4[1] + s_cnt4[2] + s_cnt4[3];
+}
+
 __global__ void __launch_bounds__(256) lm_k_emit(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
                                                  const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowoff,
                                                  const int32_t* __restrict__ final_label, const int32_t* __restrict__ st_min_y,
@@ -71,6 +95,10 @@ __global__ void __launch_bounds__(256) lm_k_emit(const uint64_t* __restrict__ bi
                                                  const unsigned long long* __restrict__ batch_word_base, LmCcRec* __restrict__ cc,
                                                  uint32_t* __restrict__ crop, uint32_t* __restrict__ chash, int first_frame, int WW, int H, int cap)
 {
+    __shared__ unsigned s_off[LM_EM_WIN + 1];
+    __shared__ int4 s_d[LM_EM_WIN];         // x = label - 1, y = min_x | max_x << 16, z = min_y, w = words per crop row
+    __shared__ unsigned s_hash[LM_EM_WIN];  // crop-hash contributions of this workgroup's words, per CC of the window
+    __shared__ int s_cnt4[4];
     const int b = blockIdx.y;
     const long long cc_base = batch_cc_base[b];
     if (cc_base < 0) return;    // capacity error raised by lm_k_batch_offsets
@@ -93,63 +121,155 @@ __global__ void __launch_bounds__(256) lm_k_emit(const uint64_t* __restrict__ bi
         r.pad = 0;
         cc[cc_base + k] = r;
     }
-    // ---- crops: one lane per crop word
-    const int lane = lm_lane();
-    const unsigned wave = (unsigned)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (unsigned)((gridDim.x * blockDim.x) >> 6);
-    for (unsigned w0 = wave * 64u; w0 < nwords; w0 += nwaves * 64u) {
-        int lo = 0, hi = nk;                // largest k with coffs[k] <= w0 (coffs[0] == 0)
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (coffs[mid] <= w0) lo = mid; else hi = mid;
+    // ---- crops: this workgroup's words [wb0, wb1) of the frame
+    constexpr unsigned STEP = 256u * LM_EM_UNR;
+    const unsigned per = (((nwords + gridDim.x - 1) / gridDim.x + STEP - 1) / STEP) * STEP;
+    const unsigned long long wb0l = (unsigned long long)blockIdx.x * per;
+    if (nk <= 0 || wb0l >= nwords) return;          // uniform in the workgroup
+    const unsigned wb0 = (unsigned)wb0l;
+    const unsigned wb1 = (nwords - wb0 < per) ? nwords : wb0 + per;
+    const int tid = (int)threadIdx.x, lane = lm_lane();
+    // largest k with coffs[k] <= wb0 (coffs[0] == 0): 256-way search, every round one load per thread
+    int klo = 0;
+    for (int len = nk; len > 1;) {
+        const int stride = (len + 255) >> 8;
+        const bool in = (long long)tid * stride < len;
+        const int c = lm_em_count256(in && coffs[klo + tid * stride] <= wb0, s_cnt4);       // >= 1
+        klo += (c - 1) * stride;
+        len = (len - (c - 1) * stride < stride) ? len - (c - 1) * stride : stride;
+    }
+    for (unsigned cur = wb0; cur < wb1;) {
+        // window: descriptors of kept CCs klo .. klo + nwin - 1; s_off[nwin ..] = where the next CC's words begin
+        const int nwin = (nk - klo < LM_EM_WIN) ? nk - klo : LM_EM_WIN;
+        __syncthreads();        // the previous window has been read
+        const unsigned wnext = (klo + nwin < nk) ? coffs[klo + nwin] : nwords;
+        if (tid < nwin) {
+            const int l0 = kept_label[off + klo + tid];
+            s_off[tid] = coffs[klo + tid];
+            const int mnx = st_min_x[off + l0], mxx = st_max_x[off + l0];
+            s_d[tid] = make_int4(l0, mnx | (mxx << 16), st_min_y[off + l0], (mxx >> 5) - (mnx >> 5) + 1);
+        } else {
+            s_off[tid] = wnext;
         }
-        const unsigned w = w0 + (unsigned)lane;
-        const bool live = w < nwords;
-        unsigned contrib = 0;
-        int k = lo;
-        if (live) {
-            while (k + 1 < nk && coffs[k + 1] <= w) k++;
-            const int l0 = kept_label[off + k];
-            const int mnx = st_min_x[off + l0], mxx = st_max_x[off + l0], mny = st_min_y[off + l0];
-            const int wx0 = mnx >> 5;
-            const int nw = (mxx >> 5) - wx0 + 1;
-            const int idx = (int)(w - coffs[k]);
-            const int r = idx / nw, j = idx - r * nw;
-            const int wx = wx0 + j;
-            const long long row = (long long)b * H + mny + r;
-            const long long rw = row * WW + (wx >> 1);
-            const int half = wx & 1;
-            unsigned b32 = (unsigned)(bits[rw] >> (32 * half));
-            const int x_lo = wx * 32;
-            // clip to the box in x
-            unsigned m = 0xffffffffu;
-            if (mnx > x_lo) m &= 0xffffffffu << (mnx - x_lo);
-            if (mxx < x_lo + 31) m &= 0xffffffffu >> (x_lo + 31 - mxx);
-            b32 &= m;
-            unsigned out = 0;
-            if (b32) {
-                const unsigned long long s = starts[rw];
-                const int idbase = (int)rowoff[row] + (int)prefix[rw] - 1;
-                unsigned rem = b32;
-                while (rem) {
-                    const int lo2 = __ffs((int)rem) - 1;
-                    const unsigned t = ~(rem >> lo2);
-                    int len = t ? (__ffs((int)t) - 1) : 32;
-                    if (len > 32 - lo2) len = 32 - lo2;
-                    const unsigned piece = ((len >= 32) ? 0xffffffffu : ((1u << len) - 1u)) << lo2;
-                    const int id = idbase + __popcll(s & lm_lowmask_incl(half * 32 + lo2));
-                    if (fin[id] == l0 + 1) out |= piece;
-                    rem &= ~piece;
+        s_hash[tid] = 0;
+        if (tid == 0) s_off[LM_EM_WIN] = wnext;
+        __syncthreads();
+        const unsigned wend = wnext < wb1 ? wnext : wb1;
+        for (unsigned w0 = cur + (unsigned)(tid & ~63) * LM_EM_UNR; w0 < wend; w0 += STEP) {       // wave-uniform trip count
+            // the CCs of the wave's first and last word: entries of the window at or below them, counted by ballots (scalar)
+            const unsigned wlast = (wend - w0 < 64u * LM_EM_UNR) ? wend - 1 : w0 + 64u * LM_EM_UNR - 1;
+            int jf = -1, jl = -1;
+#pragma unroll
+            for (int t = 0; t < LM_EM_WIN / 64; t++) {
+                const unsigned o = s_off[t * 64 + lane];
+                jf += (int)__popcll(__ballot(o <= w0));
+                jl += (int)__popcll(__ballot(o <= wlast));
+            }
+            bool live[LM_EM_UNR];
+            int jj[LM_EM_UNR], idx[LM_EM_UNR], half[LM_EM_UNR], l0[LM_EM_UNR];
+            long long row[LM_EM_UNR], rw[LM_EM_UNR];
+            unsigned msk[LM_EM_UNR], b32[LM_EM_UNR];
+            // phase A: locate the words (LDS), request the image words
+#pragma unroll
+            for (int u = 0; u < LM_EM_UNR; u++) {
+                const unsigned w = w0 + (unsigned)(u * 64 + lane);
+                live[u] = w < wend;
+                jj[u] = jf; idx[u] = 0; half[u] = 0; l0[u] = 0; row[u] = 0; rw[u] = 0; msk[u] = 0; b32[u] = 0;
+                if (live[u]) {
+                    int j = jf;
+                    if (jf != jl)       // several CCs in the wave's words: walk forward from the first (s_off[nwin] stops the walk)
+                        while (s_off[j + 1] <= w) j++;
+                    jj[u] = j;
+                    const int4 d = s_d[j];
+                    l0[u] = d.x;
+                    const int mnx = d.y & 0xffff, mxx = (int)((unsigned)d.y >> 16), mny = d.z, nw = d.w;
+                    const int wx0 = mnx >> 5;
+                    idx[u] = (int)(w - s_off[j]);
+                    // row and column of the word in the crop: idx / nw by reciprocal (exact after one correction below 2^22), else by division
+                    int r;
+                    if (idx[u] < (1 << 22)) {
+                        r = (int)((float)idx[u] * (1.0f / (float)nw));
+                        const int rem = idx[u] - r * nw;
+                        r += (rem >= nw) ? 1 : ((rem < 0) ? -1 : 0);
+                    } else {
+                        r = idx[u] / nw;
+                    }
+                    const int wx = wx0 + (idx[u] - r * nw);
+                    row[u] = (long long)b * H + mny + r;
+                    rw[u] = row[u] * WW + (wx >> 1);
+                    half[u] = wx & 1;
+                    const int x_lo = wx * 32;
+                    unsigned m = 0xffffffffu;           // clip to the box in x
+                    if (mnx > x_lo) m &= 0xffffffffu << (mnx - x_lo);
+                    if (mxx < x_lo + 31) m &= 0xffffffffu >> (x_lo + 31 - mxx);
+                    msk[u] = m;
                 }
             }
-            crop[wbase + w] = out;
-            contrib = lm_mix32(out + 0x9e3779b9u * (unsigned)idx);
+#pragma unroll
+            for (int u = 0; u < LM_EM_UNR; u++)
+                if (live[u]) b32[u] = (unsigned)(bits[rw[u]] >> (32 * half[u])) & msk[u];
+            // phase B: run tables of the non-empty words
+            unsigned long long sw[LM_EM_UNR];
+            int idfirst[LM_EM_UNR];
+#pragma unroll
+            for (int u = 0; u < LM_EM_UNR; u++) {
+                sw[u] = 0; idfirst[u] = 0;
+                if (b32[u]) {
+                    sw[u] = starts[rw[u]];
+                    idfirst[u] = (int)rowoff[row[u]] + (int)prefix[rw[u]] - 1;
+                }
+            }
+            // phase C: final labels of the first LM_EM_PRE pieces of every word.  A piece's run id = idbase + run starts at or
+            // left of its first pixel; a later piece of the same word begins with a start bit: consecutive ids.
+            int labs[LM_EM_UNR][LM_EM_PRE], npieces[LM_EM_UNR];
+#pragma unroll
+            for (int u = 0; u < LM_EM_UNR; u++) {
+                npieces[u] = 0;
+                if (b32[u]) {
+                    const int lo2 = __ffs((int)b32[u]) - 1;
+                    idfirst[u] += __popcll(sw[u] & lm_lowmask_incl(half[u] * 32 + lo2));
+                    npieces[u] = __popc(b32[u] & ~(b32[u] << 1));
+                }
+#pragma unroll
+                for (int q = 0; q < LM_EM_PRE; q++) labs[u][q] = (q < npieces[u]) ? fin[idfirst[u] + q] : 0;
+            }
+            // phase D: keep the pieces of this CC, store, hash.  With the first pixels of the wanted pieces in `pick`, adding
+            // `pick` to the word clears exactly those pieces (a carry runs through a piece and stops in the gap behind it).
+            unsigned acc = 0;
+#pragma unroll
+            for (int u = 0; u < LM_EM_UNR; u++) {
+                unsigned contrib = 0;
+                if (live[u]) {
+                    const unsigned want = (unsigned)(l0[u] + 1);
+                    unsigned firsts = b32[u] & ~(b32[u] << 1), pick = 0;
+#pragma unroll
+                    for (int q = 0; q < LM_EM_PRE; q++) {
+                        const unsigned fq = firsts & (0u - firsts);
+                        pick |= ((unsigned)labs[u][q] == want) ? fq : 0u;
+                        firsts ^= fq;
+                    }
+                    for (int q = LM_EM_PRE; firsts; q++) {      // words with more pieces than were fetched ahead
+                        const unsigned fq = firsts & (0u - firsts);
+                        pick |= ((unsigned)fin[idfirst[u] + q] == want) ? fq : 0u;
+                        firsts ^= fq;
+                    }
+                    const unsigned out = b32[u] & (b32[u] ^ (b32[u] + pick));
+                    crop[wbase + w0 + (unsigned)(u * 64 + lane)] = out;
+                    contrib = lm_mix32(out + 0x9e3779b9u * (unsigned)idx[u]);
+                }
+                // crop hash for the twin detection, gathered per CC in LDS (global atomics on a CC's one hash word, one per crop word
+                // or even per wave, were half of this kernel's time): the words of the wave's first CC (all of them in a large
+                // component's waves) add up in registers first
+                if (live[u] && jj[u] != jf) atomicAdd(&s_hash[jj[u]], contrib);
+                else acc += contrib;
+            }
+            acc = lm_wave_sum(acc);
+            if (lane == 0) atomicAdd(&s_hash[jf], acc);
         }
-        // crop hash for the twin detection: the lanes that share lane 0's CC (nearly all of a large component's waves) add up
-        // in the wave, the others add on their own
-        const bool same = live && k == lo;
-        const unsigned wsum = lm_wave_sum(same ? contrib : 0u);
-        if (lane == 0 && live) atomicAdd(&chash[cc_base + lo], wsum);
-        if (live && !same) atomicAdd(&chash[cc_base + k], contrib);
+        __syncthreads();
+        if (tid < nwin && s_hash[tid]) atomicAdd(&chash[cc_base + klo + tid], s_hash[tid]);        // other workgroups hold the CC's other words
+        cur = wend;
+        klo += nwin;
     }
 }
 

@@ -119,6 +119,15 @@ def test_stream_large_components(emu_lib, oracle_built):
     lm_checks.check_stream_large_components(emu_lib, n_frames=8)
 
 
+def test_stream_many_small_ccs(emu_lib, oracle_built):
+    """~1,000 kept CCs and ~1,300 crop words per frame: lm_k_emit's workgroups start in the middle of the frame's crop words
+    (two-round 256-way search for their first CC) and walk through several windows of staged CC descriptors; lm_k_select
+    passes over more than one wave of labels per thread group; lm_k_mb_twin_cmp's workgroups likewise."""
+    frames = lm_checks.churn_stream(n_frames=5, empty_every=3)
+    r = lm_checks.check_stream_oracle(emu_lib, frames, max_gap=3, max_batch=5, max_ccs=1 << 14, max_crop_words=1 << 16)
+    assert max(len(x) for x in r["cc_idx_per_frame"]) > 600
+
+
 def test_stream_threshold_edges(emu_lib, oracle_built):
     lm_checks.check_stream_threshold_edges(emu_lib)
 

@@ -2,7 +2,7 @@
 """The two chains of steps 01-02 ALONE on the 10,000-frame bench stream (for rocprofv3 --kernel-trace --stats): first the wide chain
 (logits -> labels -> stats -> records / crops, no matching), then the temporal matching of the whole stream in batches of 64, then
 step 03 + rendering.  Wall times per chain are printed; per-kernel averages come from the trace.
-    python tools/chain_profile.py [frames]"""
+    python tools/chain_profile.py [frames [first frame of the stream to take]]      LM_VARIANT_LIB=<path of another build of the library>"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,8 +11,9 @@ import bench
 from lecturemath_amd import _lib, device, synth
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 H, W, B = 1080, 1920, 64
-lib = _lib.load()
-logits = bench.make_logits(torch, synth, F, H, W, 20213, 0, F)
+F0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+lib = _lib.load(os.environ.get("LM_VARIANT_LIB"))
+logits = bench.make_logits(torch, synth, F0 + F, H, W, 20213, F0, F0 + F)
 fs = device.FrameStream(W, H, F, 0.85, 0.85, 85, 20, max_batch=B, max_ccs=F * 4096, max_crop_words=F * max(1 << 17, (W * H) // 16), lib=lib)
 labels = torch.empty((B, H, W), dtype=torch.int32, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
