@@ -489,11 +489,12 @@ def main():
     # runs on the slot's own normal-priority stream behind an event per batch, under the wide kernels of the next batches.
     # (The streams must differ in priority: with both high the runtime puts them on one hardware queue and nothing overlaps.)
     s_wide = torch.cuda.Stream(priority=-1 if prio == "front" else 0)
+    back_prio = int(os.environ.get("LM_BENCH_BACK_PRIO", "0"))      # priority of the step-03 streams
     slots = []
     for _ in range(depth):
         fs = device.FrameStream(W, H, cap_frames, 0.85, 0.85, 85, 20, max_batch=B, max_ccs=max_ccs, max_crop_words=max_words, lib=lib)
         slots.append({"fs": fs, "clean": torch.empty((B, H, W), dtype=torch.uint8, device="cuda"),
-                      "s_match": torch.cuda.Stream(priority=0), "s_back": torch.cuda.Stream(priority=0),
+                      "s_match": torch.cuda.Stream(priority=0), "s_back": torch.cuda.Stream(priority=back_prio),
                       "done": torch.cuda.Event(), "rdone": torch.cuda.Event(), "gr": None, "recorded": []})
     # binary frames and the label image live for one batch: written by threshold / the labeller, consumed in order on s_wide
     binary = torch.empty((B, H, W), dtype=torch.uint8, device="cuda")

@@ -603,6 +603,7 @@ extern "C" void lm_stream_destroy(LmStream* s)
     free(s->run_events);
     if (s->rd_scratch) (void)hipFree(s->rd_scratch);
     if (s->garena) (void)hipFree(s->garena);
+    if (s->gpin) (void)hipHostFree(s->gpin);
     delete s;
 }
 
@@ -908,8 +909,14 @@ extern "C" int lm_stream_run_logits(LmStream* s, const float* d_logits, int n_fr
     // events of batch k: 3k = labelled, 3k + 1 = records appended, 3k + 2 = its matching has reached the replay kernel
     hipEvent_t* ev = s->run_events;
     int prev_n = 0;
+    // LM_RUN_AHEAD=R (two-stream forms): the launch loop stays at most R batches ahead of the GPU (it waits for the records of batch
+    // k - R before it enqueues batch k).  A stream's ~4,500 launches enqueued at once fill the hardware queues for >100 ms; kernels
+    // that another host thread submits meanwhile (step 03 of the previous stream) on a stream that shares a hardware queue with this
+    // one's wait behind all of them.  0 (default) = no limit.
+    static const int run_ahead = [] { const char* e = getenv("LM_RUN_AHEAD"); return (e && atoi(e) > 0) ? atoi(e) : 0; }();
     for (int k = 0, f0 = 0; f0 < n_frames; f0 += batch, k++) {
         const int n = (n_frames - f0 < batch) ? n_frames - f0 : batch;
+        if (two && run_ahead > 0 && k >= run_ahead) LM_HIP(hipEventSynchronize(ev[3 * (k - run_ahead) + 1]));
         if (gated && k >= 2) LM_HIP(hipStreamWaitEvent(sw, ev[3 * (k - 2) + 2], 0));       // the wide kernels of matching k-2 are through
         int rc = lm_label_batch_logits(s->ctx, d_logits + (size_t)f0 * px, n, thr, 1, d_binary, d_labels, stream_wide);
         if (rc) return rc;

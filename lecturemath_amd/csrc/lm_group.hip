@@ -963,6 +963,8 @@ struct LmGroups {
     char* pin = nullptr;                        // pinned host staging (D2H / H2D at PCIe rate instead of the pageable path)
     size_t pin_cap = 0, pin_used = 0;
     std::vector<void*> pin_owned;
+    bool pin_cached = false;
+    size_t pin_want = 0;
 };
 
 // Device memory for one lm_group_run: bump allocation from the arena, hipMalloc only for what does not fit.
@@ -985,6 +987,7 @@ static void* lm_galloc(LmGroups* g, size_t bytes)
 static void* lm_gpin(LmGroups* g, size_t bytes)
 {
     const size_t need = (bytes + 255) & ~(size_t)255;
+    g->pin_want += need;
     if (g->pin && g->pin_used + need <= g->pin_cap) {
         void* p = g->pin + g->pin_used;
         g->pin_used += need;
@@ -1033,7 +1036,20 @@ extern "C" void lm_group_destroy(LmGroups* g)
     if (!g) return;
     for (void* p : g->d_owned) (void)hipFree(p);
     for (void* p : g->pin_owned) (void)hipHostFree(p);
-    if (g->pin) (void)hipHostFree(g->pin);
+    if (g->pin) {
+        LmStream* s = g->s;
+        if (g->pin_cached) {
+            s->gpin_busy = 0;
+            if (g->pin_want > s->gpin_bytes) {              // grow for the next run
+                (void)hipHostFree(s->gpin);
+                s->gpin = nullptr; s->gpin_bytes = 0;
+                const size_t want = g->pin_want + g->pin_want / 4;
+                if (hipHostMalloc(&s->gpin, want) == hipSuccess) s->gpin_bytes = want;
+            }
+        } else {
+            (void)hipHostFree(g->pin);
+        }
+    }
     if (g->arena) {
         LmStream* s = g->s;
         if (g->arena_cached) {
@@ -1129,8 +1145,15 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
     g->n_frames = F;
     g->n_uniq0 = nU0;
     {   // pinned staging for this run: the assignments down, the tables up
+        // (the stream keeps the block between runs: hipHostMalloc / hipHostFree of ~100 MB per run cost milliseconds and, like
+        // hipMalloc / hipFree, wait for every queue of the device -- in a pipeline, for the other stream's whole backlog)
         const size_t want = (size_t)std::max<long long>(n_cc, 1) * 16 + ((size_t)F + 1) * 64 + ((size_t)4 << 20);
-        if (hipHostMalloc((void**)&g->pin, want) == hipSuccess) g->pin_cap = want;
+        if (!s->gpin_busy) {
+            if (!s->gpin && hipHostMalloc(&s->gpin, want) == hipSuccess) s->gpin_bytes = want;
+            if (s->gpin) { g->pin = (char*)s->gpin; g->pin_cap = s->gpin_bytes; g->pin_cached = true; s->gpin_busy = 1; }
+        } else if (hipHostMalloc((void**)&g->pin, want) == hipSuccess) {
+            g->pin_cap = want;
+        }
     }
     // ---- what the host bookkeeping needs of the records: the unique every CC was assigned to and its frame (the frame
     // follows from the per-frame offsets)

@@ -219,14 +219,13 @@ __global__ void __launch_bounds__(1024) lm_k_mb_nt(const long long* __restrict__
 // filtered against the tile's union box (CCs are in raster order of their first pixel, so 64 consecutive ones cover a
 // thin strip of the frame).
 // ------------------------------------------------------------------------------------------------
+// largest b < B with ftile[b] <= t (frames without CCs own no tile and are skipped).  B <= 64: one entry per lane and a ballot -- one
+// memory latency instead of the six of a binary search (every wave of the workgroup calls; ftile[0] == 0 <= t)
 LM_DEV int lm_mb_tile_frame(const int32_t* __restrict__ ftile, int B, int t)
 {
-    int lo = 0, hi = B;       // largest b with ftile[b] <= t (frames without CCs own no tile and are skipped by the search)
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (ftile[mid] <= t) lo = mid; else hi = mid;
-    }
-    return lo;
+    const int lane = lm_lane();
+    const unsigned long long le = __ballot(lane < B && ftile[lane] <= t);
+    return 63 - __clzll((long long)le);
 }
 
 template <int SRC, int FILL>
@@ -1050,10 +1049,11 @@ __global__ void __launch_bounds__(256) lm_k_mb_tempo(const LmCcRec* __restrict__
                 const int i = base + k * 256 + (int)threadIdx.x;
                 if (i < nA) {
                     const unsigned long long sb = active_box[i];
-                    if (lm_box_hit_packed(ubox, sb)) {
-                        const int last = active_last[i];
-                        const int born = cc[active_cc[i]].frame;
-                        if (born < f && lm_mb_alive(f, last, max_gap)) {        // the same for every CC of the tile (one frame)
+                    const int last = active_last[i];            // requested with the box (coalesced): one latency less on the hit path
+                    const int ucc = active_cc[i];
+                    if (lm_box_hit_packed(ubox, sb) && lm_mb_alive(f, last, max_gap)) {
+                        const int born = cc[ucc].frame;
+                        if (born < f) {        // the same for every CC of the tile (one frame)
                             const int slot = atomicAdd(&s_nsurv, 1);
                             s_sbox[slot] = sb;
                             s_sinfo[slot] = make_int2(born, last);

@@ -58,6 +58,9 @@ struct LmStream {
     void* garena;               // cached bump arena handed to lm_group_run
     size_t garena_bytes;
     int garena_busy;
+    void* gpin;                 // cached pinned staging handed to lm_group_run (hipHostMalloc / hipHostFree wait for the whole device)
+    size_t gpin_bytes;
+    int gpin_busy;
     struct LmMatchBatch* mb;    // tables of the batched matcher (lm_match_batch.hip); host struct holding device pointers
     int last_match_frames;      // frames in the last batch handed to the batched matcher (lm_stream_match_stats)
     int match_per_frame;        // 1: one lm_k_match + lm_k_update per frame (LM_MATCH_PER_FRAME=1), 0: batched matcher
