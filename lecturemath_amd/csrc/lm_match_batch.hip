@@ -86,6 +86,31 @@ struct LmMatchBatch {
 
 LM_DEV bool lm_mb_alive(int f, int last, int max_gap) { return f <= 1 || (f - 1) - last < max_gap; }
 
+// Box test of the join inner loops on packed 16-bit lanes.  A CC's box goes in as (x0, -x1 | y0, -y1), a source's as (x1, -x0 | y1, -y0):
+// the boxes intersect iff all four 16-bit differences source - cc are >= 0 (x1' - x0 >= 0, x1 - x0' >= 0, the same in y) -- two packed
+// subtractions, an OR and a sign test instead of unpacking eight fields (the loops were VALU bound: 28 of lm_k_mb_tempo's 54 us).
+// Coordinates are int16 >= 0, so no difference overflows.
+typedef short lm_s16x2 __attribute__((ext_vector_type(2)));
+struct alignas(16) lm_u64x2 { unsigned long long x, y; };
+LM_DEV unsigned long long lm_box_as_cc(unsigned long long b)
+{
+    const unsigned x0 = (unsigned)(b & 0xffff), x1 = (unsigned)((b >> 16) & 0xffff), y0 = (unsigned)((b >> 32) & 0xffff), y1 = (unsigned)(b >> 48);
+    return (unsigned long long)(x0 | ((0u - x1) << 16)) | ((unsigned long long)(y0 | ((0u - y1) << 16)) << 32);
+}
+LM_DEV unsigned long long lm_box_as_src(unsigned long long b)
+{
+    const unsigned x0 = (unsigned)(b & 0xffff), x1 = (unsigned)((b >> 16) & 0xffff), y0 = (unsigned)((b >> 32) & 0xffff), y1 = (unsigned)(b >> 48);
+    return (unsigned long long)(x1 | ((0u - x0) << 16)) | ((unsigned long long)(y1 | ((0u - y0) << 16)) << 32);
+}
+LM_DEV bool lm_box_hit_pk(unsigned long long c, unsigned long long u)
+{
+    const lm_s16x2 dx = __builtin_bit_cast(lm_s16x2, (unsigned)u) - __builtin_bit_cast(lm_s16x2, (unsigned)c);
+    const lm_s16x2 dy = __builtin_bit_cast(lm_s16x2, (unsigned)(u >> 32)) - __builtin_bit_cast(lm_s16x2, (unsigned)(c >> 32));
+    return ((__builtin_bit_cast(unsigned, dx) | __builtin_bit_cast(unsigned, dy)) & 0x80008000u) == 0u;
+}
+// a source entry no CC box intersects (x0 = 32767 is right of every box narrower than that)
+#define LM_BOX_SRC_NEVER ((unsigned long long)(0u | ((0u - 32767u) << 16)) | ((unsigned long long)(0u | ((0u - 32767u) << 16)) << 32))
+
 // ------------------------------------------------------------------------------------------------
 // P: first part of lm_k_mb_nt (one block).
 // ------------------------------------------------------------------------------------------------
@@ -268,7 +293,7 @@ __global__ void __launch_bounds__(256) lm_k_mb_join(const LmCcRec* __restrict__ 
         const long long my_cc = have ? (long long)mb.nt_list[k_first + ccl] : 0;
         if (have) {
             const LmCcRec r = cc[my_cc];
-            mybox = lm_pack_box(r);
+            mybox = lm_box_as_cc(lm_pack_box(r));
             if (q == 0) {
                 atomicMin(&s_ub[0], (int)r.min_x); atomicMax(&s_ub[1], (int)r.max_x);
                 atomicMin(&s_ub[2], (int)r.min_y); atomicMax(&s_ub[3], (int)r.max_y);
@@ -298,7 +323,7 @@ __global__ void __launch_bounds__(256) lm_k_mb_join(const LmCcRec* __restrict__ 
                         const unsigned long long sb = src_box[i];
                         if (lm_box_hit_packed(ubox, sb)) {
                             const int slot = atomicAdd(&s_nsurv, 1);
-                            s_sbox[slot] = sb;
+                            s_sbox[slot] = lm_box_as_src(sb);
                             s_spos[slot] = i;
                         }
                     }
@@ -307,7 +332,7 @@ __global__ void __launch_bounds__(256) lm_k_mb_join(const LmCcRec* __restrict__ 
                 const int ns = s_nsurv;
                 // the wave's trip count is uniform (q and ns are), so the hits of one trip can share one LDS slot allocation
                 for (int j = q; j < ns; j += 4) {
-                    const bool hit = have && lm_box_hit_packed(mybox, s_sbox[j]);
+                    const bool hit = have && lm_box_hit_pk(mybox, s_sbox[j]);
                     if (FILL && pass == 1) {
                         const unsigned long long bal = __ballot(hit);
                         if (bal) {
@@ -999,17 +1024,19 @@ __global__ void __launch_bounds__(256) lm_k_mb_finish(const long long* __restric
 // left it -- entries that died inside the batch are still there, entries that were dead before it were dropped by the
 // prologue.  One 64-bit atomic per workgroup.
 // ------------------------------------------------------------------------------------------------
-// sources filtered per round by lm_k_mb_tempo: 1024 (24 KB of LDS) instead of the joins' 4096 (96 KB with the birth / last-match
-// pairs: two workgroups per CU, and a batch's ~700 tiles took two rounds)
-#define LM_MB_TCHUNK 1024
+// sources filtered per round by lm_k_mb_tempo: the survivors' boxes are all the inner loop needs (the birth / last-match tests are
+// made when a source is listed), so 4096 candidates per round are 32 KB of LDS and the usual active list (2-3 thousand) is ONE
+// round: a header and two memory latencies per tile instead of three rounds of three (45 us alone, 108 us beside the record
+// emission, per 64 dense frames).  The loads of a round are issued together, LM_MB_TUN per thread.
+#define LM_MB_TCHUNK 4096
+#define LM_MB_TUN 8
 
 __global__ void __launch_bounds__(256) lm_k_mb_tempo(const LmCcRec* __restrict__ cc, const long long* __restrict__ frame_cc_off, int f0, int B,
                                                      const unsigned long long* __restrict__ active_box, const int32_t* __restrict__ active_cc,
                                                      const int32_t* __restrict__ active_last, LmCounters* __restrict__ cnt, LmMatchBatch mb,
                                                      int max_gap)
 {
-    __shared__ unsigned long long s_sbox[LM_MB_TCHUNK];
-    __shared__ int2 s_sinfo[LM_MB_TCHUNK];               // (birth frame, last match)
+    __shared__ __attribute__((aligned(16))) unsigned long long s_sbox[LM_MB_TCHUNK + 4];
     __shared__ int s_ub[4];
     __shared__ int s_nsurv;
     __shared__ unsigned long long s_sum;
@@ -1031,7 +1058,7 @@ __global__ void __launch_bounds__(256) lm_k_mb_tempo(const LmCcRec* __restrict__
         const bool have = ccl < ncc;
         if (have) {
             const LmCcRec r = cc[c_first + ccl];
-            mybox = lm_pack_box(r);
+            mybox = lm_box_as_cc(lm_pack_box(r));
             if (q == 0) {
                 atomicMin(&s_ub[0], (int)r.min_x); atomicMax(&s_ub[1], (int)r.max_x);
                 atomicMin(&s_ub[2], (int)r.min_y); atomicMax(&s_ub[3], (int)r.max_y);
@@ -1040,36 +1067,66 @@ __global__ void __launch_bounds__(256) lm_k_mb_tempo(const LmCcRec* __restrict__
         __syncthreads();
         const unsigned long long ubox = (unsigned long long)(unsigned short)s_ub[0] | ((unsigned long long)(unsigned short)s_ub[1] << 16) |
                                         ((unsigned long long)(unsigned short)s_ub[2] << 32) | ((unsigned long long)(unsigned short)s_ub[3] << 48);
+#if defined(LM_TEMPO_CUT) && LM_TEMPO_CUT == 1
+        mine += ubox & 1ull; continue;
+#endif
         for (int base = 0; base < nA; base += LM_MB_TCHUNK) {
             __syncthreads();
             if (threadIdx.x == 0) s_nsurv = 0;
             __syncthreads();
-#pragma unroll 4
-            for (int k = 0; k < LM_MB_TCHUNK / 256; k++) {
-                const int i = base + k * 256 + (int)threadIdx.x;
-                if (i < nA) {
-                    const unsigned long long sb = active_box[i];
-                    const int last = active_last[i];            // requested with the box (coalesced): one latency less on the hit path
-                    const int ucc = active_cc[i];
-                    if (lm_box_hit_packed(ubox, sb) && lm_mb_alive(f, last, max_gap)) {
-                        const int born = cc[ucc].frame;
-                        if (born < f) {        // the same for every CC of the tile (one frame)
-                            const int slot = atomicAdd(&s_nsurv, 1);
-                            s_sbox[slot] = sb;
-                            s_sinfo[slot] = make_int2(born, last);
-                        }
-                    }
+            for (int k0 = 0; k0 < LM_MB_TCHUNK / 256; k0 += LM_MB_TUN) {
+                if (base + k0 * 256 >= nA) break;           // uniform
+                unsigned long long sb[LM_MB_TUN];
+                int last[LM_MB_TUN], ucc[LM_MB_TUN], born[LM_MB_TUN];
+                bool cand[LM_MB_TUN];
+#pragma unroll
+                for (int u = 0; u < LM_MB_TUN; u++) {
+                    const int i = base + (k0 + u) * 256 + (int)threadIdx.x;
+                    const bool in = i < nA;
+                    sb[u] = in ? active_box[i] : 0ull;
+                    last[u] = in ? active_last[i] : 0;
+                    ucc[u] = in ? active_cc[i] : 0;
+                    cand[u] = in;
                 }
+#pragma unroll
+                for (int u = 0; u < LM_MB_TUN; u++) {
+                    cand[u] = cand[u] && lm_box_hit_packed(ubox, sb[u]) && lm_mb_alive(f, last[u], max_gap);
+                    born[u] = cand[u] ? cc[ucc[u]].frame : 0x7fffffff;
+                }
+#pragma unroll
+                for (int u = 0; u < LM_MB_TUN; u++)
+                    if (cand[u] && born[u] < f) s_sbox[atomicAdd(&s_nsurv, 1)] = lm_box_as_src(sb[u]);        // born / alive: the same for every CC of the tile (one frame)
             }
             __syncthreads();
             const int ns = s_nsurv;
+#if defined(LM_TEMPO_CUT) && (LM_TEMPO_CUT == 2 || LM_TEMPO_CUT == 3)
+            mine += (unsigned long long)ns; continue;
+#endif
+            // the list is padded to a multiple of four; a wave takes four consecutive entries per trip (two 16-byte LDS reads in
+            // flight together -- one entry per trip left every test behind an LDS round trip)
+            if (threadIdx.x < 4) s_sbox[ns + (int)threadIdx.x] = LM_BOX_SRC_NEVER;
+            __syncthreads();
+            unsigned hits = 0;
             if (have)
-                for (int j = q; j < ns; j += 4) mine += lm_box_hit_packed(mybox, s_sbox[j]) ? 1ull : 0ull;
+                for (int j = q * 4; j < ns; j += 16) {
+                    const lm_u64x2 e01 = *(const lm_u64x2*)&s_sbox[j], e23 = *(const lm_u64x2*)&s_sbox[j + 2];
+                    hits += (lm_box_hit_pk(mybox, e01.x) ? 1u : 0u) + (lm_box_hit_pk(mybox, e01.y) ? 1u : 0u) +
+                            (lm_box_hit_pk(mybox, e23.x) ? 1u : 0u) + (lm_box_hit_pk(mybox, e23.y) ? 1u : 0u);
+                }
+            mine += hits;
         }
     }
+#if defined(LM_TEMPO_CUT) && LM_TEMPO_CUT == 2
+    if (mine == 0x123456789ull) cnt->tempo_count = 1;
+    return;
+#endif
     if (threadIdx.x == 0) s_sum = 0;
     __syncthreads();
     if (mine) atomicAdd(&s_sum, mine);
     __syncthreads();
+#if defined(LM_TEMPO_CUT) && LM_TEMPO_CUT == 4
+    if (threadIdx.x == 0 && s_sum == 0x123456789ull) cnt->tempo_count = 1;
+    return;
+#endif
     if (threadIdx.x == 0 && s_sum) atomicAdd(&cnt->tempo_count, s_sum);
 }
