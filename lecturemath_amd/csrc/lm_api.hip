@@ -684,7 +684,7 @@ extern "C" LmStream* lm_stream_create(LmCtx* ctx, int max_frames, int64_t max_cc
         for (int k = 0; k < 2; k++) {
             rc |= lm_alloc(&m->tcount[k], (size_t)m->cap_tiles + 1);
             rc |= lm_alloc(&m->toff[k], (size_t)m->cap_tiles + 1);
-            rc |= lm_alloc(&m->tcur[k], (size_t)m->cap_tiles + 1);
+            rc |= lm_alloc(&m->tcur[k], ((size_t)m->cap_tiles + 1) * LM_MB_JY);
             rc |= lm_alloc(&m->pairs[k], (size_t)m->cap_pairs);
             rc |= lm_alloc(&m->pair_u[k], (size_t)m->cap_pairs);
         }
@@ -751,7 +751,7 @@ static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st, h
         return;
     }
     const LmMatchBatch mb = *s->mb;
-    const dim3 gj(LM_HIP_EMULATED ? 2 : 128, LM_HIP_EMULATED ? 2 : 8), gt(LM_HIP_EMULATED ? 2 : 1024), ge(LM_HIP_EMULATED ? 2 : 2048), gb(LM_HIP_EMULATED ? 2 : 1024);
+    const dim3 gj(LM_HIP_EMULATED ? 2 : 128, LM_HIP_EMULATED ? 2 : LM_MB_JY), gt(LM_HIP_EMULATED ? 2 : 1024), ge(LM_HIP_EMULATED ? 2 : 2048), gb(LM_HIP_EMULATED ? 2 : 1024);
     for (int done = 0; done < n;) {
         const int B = (n - done < LM_MB_MAX_FRAMES) ? n - done : LM_MB_MAX_FRAMES;
         const int f = f0 + done;

@@ -199,11 +199,25 @@ LM_DEV void lm_union_t(int32_t* parent, int a, int b)
     }
 }
 
+// LM_SEAM_HALVE (default 1): the finds of the seam unions halve the paths they walk.  A component that
+// crosses every band of the frame leaves a chain of band roots as long as the frame has bands (34 at 1080p): without compression
+// every contact of a seam row walked it hop by hop through L2 (and the flattening pass after it, run by run).  Plain stores beside the device-
+// scope atomicMin are safe: a node that is re-pointed is not a root and never becomes one again, and what is stored is an ancestor
+// of it in the same set; another XCD may keep reading the older, longer path.
+#ifndef LM_SEAM_HALVE
+#define LM_SEAM_HALVE 1
+#endif
+
 LM_DEV void lm_union(int32_t* parent, int a, int b)
 {
     for (;;) {
+#if LM_SEAM_HALVE
+        a = lm_find_halve(parent, a);
+        b = lm_find_halve(parent, b);
+#else
         a = lm_find(parent, a);
         b = lm_find(parent, b);
+#endif
         if (a == b) return;
         if (a < b) { int t = a; a = b; b = t; }
         int old = atomicMin(&parent[a], b);     // global: device-scope RMW, coherent across XCDs; LDS: ds_min_rtn
@@ -565,6 +579,8 @@ LM_DEV void lm_flatten_body(int b, int band, int nbands, int32_t* __restrict__ p
                 bool flag = false;
                 if (gid[u] >= 0) {
                     int x = gid[u], q = p[u];
+                    // (no path halving here: a node is re-pointed by its owner only, to the root -- a racing halving store could
+                    // put a non-root ancestor back after the owner's store, and lm_k_apply_labels takes par[] as flat)
                     while (q != x) { x = q; q = par[x]; }      // lm_find, continued from the prefetched parent
                     par[gid[u]] = x;
                     flag = (x == gid[u]);
@@ -866,9 +882,17 @@ __global__ void __launch_bounds__(256) lm_k_stats(const uint64_t* __restrict__ b
             id0[c] += first_start;
             npieces = __popcll(sbits[c]) + 1 - first_start;
         }
-#pragma unroll
-        for (int z = 0; z < LM_ST_PRE; z++) labs[c][z] = (z < npieces) ? fin[id0[c] + z] : 0;
+        // (entries behind the cell's last piece are read and ignored: final_label has slack behind its last frame)
+        if (npieces) lm_load4(fin + id0[c], labs[c]);
+        else { labs[c][0] = 0; labs[c][1] = 0; labs[c][2] = 0; labs[c][3] = 0; }
     }
+#if defined(LM_STATS_CUT) && LM_STATS_CUT == 1
+    { int acc = 0;
+#pragma unroll
+      for (int c = 0; c < NC; c++) for (int z = 0; z < LM_ST_PRE; z++) acc += labs[c][z];
+      if (acc == 0x12345678) st_count[0] = 1;
+      return; }
+#endif
 #pragma unroll
     for (int c = 0; c < NC; c++) {
     const int y = blockIdx.y * LM_ST_ROWS + c * 64 + (int)(threadIdx.x >> 2);
@@ -899,6 +923,10 @@ __global__ void __launch_bounds__(256) lm_k_stats(const uint64_t* __restrict__ b
                 }
             }
         }
+#if defined(LM_STATS_CUT) && LM_STATS_CUT == 2
+        if (cnt + mnx + mxx + (int)has_start == 0x12345678) st_count[0] = 1;
+        continue;
+#endif
         // ---- the wave reports (lab, cnt, box) of its lanes
         const bool valid = lab != 0;
         int slot = (int)(((unsigned)lab * 2654435761u) >> 23) & (LM_ST_SLOTS - 1);
@@ -946,6 +974,10 @@ __global__ void __launch_bounds__(256) lm_k_stats(const uint64_t* __restrict__ b
     }
     }
     __syncthreads();
+#if defined(LM_STATS_CUT) && LM_STATS_CUT == 3
+    if (s_cnt[threadIdx.x] == 0x12345678) st_count[0] = 1;
+    return;
+#endif
     for (int i = threadIdx.x; i < LM_ST_SLOTS; i += blockDim.x) {
         const int lab = s_key[i];
         if (!lab) continue;

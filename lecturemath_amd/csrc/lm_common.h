@@ -222,5 +222,14 @@ template <int BLOCK> LM_DEV unsigned lm_block_excl_scan_lds(unsigned v, unsigned
     return res;
 }
 
+// four consecutive int32 from a 4-byte aligned address as ONE load instruction (global_load_dwordx4; gfx950 takes dword-aligned
+// vector loads): a lane that needs the labels of runs id .. id + 3 issues one request instead of four
+typedef int lm_i32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+LM_DEV void lm_load4(const int32_t* p, int (&out)[4])
+{
+    const lm_i32x4_a4 v = *(const lm_i32x4_a4*)p;
+    out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+}
+
 LM_DEV uint64_t lm_lowmask_incl(int p) { return (p >= 63) ? ~0ull : ((1ull << (p + 1)) - 1ull); }
 LM_DEV uint64_t lm_lowmask_excl(int p) { return (p <= 0) ? 0ull : ((p >= 64) ? ~0ull : ((1ull << p) - 1ull)); }

@@ -34,6 +34,7 @@
 #include "lm_stream.h"
 
 #define LM_MB_TILE 64
+#define LM_MB_JY 8              // workgroups that share the sources of one tile in the join launches (gridDim.y, at most)
 #define LM_MB_TTAB (1 << 18)     // twin table slots; batches with more than LM_MB_TTAB / 2 CCs skip twin detection
 #define LM_MB_CHUNK 4096        // source boxes filtered per round (LDS survivors list)
 #define LM_MB_MAX_FRAMES 64     // frames per batch (per-frame tables of the replay kernel live in LDS)
@@ -65,7 +66,7 @@ struct LmMatchBatch {
     int32_t* s_prefix;          // [cap_frames + 2] number of sources that belong to frames before frame b of the batch
     uint32_t* tcount[2];        // [cap_tiles + 1]  pairs per tile (A: vs actives, B: vs in-batch sources)
     uint32_t* toff[2];          // [cap_tiles + 1]  exclusive prefix, toff[nt] = total
-    uint32_t* tcur[2];          // [cap_tiles + 1]  fill cursors (one reservation per workgroup)
+    uint32_t* tcur[2];          // [(cap_tiles + 1) * LM_MB_JY]  hits of every (tile, blockIdx.y) workgroup of the count launch
     uint2* pairs[2];            // x = index in nt_list | accepted << 31, y = active position (A) / source index (B)
     int32_t* pair_u[2];         // cc index of the unique's first-seen CC (what the pair is evaluated against)
     int32_t* sidx;              // [cap_cc] per global cc: -2 undecided, -1 surely matched; after lm_k_mb_sources: k >= 0 index into
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(1024) lm_k_mb_nt(const long long* __restrict__
     }
     __syncthreads();
     const int t0 = s_head[1], t1 = s_head[2] + (b == B - 1 ? 1 : 0);      // this frame's tiles (the last frame also clears entry [n_tiles])
-    for (int t = t0 + (int)threadIdx.x; t < t1 && t <= mb.cap_tiles; t += 1024) { mb.tcount[0][t] = 0; mb.tcount[1][t] = 0; mb.tcur[0][t] = 0; mb.tcur[1][t] = 0; }
+    for (int t = t0 + (int)threadIdx.x; t < t1 && t <= mb.cap_tiles; t += 1024) { mb.tcount[0][t] = 0; mb.tcount[1][t] = 0; }
     const long long C0 = frame_cc_off[f0 + b], C1 = frame_cc_off[f0 + b + 1];
     unsigned carry = (unsigned)s_head[0];
     for (long long base = C0; base < C1; base += 1024 * LM_MB_NT_R) {
@@ -258,7 +259,7 @@ __global__ void __launch_bounds__(256) lm_k_mb_join(const LmCcRec* __restrict__ 
                                                     int B, const unsigned long long* __restrict__ active_box,
                                                     const int32_t* __restrict__ active_cc, LmCounters* __restrict__ cnt, LmMatchBatch mb)
 {
-    __shared__ unsigned long long s_sbox[LM_MB_CHUNK];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_sbox[LM_MB_CHUNK + 4];
     __shared__ int s_spos[LM_MB_CHUNK];
     __shared__ int s_ub[4];
     __shared__ int s_nsurv;
@@ -309,8 +310,15 @@ __global__ void __launch_bounds__(256) lm_k_mb_join(const LmCcRec* __restrict__ 
             if (t == nt - 1) mb.toff[SRC][nt] = off + tc;
         }
         const bool room = !FILL || (unsigned long long)off + tc <= mb.cap_pairs;
-        // FILL runs the hit loop twice: pass 0 counts this workgroup's hits (to reserve its slots with one atomic), pass 1 writes
-        for (int pass = FILL ? 0 : 1; pass < 2; pass++) {
+        // where this workgroup's pairs go inside the tile's range: behind those of the workgroups with a smaller blockIdx.y, whose hit
+        // counts the count launch left in tcur[] (round 2 counted them again here to reserve the slots: the hit loop ran twice)
+        if (FILL && threadIdx.x == 0) {
+            unsigned before = 0;
+            for (unsigned yy = 0; yy < blockIdx.y; yy++) before += mb.tcur[SRC][(size_t)t * LM_MB_JY + yy];
+            s_base = before;
+        }
+        {
+            const int pass = 1;
             unsigned mycount = 0;
             for (int base = s_lo; base < s_hi; base += LM_MB_CHUNK) {
                 __syncthreads();
@@ -330,6 +338,17 @@ __global__ void __launch_bounds__(256) lm_k_mb_join(const LmCcRec* __restrict__ 
                 }
                 __syncthreads();
                 const int ns = s_nsurv;
+                if (!FILL) {        // counting: four entries per trip, the list padded with entries nothing intersects (as lm_k_mb_tempo)
+                    if (threadIdx.x < 4) s_sbox[ns + (int)threadIdx.x] = LM_BOX_SRC_NEVER;
+                    __syncthreads();
+                    if (have)
+                        for (int j = q * 4; j < ns; j += 16) {
+                            const lm_u64x2 e01 = *(const lm_u64x2*)&s_sbox[j], e23 = *(const lm_u64x2*)&s_sbox[j + 2];
+                            mycount += (lm_box_hit_pk(mybox, e01.x) ? 1u : 0u) + (lm_box_hit_pk(mybox, e01.y) ? 1u : 0u) +
+                                       (lm_box_hit_pk(mybox, e23.x) ? 1u : 0u) + (lm_box_hit_pk(mybox, e23.y) ? 1u : 0u);
+                        }
+                    continue;
+                }
                 // the wave's trip count is uniform (q and ns are), so the hits of one trip can share one LDS slot allocation
                 for (int j = q; j < ns; j += 4) {
                     const bool hit = have && lm_box_hit_pk(mybox, s_sbox[j]);
@@ -351,12 +370,12 @@ __global__ void __launch_bounds__(256) lm_k_mb_join(const LmCcRec* __restrict__ 
                     }
                 }
             }
-            if (!(FILL && pass == 1)) {
+            if (!FILL) {
                 if (mycount) atomicAdd(&s_count, mycount);
                 __syncthreads();
                 if (threadIdx.x == 0) {
-                    if (!FILL) { if (s_count) atomicAdd(&mb.tcount[SRC][t], s_count); }
-                    else { s_base = s_count ? atomicAdd(&mb.tcur[SRC][t], s_count) : 0u; s_count = 0; }
+                    if (s_count) atomicAdd(&mb.tcount[SRC][t], s_count);
+                    mb.tcur[SRC][(size_t)t * LM_MB_JY + blockIdx.y] = s_count;
                 }
                 __syncthreads();
             }

@@ -230,8 +230,8 @@ __global__ void __launch_bounds__(256) lm_k_emit(const uint64_t* __restrict__ bi
                     idfirst[u] += __popcll(sw[u] & lm_lowmask_incl(half[u] * 32 + lo2));
                     npieces[u] = __popc(b32[u] & ~(b32[u] << 1));
                 }
-#pragma unroll
-                for (int q = 0; q < LM_EM_PRE; q++) labs[u][q] = (q < npieces[u]) ? fin[idfirst[u] + q] : 0;
+                if (npieces[u]) lm_load4(fin + idfirst[u], labs[u]);       // entries behind the word's last piece are read and ignored
+                else { labs[u][0] = 0; labs[u][1] = 0; labs[u][2] = 0; labs[u][3] = 0; }
             }
             // phase D: keep the pieces of this CC, store, hash.  With the first pixels of the wanted pieces in `pick`, adding
             // `pick` to the word clears exactly those pieces (a carry runs through a piece and stops in the gap behind it).
