@@ -361,14 +361,11 @@ __global__ void __launch_bounds__(256) lm_k_render_items(const long long* __rest
                                                          const int32_t* __restrict__ bounds, const int64_t* __restrict__ gitem_first,
                                                          const int64_t* __restrict__ gbits_off, LmRenderItem* __restrict__ out)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= frame_item_off[F]) return;
-    int lo = 0, hi = F;         // frame of item i: largest f with frame_item_off[f] <= i
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (frame_item_off[mid] <= i) lo = mid; else hi = mid;
-    }
-    const int f = lo, gi = gpf[i];
+    // a workgroup per frame (its items are contiguous); round 2 dealt the items to threads and found each one's frame by a 14-step
+    // binary search over frame_item_off[] in L2 (3 ms for the 10,000-frame stream's four million items)
+    for (int f = blockIdx.x; f < F; f += gridDim.x)
+    for (long long i = frame_item_off[f] + threadIdx.x; i < frame_item_off[f + 1]; i += blockDim.x) {
+    const int gi = gpf[i];
     const int32_t* a = ages + ages_off[gi];
     const int na = ages_off[gi + 1] - ages_off[gi];
     LmRenderItem ri;
@@ -378,11 +375,18 @@ __global__ void __launch_bounds__(256) lm_k_render_items(const long long* __rest
     if (na < 2) {               // no segment image (the reference would raise IndexError at :650 here): an item that hits no tile
         ri.w = 0; ri.h = 0;
     } else {
-        int sidx = 0;
-        while (sidx + 1 < na - 1 && a[sidx + 1] < f) sidx++;
+        // the reference walks `while ages[ptr + 1] < f: ptr += 1` (bounded by the last segment); ages ascend, so that is the number of
+        // k in [1, na - 2] with a[k] < f -- by bisection (a group that was edited fifty times made the walk fifty dependent loads)
+        int lo = 0, hi = na - 1;        // invariant: a[k] < f for 1 <= k <= lo, a[k] >= f for hi <= k <= na - 2 (hi == na - 1: none known)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a[mid] < f) lo = mid; else hi = mid;
+        }
+        const int sidx = lo;
         ri.bits_off = gbits_off[gitem_first[gi] + sidx];
     }
     out[i] = ri;
+    }
 }
 
 __global__ void __launch_bounds__(256) lm_k_render_frames(const long long* __restrict__ frame_item_off,
@@ -391,6 +395,7 @@ __global__ void __launch_bounds__(256) lm_k_render_frames(const long long* __res
 {
     __shared__ unsigned s_pl[8 * LM_RT_PLANE];      // bit-sliced k per pixel (see lm_render_paint)
     __shared__ LmRenderItem s_hit[LM_RT_MAXHIT];
+    __shared__ unsigned s_pre[LM_RT_MAXHIT + 1];
     __shared__ int s_nhit;
     const int f = first_frame + blockIdx.z;
     const int X0 = blockIdx.x * LM_RT_COLS, Y0 = blockIdx.y * LM_RT_ROWS;
@@ -410,8 +415,76 @@ __global__ void __launch_bounds__(256) lm_k_render_frames(const long long* __res
     }
     __syncthreads();
     const int nhit = s_nhit < LM_RT_MAXHIT ? s_nhit : LM_RT_MAXHIT;
-    const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6), lane = lm_lane();
-    for (int h = wave; h < nhit; h += nwaves) lm_render_paint(s_hit[h], X0, Y0, bits, s_pl, lane, 64);
+    // Round 3: the tile words of ALL listed items are dealt to the threads as one flat list (an item per wave left a wave walking
+    // through its items one after the other, two memory latencies each: a tile under a large component and a dozen glyphs took
+    // eight).  s_pre[h] = tile words of the items before h.
+    {
+        const int lane = lm_lane();
+        if (threadIdx.x < 64) {
+            unsigned carry = 0;
+            for (int h0 = 0; h0 < nhit; h0 += 64) {
+                const int h = h0 + lane;
+                unsigned words = 0;
+                if (h < nhit) {
+                    const LmRenderItem it = s_hit[h];
+                    const int xa = it.x0 > X0 ? it.x0 : X0, xb = (it.x0 + it.w < X0 + LM_RT_COLS) ? it.x0 + it.w : X0 + LM_RT_COLS;
+                    const int ya = it.y0 > Y0 ? it.y0 : Y0, yb = (it.y0 + it.h < Y0 + LM_RT_ROWS) ? it.y0 + it.h : Y0 + LM_RT_ROWS;
+                    const int jlo = (xa - X0) >> 5, nw = ((xb - 1 - X0) >> 5) - jlo + 1;
+                    words = (nw > 0 && yb > ya) ? (unsigned)(nw * (yb - ya)) : 0u;
+                }
+                const unsigned incl = lm_wave_incl_scan(words);
+                if (h < nhit) s_pre[h] = carry + incl - words;
+                carry += (unsigned)__shfl((int)incl, 63);
+            }
+            if (lane == 0) s_pre[nhit] = carry;
+        }
+    }
+    __syncthreads();
+    {
+        const unsigned total = s_pre[nhit];
+        for (unsigned g0 = threadIdx.x; g0 < total; g0 += blockDim.x * LM_RT_WPL) {
+            unsigned lo[LM_RT_WPL], hi[LM_RT_WPL];
+            int col[LM_RT_WPL], slot[LM_RT_WPL], xa_[LM_RT_WPL], xb_[LM_RT_WPL], x0_[LM_RT_WPL];
+#pragma unroll
+            for (int u = 0; u < LM_RT_WPL; u++) {
+                const unsigned g = g0 + (unsigned)u * blockDim.x;
+                lo[u] = 0; hi[u] = 0; col[u] = 0; slot[u] = 0; xa_[u] = 0; xb_[u] = 0; x0_[u] = 0;
+                if (g < total) {
+                    int a = 0, b2 = nhit;            // largest h with s_pre[h] <= g
+                    while (b2 - a > 1) {
+                        const int mid = (a + b2) >> 1;
+                        if (s_pre[mid] <= g) a = mid; else b2 = mid;
+                    }
+                    const LmRenderItem it = s_hit[a];
+                    const int xa = it.x0 > X0 ? it.x0 : X0, xb = (it.x0 + it.w < X0 + LM_RT_COLS) ? it.x0 + it.w : X0 + LM_RT_COLS;
+                    const int ya = it.y0 > Y0 ? it.y0 : Y0;
+                    const int bw = (it.w + 31) >> 5;
+                    const int jlo = (xa - X0) >> 5, nw = ((xb - 1 - X0) >> 5) - jlo + 1;
+                    const int idx = (int)(g - s_pre[a]);
+                    int yy = (int)((float)idx * (1.0f / (float)nw));
+                    int j = idx - yy * nw;
+                    if (j < 0) { yy--; j += nw; }
+                    if (j >= nw) { yy++; j -= nw; }
+                    col[u] = X0 + 32 * (jlo + j);                   // frame column of the tile word's bit 0
+                    const int d = col[u] - it.x0;                   // ... and the image column under it (> -32)
+                    const int sw = d >> 5;                          // floor
+                    const uint32_t* r = bits + it.bits_off + (long long)(ya - it.y0 + yy) * bw;
+                    lo[u] = (sw >= 0 && sw < bw) ? r[sw] : 0u;
+                    hi[u] = ((d & 31) && sw + 1 < bw) ? r[sw + 1] : 0u;
+                    slot[u] = (ya - Y0 + yy) * LM_RT_PITCH + jlo + j;
+                    xa_[u] = xa; xb_[u] = xb; x0_[u] = it.x0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < LM_RT_WPL; u++) {
+                const int sh = (col[u] - x0_[u]) & 31;
+                unsigned c = sh ? ((lo[u] >> sh) | (hi[u] << (32 - sh))) : lo[u];
+                if (col[u] < xa_[u]) c &= 0xffffffffu << (xa_[u] - col[u]);             // clip to the tile / item intersection in x
+                if (col[u] + 32 > xb_[u]) c &= 0xffffffffu >> (col[u] + 32 - xb_[u]);
+                for (int p = 0; p < 8 && c; p++) c &= atomicXor(&s_pl[p * LM_RT_PLANE + slot[u]], c);
+            }
+        }
+    }
     __syncthreads();
     uint8_t* dst = out + (long long)blockIdx.z * W * H;
     const bool vec = ((W & 15) == 0) && ((((uintptr_t)out) & 15) == 0);
@@ -562,28 +635,46 @@ __global__ void __launch_bounds__(256) lm_k_bitimg_pair_any(const LmBitImage* __
 //   aov / tov      all_overlapping_cc / time_overlapping_cc rows (:291-304) compacted out of the adjacency in order
 //   strong         tov entries with recall >= min_recall (:336): the only edges compute_groups follows -> host
 // ------------------------------------------------------------------------------------------------
+// Round 3: a wave takes LM_ADJ_R consecutive rows and tests every box it loads against all of them.  One row per wave read the
+// whole box array (650 KB for the 10,000-frame stream's 81 k stable uniques) once per ROW: 53 GB through L2 per launch, 3.5 ms.
+#define LM_ADJ_R 4
+
 template <int FILL>
 __global__ void __launch_bounds__(256) lm_k_adj_rows(const unsigned long long* __restrict__ box, int n, unsigned* __restrict__ cnt_or_off,
                                                      int32_t* __restrict__ adj, int32_t* __restrict__ arow)
 {
     const int lane = lm_lane();
     const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * blockDim.x) >> 6);
-    for (int i = wave; i < n; i += nwaves) {
-        const unsigned long long bi = box[i];
-        const unsigned base = FILL ? cnt_or_off[i] : 0u;
-        unsigned c = 0;
+    for (int i0 = wave * LM_ADJ_R; i0 < n; i0 += nwaves * LM_ADJ_R) {
+        unsigned long long bi[LM_ADJ_R];
+        unsigned base[LM_ADJ_R], c[LM_ADJ_R];
+#pragma unroll
+        for (int r = 0; r < LM_ADJ_R; r++) {
+            const int i = (i0 + r < n) ? i0 + r : n - 1;        // rows past the end repeat the last one; nothing is stored for them
+            bi[r] = box[i];
+            base[r] = FILL ? cnt_or_off[i] : 0u;
+            c[r] = 0;
+        }
         for (int j0 = 0; j0 < n; j0 += 64) {
             const int j = j0 + lane;
-            const bool hit = j < n && j != i && lm_box_hit_packed(bi, box[j]);
-            const unsigned long long m = __ballot(hit);
-            if (FILL && hit) {
-                const unsigned p = base + c + (unsigned)__popcll(m & lm_lowmask_excl(lane));
-                adj[p] = j;
-                arow[p] = i;
+            const unsigned long long bj = box[j < n ? j : n - 1];
+#pragma unroll
+            for (int r = 0; r < LM_ADJ_R; r++) {
+                const bool hit = j < n && j != i0 + r && i0 + r < n && lm_box_hit_packed(bi[r], bj);
+                const unsigned long long m = __ballot(hit);
+                if (FILL && hit) {
+                    const unsigned p = base[r] + c[r] + (unsigned)__popcll(m & lm_lowmask_excl(lane));
+                    adj[p] = j;
+                    arow[p] = i0 + r;
+                }
+                c[r] += (unsigned)__popcll(m);
             }
-            c += (unsigned)__popcll(m);
         }
-        if (!FILL && lane == 0) cnt_or_off[i] = c;
+        if (!FILL && lane == 0) {
+#pragma unroll
+            for (int r = 0; r < LM_ADJ_R; r++)
+                if (i0 + r < n) cnt_or_off[i0 + r] = c[r];
+        }
     }
 }
 
@@ -1283,8 +1374,9 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         // ---- adjacency of the stable uniques (:245-306)
         g->d_adj_off = (unsigned*)lm_galloc(g, ((size_t)nS + 1) * sizeof(unsigned));
         if (!g->d_adj_off) return LM_ERR_HIP;
-        const unsigned row_blocks = lm_gblocks(nS, 4, 4096);       // one wave per row, four rows per workgroup
-        hipLaunchKernelGGL((lm_k_adj_rows<0>), dim3(row_blocks), dim3(256), 0, st, d_sbox, nS, g->d_adj_off, (int32_t*)nullptr, (int32_t*)nullptr);
+        const unsigned row_blocks = lm_gblocks(nS, 4, 4096);       // one wave per row, four rows per workgroup (lm_k_adj_lists)
+        const unsigned join_blocks = lm_gblocks(nS, 4 * LM_ADJ_R, 4096);      // lm_k_adj_rows: LM_ADJ_R rows per wave
+        hipLaunchKernelGGL((lm_k_adj_rows<0>), dim3(join_blocks), dim3(256), 0, st, d_sbox, nS, g->d_adj_off, (int32_t*)nullptr, (int32_t*)nullptr);
         hipLaunchKernelGGL(lm_k_scan_u32, dim3(1), dim3(1024), 0, st, g->d_adj_off, g->d_adj_off, nS, d_tot);
         unsigned long long h_tot[8];
         LM_HIP(hipMemcpyAsync(h_tot, d_tot, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -1301,7 +1393,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
         unsigned* d_str_off = (unsigned*)lm_galloc(g, ((size_t)nS + 1) * sizeof(unsigned));
         if (!g->d_adj || !g->d_arow || !g->d_match || !g->d_aov_off || !g->d_tov_off || !d_str_off) return LM_ERR_HIP;
         tm.mark("adjacency: count + scan", st, true);
-        hipLaunchKernelGGL((lm_k_adj_rows<1>), dim3(row_blocks), dim3(256), 0, st, d_sbox, nS, g->d_adj_off, g->d_adj, g->d_arow);
+        hipLaunchKernelGGL((lm_k_adj_rows<1>), dim3(join_blocks), dim3(256), 0, st, d_sbox, nS, g->d_adj_off, g->d_adj, g->d_arow);
         tm.mark("adjacency: fill", st, true);
         if (ne > 0) {
             hipLaunchKernelGGL(lm_k_adj_match, dim3(lm_gblocks(ne, 16, 8192)), dim3(256), 0, st, s->cc, s->crop, d_scc, g->d_adj, g->d_arow, ne, g->d_match);
@@ -1638,7 +1730,7 @@ static int lm_group_run_impl(LmGroups* g, int reconstruct_tables, hipStream_t st
             if (lm_upload(g, g->gpf, &d_gpf, st) || lm_upload(g, ages_off32, &d_ages_off, st) || lm_upload(g, g->bounds, &d_bounds, st) ||
                 lm_upload(g, g->gbits_off, &d_gbits_off, st))
                 return LM_ERR_HIP;
-            hipLaunchKernelGGL(lm_k_render_items, dim3((unsigned)((n_ritems + 255) / 256)), dim3(256), 0, st, g->d_frame_item_off, F, d_gpf,
+            hipLaunchKernelGGL(lm_k_render_items, dim3(lm_gblocks(F, 1, 16384)), dim3(256), 0, st, g->d_frame_item_off, F, d_gpf,
                                d_ages, d_ages_off, d_bounds, d_gitem_first, d_gbits_off, g->d_render_items);
         }
     }
