@@ -303,6 +303,7 @@ rest:
     hipLaunchKernelGGL(lm_k_band, dim3(nbands, n), dim3(band_threads), band_smem, st, c->bits + w0, c->starts + w0, c->prefix + w0, c->rowcnt + r0,
                        c->rowoff + r0, c->band_runs + b0, c->parent + c0, c->band_fallback + b0, g.H, g.WW, slot, g.cap, lm_debug_band_phases(), magic_ww,
                        c->band_rows, f0 == 0 ? lm_debug_band_stamps(nbands, n) : nullptr);
+    const LmStatInit si = {c->st_min_y + c0, c->st_max_y + c0, c->st_min_x + c0, c->st_max_x + c0, c->st_count + c0, g.W, g.H};
     static const int fused_middle = [] { const char* e = getenv("LM_LABEL_FUSED_MIDDLE"); return e ? atoi(e) : LM_LABEL_FUSED_MIDDLE_DEFAULT; }();
 #if !LM_HIP_EMULATED
     if (fused_middle) {
@@ -311,7 +312,7 @@ rest:
         LM_HIP(hipMemsetAsync(sync, 0, (1 + 2 * (size_t)n) * sizeof(unsigned), st));
         hipLaunchKernelGGL(lm_k_middle, dim3((unsigned)nbands * n), dim3(256), 0, st, c->bits + w0, c->starts + w0, c->prefix + w0, c->rowoff + r0,
                            c->band_fallback + b0, c->parent + c0, c->band_runs + b0, c->rootbits + cw0, c->wordprefix + cw0, c->band_roots + b0,
-                           c->band_base + b0, c->n_labels + f0, c->final_label + c0, g.WW, g.H, g.cap, c->band_rows, slot, capw, nbands, sync, 0u, 0u);
+                           c->band_base + b0, c->n_labels + f0, c->final_label + c0, g.WW, g.H, g.cap, c->band_rows, slot, capw, nbands, sync, 0u, 0u, si);
     } else
 #endif
     {
@@ -320,7 +321,7 @@ rest:
     hipLaunchKernelGGL(lm_k_flatten_flag, dim3(nbands, n), dim3(256), 0, st, c->parent + c0, c->band_runs + b0, c->rootbits + cw0, c->wordprefix + cw0,
                        c->band_roots + b0, slot, g.cap, capw);
     hipLaunchKernelGGL(lm_k_apply_labels, dim3(nbands, n), dim3(256), 0, st, c->parent + c0, c->band_runs + b0, c->rootbits + cw0, c->wordprefix + cw0,
-                       c->band_roots + b0, c->band_base + b0, c->n_labels + f0, c->final_label + c0, slot, g.cap, capw);
+                       c->band_roots + b0, c->band_base + b0, c->n_labels + f0, c->final_label + c0, slot, g.cap, capw, si);
     }
     if (d_labels) {
         const unsigned Q = (unsigned)(g.W + 3) / 4;
@@ -405,6 +406,7 @@ static int lm_label_batch_src(LmCtx* c, const LmLabelSrc& src, int n_frames, int
     if (lm_profile_mark(c, st, false, n_frames)) return LM_ERR_HIP;
     c->last_batch = n_frames;
     c->last_fused = src.logits ? 1 : 0;
+    c->stats_fresh = 1;
     return LM_OK;
 }
 
@@ -469,8 +471,11 @@ extern "C" int lm_cc_stats_batch(LmCtx* c, void* stream)
     const LmGeom g = c->g;
     hipStream_t st = (hipStream_t)stream;
     const int B = c->last_batch;
-    hipLaunchKernelGGL(lm_k_stats_init, dim3(32, B), dim3(256), 0, st, c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x,
-                       c->st_count, c->n_labels, g.W, g.H, g.cap);
+    // the labelling launch leaves the arrays initialised (lm_k_apply_labels); a second call for the same batch starts over
+    if (!c->stats_fresh)
+        hipLaunchKernelGGL(lm_k_stats_init, dim3(32, B), dim3(256), 0, st, c->st_min_y, c->st_max_y, c->st_min_x, c->st_max_x,
+                           c->st_count, c->n_labels, g.W, g.H, g.cap);
+    c->stats_fresh = 0;
     hipLaunchKernelGGL(lm_k_stats, dim3((g.WW + LM_ST_WORDS - 1) / LM_ST_WORDS, (g.H + LM_ST_ROWS - 1) / LM_ST_ROWS, B), dim3(256), 0,
                        st, c->bits, c->starts, c->prefix, c->rowoff, c->final_label, c->st_min_y, c->st_max_y, c->st_min_x,
                        c->st_max_x, c->st_count, g.WW, g.H, g.cap);
@@ -739,7 +744,7 @@ static void lm_flush_tempo(LmStream* s, hipStream_t st)
     if (s->tempo_B <= 0) return;
     const LmMatchBatch mb = *s->mb;
     hipLaunchKernelGGL(lm_k_mb_tempo, dim3(LM_HIP_EMULATED ? 2 : 1024), dim3(256), 0, st, s->cc, s->frame_cc_off, s->tempo_f0, s->tempo_B, s->active_box,
-                       s->active_cc, s->active_last, s->counters, mb, s->max_gap);
+                       s->active_cc, s->active_last, s->counters, mb, s->max_gap, s->active, s->assign);
     s->tempo_B = 0;
 }
 
@@ -782,11 +787,10 @@ static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st, h
         if (ev_pre && done + B >= n) (void)hipEventRecord(ev_pre, st);
         hipLaunchKernelGGL(lm_k_mb_resolve, dim3(1), dim3(LM_MB_RT), LM_MB_RESOLVE_SMEM, st, s->cc, s->frame_cc_off, f, B, s->active, s->active_cc,
                            s->active_box, s->active_last, s->counters, s->assign, mb, s->max_gap, s->cap_uniq);
-        hipLaunchKernelGGL(lm_k_mb_finish, dim3(160), dim3(256), 0, st, s->frame_cc_off, f, B, s->active, s->counters, s->assign, mb);
         if (defer_tempo && done + B >= n) { s->tempo_f0 = f; s->tempo_B = B; }
         else
             hipLaunchKernelGGL(lm_k_mb_tempo, gt, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->active_last,
-                               s->counters, mb, s->max_gap);
+                               s->counters, mb, s->max_gap, s->active, s->assign);
         done += B;
     }
 }

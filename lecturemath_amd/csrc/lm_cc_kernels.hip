@@ -608,9 +608,13 @@ __global__ void __launch_bounds__(256) lm_k_flatten_flag(int32_t* __restrict__ p
 
 // K5b: final[i] = (roots in the bands above) + (roots before the run's root inside its band) + 1.  One block per
 // (band, frame); the band bases are a 64-wide scan of the per-band root counts; block 0 of a frame also writes n_labels.
+// the per-label statistics arrays of the frames a launch numbers (CC_AgeBoundaries' "nothing seen yet" values are written by the
+// numbering kernel itself, which knows the label count: round 2 had a launch of its own for that, 6 us + a kernel boundary per batch)
+struct LmStatInit { int32_t *min_y, *max_y, *min_x, *max_x, *count; int W, H; };
+
 LM_DEV void lm_apply_body(int b, int band, int nbands, const int32_t* parent, const int32_t* __restrict__ band_runs, const unsigned long long* rootbits,
                           const uint32_t* wordprefix, const uint32_t* band_roots, uint32_t* __restrict__ band_base, int32_t* __restrict__ n_labels,
-                          int32_t* __restrict__ final_label, int slot, int cap, int capw)
+                          int32_t* __restrict__ final_label, int slot, int cap, int capw, const LmStatInit si)
 {
     __shared__ unsigned s_base[1024];
     // exclusive scan of the frame's band root counts (nbands <= 1024), redundantly per block: a few hundred loads from L2
@@ -627,6 +631,14 @@ LM_DEV void lm_apply_body(int b, int band, int nbands, const int32_t* parent, co
     if (band == 0) {
         for (int j = threadIdx.x; j < nbands; j += blockDim.x) band_base[b * nbands + j] = s_base[j];
         if (threadIdx.x == 0) n_labels[b] = (int32_t)carry;
+    }
+    if (si.count) {     // this band's share of the frame's labels (every workgroup of the frame knows their number)
+        const int nl = (int)carry, per = (nl + nbands - 1) / nbands;
+        const int i1 = (band + 1) * per < nl ? (band + 1) * per : nl;
+        const long long off = (long long)b * cap;
+        for (int i = band * per + (int)threadIdx.x; i < i1; i += blockDim.x) {
+            si.min_y[off + i] = si.H; si.max_y[off + i] = 0; si.min_x[off + i] = si.W; si.max_x[off + i] = 0; si.count[off + i] = 0;
+        }
     }
     const int n = band_runs[b * nbands + band];
     const int32_t* par = parent + (long long)b * cap;
@@ -657,9 +669,9 @@ __global__ void __launch_bounds__(256) lm_k_apply_labels(const int32_t* __restri
                                                          const unsigned long long* __restrict__ rootbits,
                                                          const uint32_t* __restrict__ wordprefix, const uint32_t* __restrict__ band_roots,
                                                          uint32_t* __restrict__ band_base, int32_t* __restrict__ n_labels,
-                                                         int32_t* __restrict__ final_label, int slot, int cap, int capw)
+                                                         int32_t* __restrict__ final_label, int slot, int cap, int capw, const LmStatInit si)
 {
-    lm_apply_body(blockIdx.y, blockIdx.x, gridDim.x, parent, band_runs, rootbits, wordprefix, band_roots, band_base, n_labels, final_label, slot, cap, capw);
+    lm_apply_body(blockIdx.y, blockIdx.x, gridDim.x, parent, band_runs, rootbits, wordprefix, band_roots, band_base, n_labels, final_label, slot, cap, capw, si);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -694,7 +706,7 @@ __global__ void __launch_bounds__(256) lm_k_middle(const uint64_t* __restrict__ 
                                                    const int32_t* __restrict__ band_runs, unsigned long long* rootbits, uint32_t* wordprefix,
                                                    uint32_t* band_roots, uint32_t* __restrict__ band_base, int32_t* __restrict__ n_labels,
                                                    int32_t* __restrict__ final_label, int WW, int H, int cap, int brows, int slot, int capw, int nbands,
-                                                   unsigned* __restrict__ sync, unsigned ticket_base, unsigned arrive_base)
+                                                   unsigned* __restrict__ sync, unsigned ticket_base, unsigned arrive_base, const LmStatInit si)
 {
     // sync[0]: tickets; sync[1 + 2 * frame + phase]: arrivals of the frame's workgroups at rendezvous `phase`
     __shared__ unsigned s_ticket;
@@ -705,7 +717,7 @@ __global__ void __launch_bounds__(256) lm_k_middle(const uint64_t* __restrict__ 
     lm_frame_rendezvous(sync + 1 + 2 * b, arrive_base + (unsigned)nbands);
     lm_flatten_body(b, band, nbands, parent, band_runs, rootbits, wordprefix, band_roots, slot, cap, capw);
     lm_frame_rendezvous(sync + 2 + 2 * b, arrive_base + (unsigned)nbands);
-    lm_apply_body(b, band, nbands, parent, band_runs, rootbits, wordprefix, band_roots, band_base, n_labels, final_label, slot, cap, capw);
+    lm_apply_body(b, band, nbands, parent, band_runs, rootbits, wordprefix, band_roots, band_base, n_labels, final_label, slot, cap, capw, si);
 }
 #endif
 

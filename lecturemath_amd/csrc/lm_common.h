@@ -84,6 +84,7 @@ struct LmCtx {
     uint32_t* frame_cropwords;  // [B]
     int last_batch;          // frames in the most recent lm_label_batch
     int last_fused;          // 1: that batch came through lm_k_pack_rows_logits (threshold fused into the row packing)
+    int stats_fresh;         // 1: the statistics arrays of that batch hold their initial values (written by the numbering kernel)
     // host-pointer convenience path (drop-in entry points): staging buffers
     uint8_t* stage_u8;
     int32_t* stage_i32;

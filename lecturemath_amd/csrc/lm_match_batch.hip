@@ -1006,7 +1006,7 @@ __global__ void __launch_bounds__(LM_MB_RT) lm_k_mb_resolve(const LmCcRec* __res
         }
     }
     __syncthreads();        // everything the replay wrote is visible to the whole block
-    // ---- after the replay: boxes of the new actives (assignments are finished by lm_k_mb_finish)
+    // ---- after the replay: boxes of the new actives (assignments are finished by lm_k_mb_tempo)
     if (!s_fail) {
         for (int pos = nA0 + (int)threadIdx.x; pos < nA; pos += LM_MB_RT) active_box[pos] = lm_pack_box(cc[active_cc[pos]]);
     }
@@ -1019,21 +1019,6 @@ __global__ void __launch_bounds__(LM_MB_RT) lm_k_mb_resolve(const LmCcRec* __res
             cnt->n_active = nA;
             cnt->n_matched = f0 + B;
         }
-    }
-}
-
-// C': the replay left active POSITIONS (-2 - pos) in the matched non-twins' assignments and nothing in the twins': positions
-// become unique indices and every twin takes its root's unique.  A twin's thread may read its root's entry before or after the
-// root's own thread translated it; both forms are understood.
-__global__ void __launch_bounds__(256) lm_k_mb_finish(const long long* __restrict__ frame_cc_off, int f0, int B, const int32_t* __restrict__ active,
-                                                      const LmCounters* __restrict__ cnt, int32_t* __restrict__ assign, LmMatchBatch mb)
-{
-    if (cnt->error) return;
-    const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
-    for (long long i = C0 + (long long)blockIdx.x * 256 + threadIdx.x; i < C1; i += (long long)gridDim.x * 256) {
-        int32_t v = assign[mb.twin[i] ? (long long)mb.troot[i] : i];
-        if (v <= -2) v = active[-2 - v];
-        assign[i] = v;
     }
 }
 
@@ -1053,13 +1038,25 @@ __global__ void __launch_bounds__(256) lm_k_mb_finish(const long long* __restric
 __global__ void __launch_bounds__(256) lm_k_mb_tempo(const LmCcRec* __restrict__ cc, const long long* __restrict__ frame_cc_off, int f0, int B,
                                                      const unsigned long long* __restrict__ active_box, const int32_t* __restrict__ active_cc,
                                                      const int32_t* __restrict__ active_last, LmCounters* __restrict__ cnt, LmMatchBatch mb,
-                                                     int max_gap)
+                                                     int max_gap, const int32_t* __restrict__ active, int32_t* __restrict__ assign)
 {
     __shared__ __attribute__((aligned(16))) unsigned long long s_sbox[LM_MB_TCHUNK + 4];
     __shared__ int s_ub[4];
     __shared__ int s_nsurv;
     __shared__ unsigned long long s_sum;
     if (cnt->error) return;
+    // C' (round 2: lm_k_mb_finish, a launch of its own): the replay left active POSITIONS (-2 - pos) in the matched non-twins'
+    // assignments and nothing in the twins': positions become unique indices and every twin takes its root's unique.  A twin's thread
+    // may read its root's entry before or after the root's own thread translated it; both forms are understood.  Like the count
+    // below it reads the active list as the replay left it.
+    {
+        const long long C0 = frame_cc_off[f0], C1 = frame_cc_off[f0 + B];
+        for (long long i = C0 + (long long)blockIdx.x * 256 + threadIdx.x; i < C1; i += (long long)gridDim.x * 256) {
+            int32_t v = assign[mb.twin[i] ? (long long)mb.troot[i] : i];
+            if (v <= -2) v = active[-2 - v];
+            assign[i] = v;
+        }
+    }
     const int nt = mb.ftile_all[B];
     const int nA = cnt->n_active;
     const int ccl = (int)(threadIdx.x & 63), q = (int)(threadIdx.x >> 6);
