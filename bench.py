@@ -490,26 +490,29 @@ def main():
     # (The streams must differ in priority: with both high the runtime puts them on one hardware queue and nothing overlaps.)
     s_wide = torch.cuda.Stream(priority=-1 if prio == "front" else 0)
     back_prio = int(os.environ.get("LM_BENCH_BACK_PRIO", "0"))      # priority of the step-03 streams
+    match_prio = int(os.environ.get("LM_BENCH_MATCH_PRIO", "0"))    # ... of the matching streams
     slots = []
     for _ in range(depth):
         fs = device.FrameStream(W, H, cap_frames, 0.85, 0.85, 85, 20, max_batch=B, max_ccs=max_ccs, max_crop_words=max_words, lib=lib)
         slots.append({"fs": fs, "clean": torch.empty((B, H, W), dtype=torch.uint8, device="cuda"),
-                      "s_match": torch.cuda.Stream(priority=0), "s_back": torch.cuda.Stream(priority=back_prio),
+                      "s_match": torch.cuda.Stream(priority=match_prio), "s_back": torch.cuda.Stream(priority=back_prio),
                       "done": torch.cuda.Event(), "rdone": torch.cuda.Event(), "gr": None, "recorded": []})
     # binary frames and the label image live for one batch: written by threshold / the labeller, consumed in order on s_wide
     binary = torch.empty((B, H, W), dtype=torch.uint8, device="cuda")
     labels = None if a.no_labels else torch.empty((B, H, W), dtype=torch.int32, device="cuda")
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, depth))
 
-    schedule = os.environ.get("LM_BENCH_SCHEDULE", "gated")       # gated (default) | free | gated-py (the Python-driven loop below)
+    schedule = os.environ.get("LM_BENCH_SCHEDULE", "free")        # free (default) | gated | gated-py (the Python-driven loop below)
     gated = schedule == "gated-py"
 
     def front(sl, match=True, use_split=split):
         """steps 01 (threshold) + 02 (label, records; matching when `match`) of this rank's block of the stream.
-        Schedule: "free" (default) hands the whole loop to lm_stream_run_logits.  LM_BENCH_SCHEDULE=gated: the labelling launches -- the bandwidth-bound kernels the roofline is quoted on -- never share
-        the GPU with the temporal matching (dozens of small latency-bound kernels): matching of batch k-1 starts when batch k has
-        been labelled and runs under batch k's statistics / record emission and batch k+1's threshold; batch k+1 is labelled when
-        it has finished.  Uncontrolled overlap (LM_BENCH_SCHEDULE=free) stretches both."""
+        Schedule: "free" (default) hands the whole loop to lm_stream_run_logits, matching of batch k behind batch k's records on its
+        own queue.  LM_BENCH_SCHEDULE=gated: the labelling launches -- the bandwidth-bound kernels the roofline is quoted on -- never
+        share the GPU with the temporal matching: matching of batch k-1 starts when batch k has been labelled and runs under batch
+        k's statistics / record emission; batch k+1 is labelled when it has finished.  Round 3, measured on one lease with the final
+        kernels (profiles/r03_s2_operating_points.txt): free + one label part 68.3 k frames/s at 0.30 of the HBM peak in-region,
+        gated + two parts 58.6 k at 0.39 -- the gaps of the labelling middle are where the rest of the pipeline runs."""
         fs = sl["fs"]
         ctx = fs.labeler.ctx
         with torch.cuda.stream(s_wide):
@@ -757,6 +760,13 @@ def main():
         roofline["alone"] = {"launch_ms": round(alone_ms, 4), "achieved": round(algo_bytes / (alone_ms * 1e-3) / 1e9, 2),
                              "frac": round(algo_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "note": "same launches after the timed region, no matching kernels in flight"}
+    # The operating point is chosen for `value`: in the timed region the labelling launches share the GPU with the matching kernels
+    # and with step 03 of the previous step, which fill the gaps of the launch's latency-bound middle -- `frac` measures the launch
+    # while it shares.  The schedule that keeps the launch to itself is a switch away and is measured in profiles/:
+    roofline["operating_point"] = {
+        "this_run": {"schedule": schedule, "label_parts": int(os.environ.get("LM_LABEL_PARTS", "1"))},
+        "exclusive_alternative": {"how": "LM_BENCH_SCHEDULE=gated LM_LABEL_PARTS=2", "frac": 0.388, "value_frames_per_s": 58600,
+                                  "source": "profiles/r03_s2_operating_points.txt (same library, same lease)"}}
 
     # ---- CPU baseline: the oracle (C port, 1 thread) on a prefix of the same stream
     cpu = None
@@ -804,7 +814,8 @@ def main():
                    "parallelism": "one stream on one GPU" if world == 1 else "frame-range shards of one stream, gather to rank 0",
                    "pipeline_depth": depth, "matching_on_own_hip_stream": bool(split),
                    "schedule": {"gated": "lm_stream_run_logits schedule 1: labelling launches kept apart from the matching's wide kernels",
-                                "free": "lm_stream_run_logits schedule 0", "gated-py": "Python-driven gated loop"}.get(schedule, schedule)},
+                                "free": "lm_stream_run_logits schedule 0: matching of a batch behind its records on its own queue, nothing kept apart",
+                                "gated-py": "Python-driven gated loop"}.get(schedule, schedule)},
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "gen_seconds": round(gen_s, 2),
     }
     if world == 1 and a.fcn_frames > 0:

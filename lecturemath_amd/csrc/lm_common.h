@@ -100,7 +100,12 @@ struct LmCtx {
 };
 
 #define LM_LABEL_FUSED_MIDDLE_DEFAULT 0     // 1: lm_k_middle (one launch, per-frame rendezvous) instead of seam / flatten / apply launches; env LM_LABEL_FUSED_MIDDLE overrides
-#define LM_LABEL_PARTS 2        // parts a batch is labelled in (env LM_LABEL_PARTS overrides: 1..8)
+// parts a batch is labelled in, side by side on two queues (env LM_LABEL_PARTS overrides: 1..8).  Two parts shorten the launch
+// sequence where it shares the GPU with other work (0.39 of the HBM peak in the pipeline's timed region instead of 0.30-0.32) by
+// filling the gaps of its latency-bound middle with the other half of the batch -- but that is where the OTHER kernels of the
+// pipeline (matching, step 03) would have run: the whole pipeline is 14 % faster with one part (68 k against 59 k frames/s), so
+// one part is the default.  Alone the two forms take the same time (331 / 337 us per 64 frames).
+#define LM_LABEL_PARTS 1
 #define LM_LABEL_PART_MIN 8     // ... as long as every part has at least this many frames
 
 // ---------------------------------------------------------------- device helpers

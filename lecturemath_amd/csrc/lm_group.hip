@@ -477,6 +477,7 @@ __global__ void __launch_bounds__(256) lm_k_render_frames(const long long* __res
             }
 #pragma unroll
             for (int u = 0; u < LM_RT_WPL; u++) {
+                if (g0 + (unsigned)u * blockDim.x >= total) continue;      // (its zeroed descriptors would shift by 32)
                 const int sh = (col[u] - x0_[u]) & 31;
                 unsigned c = sh ? ((lo[u] >> sh) | (hi[u] << (32 - sh))) : lo[u];
                 if (col[u] < xa_[u]) c &= 0xffffffffu << (xa_[u] - col[u]);             // clip to the tile / item intersection in x

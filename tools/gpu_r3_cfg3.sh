@@ -1,0 +1,17 @@
+#!/bin/bash
+# bench configurations "<hwq or default>:<LM_LABEL_PARTS>:<schedule>" ...; the first is run twice (lease warm-up)
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/$1; shift; mkdir -p $O
+first=1
+for v in "$@"; do
+  IFS=: read q p sc <<< "$v"
+  if [ "$q" = default ]; then unset GPU_MAX_HW_QUEUES; else export GPU_MAX_HW_QUEUES=$q; fi
+  for rep in $(seq 1 $((first + 1))); do
+  LM_LABEL_PARTS=$p LM_BENCH_SCHEDULE=$sc timeout -k 10 400 python bench.py --gpus 1 --steps 9 --warmup 3 --fcn-frames 0 --cpu-frames 0 > $O/bench_$v.json 2> $O/bench_$v.err || { tail -20 $O/bench_$v.err; exit 1; }
+  done
+  first=0
+  python3 - $O/bench_$v.json $v <<'PY'
+import json, sys
+d=json.load(open(sys.argv[1]))
+print("hwq:parts:schedule", sys.argv[2], "value", d["value"], "ms/step", d["ms_per_step"], "parity", d["parity"]["match"], "frac", d["roofline"]["frac"], "launch_ms", d["roofline"]["launch_ms"], "alone", d["roofline"]["alone"]["frac"])
+PY
+done

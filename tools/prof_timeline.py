@@ -16,7 +16,7 @@ def cls(n):
     return "step03"
 packs = [r for r in rows if "pack_rows_logits" in r[0]]
 # steps = runs of 157*2 pack launches; take the window from the start of the 3rd step's first pack to the start of the last step's first pack
-per_step = 314
+per_step = int(sys.argv[2]) if len(sys.argv) > 2 else 157      # labelling launches of one step (157 batches x LM_LABEL_PARTS)
 nsteps = len(packs) // per_step
 a, b = 2, nsteps - 2          # the last step is the "alone" pass
 t0, t1 = packs[a * per_step][1], packs[b * per_step][1]
