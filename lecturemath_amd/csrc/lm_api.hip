@@ -604,6 +604,7 @@ extern "C" void lm_stream_destroy(LmStream* s)
             if (p) (void)hipFree(p);
         delete m;
     }
+    if (s->twin_stream) (void)hipStreamDestroy((hipStream_t)s->twin_stream);
     for (int i = 0; i < s->n_run_events; i++) (void)hipEventDestroy(s->run_events[i]);
     free(s->run_events);
     if (s->rd_scratch) (void)hipFree(s->rd_scratch);
@@ -748,9 +749,15 @@ static void lm_flush_tempo(LmStream* s, hipStream_t st)
     s->tempo_B = 0;
 }
 
-static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st, hipEvent_t ev_pre = nullptr, bool defer_tempo = false)
+// st_twin / ev_twin / ev_nt (lm_stream_run_logits, batches of one chunk): the twin-detection kernels of the batch go to st_twin -- the caller has
+// made that queue wait for the batch's records -- and `st` picks up behind them (ev_twin); ev_nt is recorded on `st` behind lm_k_mb_nt, the last
+// reader of the per-batch non-twin counters the NEXT batch's twin kernels reset (the caller makes st_twin wait for it).  Twin detection needs a
+// batch's records only, so it runs while `st` is still replaying the batch before: ~56 us per batch off the matching queue's chain.
+static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st, hipEvent_t ev_pre = nullptr, bool defer_tempo = false,
+                                   hipStream_t st_twin = nullptr, hipEvent_t ev_twin = nullptr, hipEvent_t ev_nt = nullptr)
 {
     if (!s->match_per_frame) lm_flush_tempo(s, st);
+    if (n > LM_MB_MAX_FRAMES) st_twin = nullptr;
     if (s->match_per_frame) {
         for (int i = 0; i < n; i++) lm_launch_match(s, f0 + i, st);
         return;
@@ -764,13 +771,16 @@ static void lm_launch_match_frames(LmStream* s, int f0, int n, hipStream_t st, h
         const int twins = (s->min_recall <= 1.0 && s->min_precision <= 1.0) ? 1 : 0;     // the twin rule needs "identical crops are accepted"; otherwise twin[] stays 0
         if (twins) {
             const dim3 gc(LM_HIP_EMULATED ? 2 : 256);
-            hipLaunchKernelGGL(lm_k_mb_twin_insert, gc, dim3(256), 0, st, s->cc, s->chash, s->frame_cc_off, f, B, s->counters, mb);
-            hipLaunchKernelGGL(lm_k_mb_twin_probe, gc, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->counters, mb, s->max_gap);
-            hipLaunchKernelGGL(lm_k_mb_twin_cmp, ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->counters, mb);
-            hipLaunchKernelGGL(lm_k_mb_twin_final, gc, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->counters, mb);
+            const hipStream_t tq = st_twin ? st_twin : st;
+            hipLaunchKernelGGL(lm_k_mb_twin_insert, gc, dim3(256), 0, tq, s->cc, s->chash, s->frame_cc_off, f, B, s->counters, mb);
+            hipLaunchKernelGGL(lm_k_mb_twin_probe, gc, dim3(256), 0, tq, s->cc, s->frame_cc_off, f, B, s->counters, mb, s->max_gap);
+            hipLaunchKernelGGL(lm_k_mb_twin_cmp, ge, dim3(256), 0, tq, s->cc, s->crop, s->frame_cc_off, f, B, s->counters, mb);
+            hipLaunchKernelGGL(lm_k_mb_twin_final, gc, dim3(256), 0, tq, s->cc, s->frame_cc_off, f, B, s->counters, mb);
+            if (st_twin) { (void)hipEventRecord(ev_twin, st_twin); (void)hipStreamWaitEvent(st, ev_twin, 0); }
         }
         hipLaunchKernelGGL(lm_k_mb_nt, dim3(B + 1), dim3(1024), 0, st, s->frame_cc_off, f, B, s->active, s->active_cc, s->active_box, s->active_last,
                            s->counters, mb, s->max_gap, twins);
+        if (twins && st_twin) (void)hipEventRecord(ev_nt, st);
         hipLaunchKernelGGL((lm_k_mb_join<0, 0>), gj, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->counters, mb);
         hipLaunchKernelGGL((lm_k_mb_join<0, 1>), gj, dim3(256), 0, st, s->cc, s->frame_cc_off, f, B, s->active_box, s->active_cc, s->counters, mb);
         hipLaunchKernelGGL((lm_k_mb_eval<0>), ge, dim3(256), 0, st, s->cc, s->crop, s->frame_cc_off, f, B, s->active_last, s->counters, mb,
@@ -909,9 +919,20 @@ extern "C" int lm_stream_run_logits(LmStream* s, const float* d_logits, int n_fr
     const bool gated = two && schedule == 1 && batch <= LM_MB_MAX_FRAMES && !s->match_per_frame;
     const size_t px = (size_t)s->ctx->g.W * s->ctx->g.H;
     const int nb = (n_frames + batch - 1) / batch;
-    if (two) { const int rc = lm_run_events(s, 3 * nb); if (rc) return rc; }
-    // events of batch k: 3k = labelled, 3k + 1 = records appended, 3k + 2 = its matching has reached the replay kernel
+    if (two) { const int rc = lm_run_events(s, 3 * nb + 2 * nb); if (rc) return rc; }
+    // events of batch k: 3k = labelled, 3k + 1 = records appended, 3k + 2 = its matching has reached the replay kernel;
+    // behind those, 3 nb + 2k = its twin detection is done, 3 nb + 2k + 1 = its lm_k_mb_nt is done
     hipEvent_t* ev = s->run_events;
+    hipEvent_t* ev2 = s->run_events + 3 * nb;
+    // LM_TWIN_QUEUE=1 (free schedule): twin detection of batch k on a queue of its own, beside the replay of batch k - 1.  Measured
+    // (profiles/r03_s2_operating_points.txt): 62-63 k frames/s against 68-70 k without -- one more queue of wide kernels beside the labelling
+    // launches costs more than the ~56 us per batch it takes off the matching queue's chain.  Off by default.
+    static const int twin_queue = [] { const char* e = getenv("LM_TWIN_QUEUE"); return e ? atoi(e) : 0; }();
+    hipStream_t st_twin = nullptr;
+    if (two && twin_queue && !s->match_per_frame && batch <= LM_MB_MAX_FRAMES) {
+        if (!s->twin_stream) LM_HIP(hipStreamCreateWithFlags((hipStream_t*)&s->twin_stream, hipStreamNonBlocking));
+        st_twin = (hipStream_t)s->twin_stream;
+    }
     int prev_n = 0;
     // LM_RUN_AHEAD=R (two-stream forms): the launch loop stays at most R batches ahead of the GPU (it waits for the records of batch
     // k - R before it enqueues batch k).  A stream's ~4,500 launches enqueued at once fill the hardware queues for >100 ms; kernels
@@ -934,8 +955,15 @@ extern "C" int lm_stream_run_logits(LmStream* s, const float* d_logits, int n_fr
         } else if (!gated) {
             LM_HIP(hipEventRecord(ev[3 * k + 1], sw));
             LM_HIP(hipStreamWaitEvent(sm, ev[3 * k + 1], 0));
-            rc = lm_stream_match(s, n, stream_match);
-            if (rc) return rc;
+            if (st_twin) {
+                LM_HIP(hipStreamWaitEvent(st_twin, ev[3 * k + 1], 0));
+                if (k >= 1) LM_HIP(hipStreamWaitEvent(st_twin, ev2[2 * (k - 1) + 1], 0));
+                lm_launch_match_frames(s, s->frames_matched, n, sm, nullptr, false, st_twin, ev2[2 * k], ev2[2 * k + 1]);
+                s->frames_matched += n;
+            } else {
+                rc = lm_stream_match(s, n, stream_match);
+                if (rc) return rc;
+            }
         } else {
             LM_HIP(hipEventRecord(ev[3 * k + 1], sw));
             if (k >= 1) {               // matching of batch k-1 starts when batch k has been labelled (which implies its records are in)

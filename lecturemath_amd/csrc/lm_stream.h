@@ -66,6 +66,7 @@ struct LmStream {
     int match_per_frame;        // 1: one lm_k_match + lm_k_update per frame (LM_MATCH_PER_FRAME=1), 0: batched matcher
     hipEvent_t* run_events;     // lm_stream_run_logits: one event per batch (records -> matching), grown on demand
     int n_run_events;
+    void* twin_stream;          // lm_stream_run_logits: queue of the twin-detection kernels (they need the batch's records only, not the matching state)
     int tempo_f0, tempo_B;      // lm_stream_run_logits (gated schedule): tempo_count kernel of the previous batch still to be launched (B > 0)
     int frames_pushed;          // host-side mirrors (frames are pushed and matched in order)
     int frames_matched;
