@@ -58,6 +58,14 @@ def test_stream_frames_with_thousands_of_ccs(hip_lib, oracle_built):
     assert len(r["cc_idx_per_frame"][0]) > 3000
 
 
+def test_stream_frames_with_seven_thousand_ccs(hip_lib, oracle_built):
+    """~7k kept CCs per frame: lm_k_select scans more than 4,096 labels per frame (two passes with a carry), lm_k_emit's workgroups
+    search more than 4,096 crop offsets for their first CC and walk many descriptor windows."""
+    frames = lm_checks.dot_grid_stream(n_frames=5, h=300, w=1000, seed=5)
+    r = lm_checks.check_stream_oracle(hip_lib, frames, max_gap=2, max_batch=5, max_ccs=1 << 16, max_crop_words=1 << 20)
+    assert len(r["cc_idx_per_frame"][0]) > 6000
+
+
 def test_stream_large_components(hip_lib, oracle_built):
     """Large components (crops of 10^3..10^4 words) among glyph-sized ones, as in the later part of a lecture: lm_k_emit by crop
     words, lm_k_mb_twin_cmp, the size prune of lm_k_mb_eval and lm_k_mb_eval_big vs the oracle, both matching paths."""

@@ -128,6 +128,14 @@ def test_stream_many_small_ccs(emu_lib, oracle_built):
     assert max(len(x) for x in r["cc_idx_per_frame"]) > 600
 
 
+def test_stream_thousands_of_ccs_per_frame(emu_lib, oracle_built):
+    """~7,000 kept CCs per frame: lm_k_select carries its scan over more than one pass of 4,096 labels, lm_k_emit's first-CC search
+    runs over more than 256 x 16 entries, the joins see more than one chunk of sources."""
+    frames = lm_checks.dot_grid_stream(n_frames=3, h=300, w=1000, seed=5)
+    r = lm_checks.check_stream_oracle(emu_lib, frames, max_gap=3, max_batch=3, max_ccs=1 << 16, max_crop_words=1 << 18)
+    assert max(len(x) for x in r["cc_idx_per_frame"]) > 6000
+
+
 def test_stream_threshold_edges(emu_lib, oracle_built):
     lm_checks.check_stream_threshold_edges(emu_lib)
 
