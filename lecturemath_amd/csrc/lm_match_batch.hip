@@ -36,7 +36,11 @@
 #define LM_MB_TILE 64
 #define LM_MB_JY 8              // workgroups that share the sources of one tile in the join launches (gridDim.y, at most)
 #define LM_MB_TTAB (1 << 18)     // twin table slots; batches with more than LM_MB_TTAB / 2 CCs skip twin detection
-#define LM_MB_CHUNK 4096        // source boxes filtered per round (LDS survivors list)
+#ifndef LM_MB_CHUNK
+#define LM_MB_CHUNK 1024        // source boxes a join workgroup filters per round (LDS survivors list: 12 KB).  A workgroup's share of the sources is
+                                // 1 / LM_MB_JY of the list (a few hundred); round 2's 4096 (48 KB) kept the joins' workgroups waiting for LDS beside the
+                                // other kernels of the pipeline
+#endif
 #define LM_MB_MAX_FRAMES 64     // frames per batch (per-frame tables of the replay kernel live in LDS)
 #define LM_MB_BIGPAIR 2048       // words of a box intersection above which a pair is evaluated by a whole workgroup
 #ifndef LM_MB_CH
