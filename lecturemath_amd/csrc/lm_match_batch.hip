@@ -1036,7 +1036,9 @@ __global__ void __launch_bounds__(LM_MB_RT) lm_k_mb_resolve(const LmCcRec* __res
 // made when a source is listed), so 4096 candidates per round are 32 KB of LDS and the usual active list (2-3 thousand) is ONE
 // round: a header and two memory latencies per tile instead of three rounds of three (45 us alone, 108 us beside the record
 // emission, per 64 dense frames).  The loads of a round are issued together, LM_MB_TUN per thread.
+#ifndef LM_MB_TCHUNK
 #define LM_MB_TCHUNK 4096
+#endif
 #define LM_MB_TUN 8
 
 __global__ void __launch_bounds__(256) lm_k_mb_tempo(const LmCcRec* __restrict__ cc, const long long* __restrict__ frame_cc_off, int f0, int B,
