@@ -1800,8 +1800,18 @@ extern "C" LmGroups* lm_group_run(LmStream* s, int max_gap, int min_times, int t
     g->s = s;
     if (!s->garena_busy) {
         if (!s->garena) {
-            const size_t first = (size_t)64 << 20;
+            // first guess from the size of the stream (the group images as bit rows dominate: about a bit per pixel of the stream -- 3,966 MB for the 10,000-frame 1080p bench stream, 1.5 bits per pixel --, plus the
+            // adjacency lists); what does not fit is allocated piecewise and the arena re-sized after the run.  A fixed 64 MB made the first run
+            // of a long stream a series of hipMalloc / hipFree calls, each a device-wide wait.
+            const LmGeom gm = s->ctx->g;
+            size_t first = ((size_t)64 << 20) + (size_t)s->frames_pushed * (size_t)gm.W * (size_t)gm.H / 4;
+            if (first > ((size_t)16 << 30)) first = (size_t)16 << 30;
             if (hipMalloc(&s->garena, first) == hipSuccess) s->garena_bytes = first;
+            else {
+                (void)hipGetLastError();
+                first = (size_t)64 << 20;
+                if (hipMalloc(&s->garena, first) == hipSuccess) s->garena_bytes = first;
+            }
         }
         if (s->garena) { g->arena = (char*)s->garena; g->arena_cap = s->garena_bytes; g->arena_cached = true; s->garena_busy = 1; }
     }
@@ -1811,6 +1821,9 @@ extern "C" LmGroups* lm_group_run(LmStream* s, int max_gap, int min_times, int t
         lm_group_destroy(g);
         return nullptr;
     }
+    if (getenv("LM_GROUP_TIMING"))
+        fprintf(stderr, "[lm_group] device arena: %zu MB wanted, %zu MB cached; pinned staging: %zu MB wanted, %zu MB cached\n", g->arena_want >> 20,
+                g->arena_cap >> 20, g->pin_want >> 20, g->pin_cap >> 20);
     return g;
 }
 
