@@ -823,13 +823,19 @@ __global__ void __launch_bounds__(256) lm_k_stats_init(int32_t* __restrict__ st_
     }
 }
 
-// One block per tile of 64 rows x 4 words (256 px wide): pieces are first combined per label in an LDS
+// One block per tile (shape below): pieces are first combined per label in an LDS
 // hash table (ds atomics), then every (tile, label) pair costs at most five device-scope atomics.
 #define LM_ST_SLOTS 512
+// Tile = LM_ST_WORDS 64-px words x LM_ST_ROWS rows; consecutive lanes take consecutive words of a row (16 words = two full cache
+// lines per row and table), a thread LM_ST_ROWS / LM_ST_RPP cells, all loaded together.  Per 64 dense 1080p frames, one lease: 4 words x 128 rows
+// 82.9 us, 8 x 64 71.0, 16 x 32 69.0, 16 x 64 79.1; another lease: 16 x 32 75.4, 32 x 16 75.7, 32 x 32 76.8, 16 x 16 (one cell per thread) 86.7.
 #ifndef LM_ST_ROWS
-#define LM_ST_ROWS 128     // tile rows (multiple of 64; a thread takes one 64-px word in every 64th row of the tile, all loaded together).  Per 64 dense 1080p frames: 64 rows 88.5 us, 128 rows 84.0, 256 rows 96.4
+#define LM_ST_ROWS 32
 #endif
-#define LM_ST_WORDS 4
+#ifndef LM_ST_WORDS
+#define LM_ST_WORDS 16     // tile width in 64-px words (a power of two <= 64)
+#endif
+#define LM_ST_RPP (256 / LM_ST_WORDS)      // rows of the tile one pass of the workgroup's 256 threads covers
 #define LM_ST_PRE 4        // final labels fetched ahead per cell
 
 __global__ void __launch_bounds__(256) lm_k_stats(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ starts,
@@ -847,7 +853,7 @@ __global__ void __launch_bounds__(256) lm_k_stats(const uint64_t* __restrict__ b
         s_key[i] = 0; s_cnt[i] = 0; s_mnx[i] = 0x7fffffff; s_mxx[i] = -1; s_mny[i] = 0x7fffffff; s_mxy[i] = -1;
     }
     __syncthreads();
-    const int w = blockIdx.x * LM_ST_WORDS + (int)(threadIdx.x & 3);
+    const int w = blockIdx.x * LM_ST_WORDS + (int)(threadIdx.x % LM_ST_WORDS);
     const int32_t* fin = final_label + foff;
     const int lane = lm_lane();
     // Round 3.  (1) The run-table loads of a non-empty cell are issued together and the final labels of its first LM_ST_PRE
@@ -859,14 +865,14 @@ __global__ void __launch_bounds__(256) lm_k_stats(const uint64_t* __restrict__ b
     // and the box only moves for pieces on the component's rim (looked at before the atomic, as before).
     // (4) A thread's LM_ST_CELLS cells (one 64-px word in every 64th row of the tile) are loaded together, phase by phase: the
     // kernel's time was rounds of workgroups x a chain of five dependent memory latencies, not arithmetic.
-    constexpr int NC = LM_ST_ROWS / 64;
+    constexpr int NC = LM_ST_ROWS / LM_ST_RPP;
     unsigned long long firsts[NC], lasts[NC], sbits[NC];
     int id0[NC], labs[NC][LM_ST_PRE];
     bool next_cont[NC];
     long long gidc[NC], rowc[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-        const int y = blockIdx.y * LM_ST_ROWS + c * 64 + (int)(threadIdx.x >> 2);
+        const int y = blockIdx.y * LM_ST_ROWS + c * LM_ST_RPP + (int)(threadIdx.x / LM_ST_WORDS);
         gidc[c] = -1; firsts[c] = 0; lasts[c] = 0; sbits[c] = 0; id0[c] = 0; next_cont[c] = false;
         rowc[c] = (long long)b * H + y;
         if (y < H && w < WW) gidc[c] = rowc[c] * WW + w;
@@ -907,7 +913,7 @@ __global__ void __launch_bounds__(256) lm_k_stats(const uint64_t* __restrict__ b
 #endif
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-    const int y = blockIdx.y * LM_ST_ROWS + c * 64 + (int)(threadIdx.x >> 2);
+    const int y = blockIdx.y * LM_ST_ROWS + c * LM_ST_RPP + (int)(threadIdx.x / LM_ST_WORDS);
     const unsigned long long s = sbits[c];
     int q = 0;
     int nxt = 0;                // label of the next piece (0: none left)
