@@ -4,7 +4,10 @@ fp32 logits resident in HBM -> threshold+invert -> CC labelling (int32 label ima
 crops -> temporal matching over the whole stream (state carried across all 10,000 frames) -> step 03 (grouping, ages, group
 images) -> reconstruction of all 10,000 frames.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W        (N > 1: one rank per GPU -- under torch.distributed.run as the driver starts
+                                                          it, or by itself: without WORLD_SIZE in the environment this process starts
+                                                          `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child
+                                                          BEFORE touching the GPU and relays its output and exit code)
 
 N = 1: a "step" is one pass over the whole stream.  Batches of the stream pipeline inside a step (matching of batch k runs on
 its own HIP stream under the labelling of batch k+1) and step 03 of step i overlaps steps 01-02 of step i+1 (--depth slots;
@@ -13,9 +16,12 @@ per rank, lecturemath_amd/sharded.py): every rank thresholds + labels its block,
 one RCCL transfer per rank, rank 0 replays the matching and runs step 03; strong scaling, digests equal to N = 1.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      labelling launch sequence (lm_label_batch), HBM bound: 5 B/px x W x H x frames per launch / mean launch
-                duration, HIP events on the launching stream INSIDE the timed region
-  cpu_baseline  the C oracle (single thread) on a bounded prefix of the same stream
+  roofline      labelling launch sequence (lm_label_batch_logits), HBM bound: 8 B/px (4 B fp32 logit in + 4 B int32 label out; the
+                byte frame of SURVEY 8(d)'s 5 B/px figure is never materialised -- that accounting is printed beside it as
+                frac_survey_5Bpx) x W x H x frames per launch / mean launch duration, HIP events on the launching stream INSIDE the
+                timed region
+  cpu_baseline  the CPU oracle (single thread) on a bounded DENSE window of the same stream, the same work as `value` (steps 01-03 +
+                reconstruction); the sparse first frames (steps 01-02 only) as a sub-key
   parity        sha256 digests of the step 02/03 products of the last timed step vs the digests the reference produced on the
                 same stream (tests/golden/g9_stream1080p_digests.json)
   fcn           configs[1] measured in the same process: FCN-LectureNet forward at 1080p (ms/frame, algorithmic TFLOP/s,
@@ -35,7 +41,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-ALGO_BYTES_PER_PX = 5           # 1 B uint8 in + 4 B int32 label out
+ALGO_BYTES_PER_PX = 5           # SURVEY.md 8(d)'s byte-frame accounting (1 B uint8 in + 4 B int32 label out), reported as frac_survey_5Bpx; the
+                                # launch that runs reads fp32 logits and is priced on its own 8 B/px (roofline.algorithmic_bytes_per_px)
 MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16/bf16 MFMA peak
 FCN_MFMA_PER_PRODUCT = {"f16": 1, "f16x2": 2, "f16x3": 3}
@@ -58,7 +65,7 @@ def parse():
     p.add_argument("--fcn-precision", default=os.environ.get("LM_FCN_PRECISION", "mixed"),
                    choices=["mixed", "planar-f16x3", "planar-f16", "f16", "f16x2", "f16x3", "fp32"],
                    help="MFMA operand format of the FCN conv stack (fp32 accumulate in all); mixed = per layer (lecturemath_amd/fcn.py)")
-    p.add_argument("--fcn-frames", type=int, default=5, help="frames timed for the `fcn` object (0 = skip fcn and e2e_rgb)")
+    p.add_argument("--fcn-frames", type=int, default=50, help="frames timed for the `fcn` object (0 = skip fcn and e2e_rgb)")
     p.add_argument("--e2e-frames", type=int, default=64, help="RGB frames of the `e2e_rgb` measurement (0 = skip)")
     p.add_argument("--no-fcn-oracle", action="store_true", help="skip the CPU oracle forward pass (max |logit diff|, FCN cpu baseline)")
     p.add_argument("--workload", default="stream", choices=["stream", "fcn"],
@@ -373,6 +380,9 @@ def main_sharded(a, torch, dist, lib, world, rank, rehearse, logits, gen_s):
     steps_all = [collect(per_step, r) for r in range(world)]
     parity = collect(parity, sh.group_rank)
     sh.close()
+    # the CPU baseline is a property of the workload, not of N: rank 0 times the oracle on the frames it holds (the other ranks wait in
+    # the next collective), after the timed region
+    cpu = measure_cpu_baseline(logits, a.cpu_frames, 0, F, W, H) if rank == 0 and a.cpu_frames > 0 else None
     del logits
     torch.cuda.empty_cache()
     seq0 = steps_all[0]["front_and_matching_ms"]
@@ -421,6 +431,7 @@ def main_sharded(a, torch, dist, lib, world, rank, rehearse, logits, gen_s):
         fpl = nfr.value / max(calls.value, 1)
         bpp = (4 if fused else 1) + (4 if labels is not None else 0)
         ach = bpp * W * H * fpl / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        traffic, traffic_note = label_traffic(W, H, fused, fpl)
         out = {"metric": "frames/sec end-to-end binarize+CC+group @1080p", "value": round(F * a.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -430,18 +441,88 @@ def main_sharded(a, torch, dist, lib, world, rank, rehearse, logits, gen_s):
                           "frames_per_step": F, "batch": B, "parallelism": "frame-range shards of one stream; point-to-point piece transfers to rank 0 (%s)" % ("gloo rehearsal on one GPU" if rehearse else "RCCL"),
                           "stages_not_in_timed_region": ["fcn conv stack (see rgb_sharded)"]},
                "roofline": {"bound": "hbm", "kernel": "labelling launches of rank 0", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launch_ms": round(launch_ms, 4), "launches": calls.value,
-                            "algorithmic_bytes_per_px": bpp},
-               "cpu_baseline": None, "parity": parity, "amdahl": amdahl, "per_rank_step_ms": steps_all, "rgb_sharded": rgb_res, "gen_seconds": round(gen_s, 2)}
+                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note, "launch_ms": round(launch_ms, 4),
+                            "launches": calls.value, "frames_per_launch": round(fpl, 2), "algorithmic_bytes_per_px": bpp},
+               "cpu_baseline": cpu, "parity": parity, "amdahl": amdahl, "per_rank_step_ms": steps_all, "rgb_sharded": rgb_res, "gen_seconds": round(gen_s, 2)}
         print(json.dumps(out))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a child torchrun BEFORE anything in this
+    process touches the GPU (no torch import here), relay the child's output and exit with its code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def label_traffic(W, H, fused, frames_per_launch):
+    """HBM bytes of one labelling launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in separate runs of
+    tools/label_microbench.py, gfx950 corrections applied by tools/pmc_traffic.py), scaled to this run's frames per launch.  PMC passes
+    cannot be collected inside this process: the figure is QUOTED from the newest matching profile, not measured by this run."""
+    import glob
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_label_traffic_pmc*.json")), reverse=True):
+        tr = json.load(open(tpath))
+        if (tr.get("width"), tr.get("height"), tr.get("fused")) == (W, H, fused) and tr.get("frames_per_launch"):
+            return (int(tr["hbm_bytes_per_launch"] * frames_per_launch / tr["frames_per_launch"]),
+                    "quoted from %s (separate --pmc passes of tools/label_microbench.py, %d frames per launch), scaled to this run's frames per launch; "
+                    "not collected by this process" % (os.path.relpath(tpath, ROOT), tr["frames_per_launch"]))
+    return None, "PMC passes cannot be collected inside this process and profiles/ holds none for this frame size"
+
+
+def measure_cpu_baseline(logits, n, first_frame, F, W, H):
+    """The CPU oracle (oracle/cc_oracle.c + oracle/grouping.py, ONE thread) on bounded samples of the stream `logits` holds (frames
+    first_frame .. first_frame + len(logits) of an F-frame stream).  `value` = the same work as the bench's `value` -- steps 01-03 with all
+    frames reconstructed -- on a DENSE window (the board is full around frame 5000) run as a stream of its own; `sparse_prefix` = steps
+    01-02 on the first frames.  The checker, timed on the host after the timed region."""
+    from oracle import cc as occ
+    from oracle import grouping as ogr
+    have = int(logits.shape[0])
+    n = min(n, have)
+    d0 = min(5000 - first_frame, have - n)          # window start inside `logits`
+    lg = logits[:n].cpu().numpy()
+    t0 = time.perf_counter()
+    st = occ.Stability(W, H, 0.85, 0.85, 85)
+    for i in range(n):
+        st.add_frame(occ.threshold_invert(lg[i]))
+    cdt = time.perf_counter() - t0
+    sparse = {"value": round(n / cdt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+              "sample": "frames %d..%d of the same stream: threshold+invert, label, stats, crops, temporal matching only (oracle/cc_oracle.c, "
+                        "single thread)" % (first_frame, first_frame + n)}
+    quoted = {"value": 3.7, "unit": "frames/s", "cores": 1, "quoted_not_measured": True, "source": "BASELINE.md section 4",
+              "note": "the reference itself (steps 02 + 03, first 1,000 frames of this stream, 8-vCPU build container); the oracle runs step 02 "
+                      "4.0x faster than the reference on the same frames"}
+    if d0 <= 0:
+        return dict(sparse, sparse_prefix=None, reference_in_build_container=quoted, note="stream too short for a dense window: steps 01-02 only")
+    lg = logits[d0:d0 + n].cpu().numpy()
+    t0 = time.perf_counter()
+    st = occ.Stability(W, H, 0.85, 0.85, 85)
+    for i in range(n):
+        st.add_frame(occ.threshold_invert(lg[i]))
+    t1 = time.perf_counter()
+    ogr.run_step03(st.result(), max_gap=85, min_times=3, t_window=5, min_recall=0.5, img_threshold=0.5, reconstruct=True)
+    t2 = time.perf_counter()
+    return {"value": round(n / (t2 - t0), 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "frames %d..%d of the same stream as a stream of their own, the same work as `value`: steps 01-02 %.1f s (oracle/cc_oracle.c) + "
+                      "step 03 with all frames reconstructed %.1f s (oracle/grouping.py, numpy); single thread, host has %d cores"
+                      % (first_frame + d0, first_frame + d0 + n, t1 - t0, t2 - t1, os.cpu_count()),
+            "sparse_prefix": sparse, "reference_in_build_container": quoted}
 
 
 def main():
     a = parse()
     if a.workload == "fcn":
         return main_fcn(a)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a)
     import concurrent.futures
 
     import torch
@@ -449,7 +530,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
+    assert world == a.gpus, "--gpus %d inside a launcher that set WORLD_SIZE=%d" % (a.gpus, world)
     # LM_BENCH_REHEARSE=1: all ranks on cuda:0 with the gloo backend -- exercises the multi-process path on a one-GPU box
     rehearse = bool(os.environ.get("LM_BENCH_REHEARSE"))
     if rehearse:
@@ -749,18 +830,11 @@ def main():
                                              "note": ("fp32 logit read + int32 label written; threshold fused, no byte frame" if fused else
                                                       "uint8 frame read + int32 label written (SURVEY 8(d))")},
                 "frac_survey_5Bpx": round(ALGO_BYTES_PER_PX * W * H * frames_per_launch / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if launch_ms > 0 else None,
-                "traffic": None, "traffic_note": "PMC passes cannot be collected inside this process; see profiles/ for the rocprofv3 --pmc runs of this command",
+                "traffic": None, "traffic_note": None,
                 "launch_ms": round(launch_ms, 4), "launches": tot_calls, "frames_per_launch": round(frames_per_launch, 2),
                 "algorithmic_bytes_per_launch": int(algo_bytes), "label_image_written": labels is not None,
                 "timed": "HIP events around every labelling launch sequence inside the timed region"}
-    tpath = os.path.join(ROOT, "profiles", "r03_label_traffic_pmc.json")
-    if os.path.exists(tpath):
-        tr = json.load(open(tpath))
-        if (tr.get("width"), tr.get("height"), tr.get("fused")) == (W, H, fused) and tr.get("frames_per_launch"):
-            # HBM bytes of one launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied
-            # there), scaled to this run's frames per launch
-            roofline["traffic"] = int(tr["hbm_bytes_per_launch"] * frames_per_launch / tr["frames_per_launch"])
-            roofline["traffic_note"] = "profiles/r03_label_traffic_pmc.json (separate --pmc passes of tools/label_microbench, %d frames per launch)" % tr["frames_per_launch"]
+    roofline["traffic"], roofline["traffic_note"] = label_traffic(W, H, fused, frames_per_launch)
     if alone_ms:
         roofline["alone"] = {"launch_ms": round(alone_ms, 4), "achieved": round(algo_bytes / (alone_ms * 1e-3) / 1e9, 2),
                              "frac": round(algo_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -770,40 +844,11 @@ def main():
     # while it shares.  The schedule that keeps the launch to itself is a switch away and is measured in profiles/:
     roofline["operating_point"] = {
         "this_run": {"schedule": schedule, "label_parts": int(os.environ.get("LM_LABEL_PARTS", "1"))},
-        "exclusive_alternative": {"how": "LM_BENCH_SCHEDULE=gated LM_LABEL_PARTS=2", "frac": 0.388, "value_frames_per_s": 58600,
-                                  "source": "profiles/r03_s2_operating_points.txt (same library, same lease)"}}
+        "exclusive_alternative": {"how": "LM_BENCH_SCHEDULE=gated LM_LABEL_PARTS=2", "quoted_not_measured": True, "frac": 0.388, "value_frames_per_s": 58600,
+                                  "source": "profiles/r03_s2_operating_points.txt (round 3's library on one lease; not re-measured by this run)"}}
 
-    # ---- CPU baseline: the oracle (C port, 1 thread) on a prefix of the same stream
-    cpu = None
-    if a.cpu_frames > 0 and world == 1:     # reported at N = 1 only
-        from oracle import cc as occ
-        n = min(a.cpu_frames, F)
-        lg = logits[:n].cpu().numpy()
-        t0 = time.perf_counter()
-        st = occ.Stability(W, H, 0.85, 0.85, 85)
-        for i in range(n):
-            st.add_frame(occ.threshold_invert(lg[i]))
-        cdt = time.perf_counter() - t0
-        cpu = {"value": round(n / cdt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": "first %d frames of the same stream: threshold+invert, label, stats, crops, temporal matching "
-                         "(oracle/cc_oracle.c, single thread; host has %d cores)" % (n, os.cpu_count()),
-               "reference_in_build_container": {"value": 3.7, "unit": "frames/s", "cores": 1,
-                                                "note": "the reference itself (steps 02 + 03, first 1,000 frames of this stream, 8-vCPU build container): BASELINE.md section 4"}}
-        # the same work as `value` on a DENSE window of the stream (the board is full around frame 5000): steps 01-03 incl. reconstruction
-        d0 = min(5000, max(F - n, 0))
-        if F >= d0 + n and d0 > 0:
-            from oracle import grouping as ogr
-            lg = logits[d0:d0 + n].cpu().numpy()
-            t0 = time.perf_counter()
-            st = occ.Stability(W, H, 0.85, 0.85, 85)
-            for i in range(n):
-                st.add_frame(occ.threshold_invert(lg[i]))
-            t1 = time.perf_counter()
-            ogr.run_step03(st.result(), max_gap=85, min_times=3, t_window=5, min_recall=0.5, img_threshold=0.5, reconstruct=True)
-            t2 = time.perf_counter()
-            cpu["dense_window"] = {"value": round(n / (t2 - t0), 3), "unit": "frames/s", "cores": 1,
-                                   "sample": "frames %d..%d of the same stream as a stream of their own: steps 01-02 %.1f s (oracle/cc_oracle.c) + step 03 with "
-                                             "all frames reconstructed %.1f s (oracle/grouping.py, numpy)" % (d0, d0 + n, t1 - t0, t2 - t1)}
+    # ---- CPU baseline (the checker, timed after the timed region; rank 0 only)
+    cpu = measure_cpu_baseline(logits, a.cpu_frames, 0, F, W, H) if a.cpu_frames > 0 else None
 
     out = {
         "metric": "frames/sec end-to-end binarize+CC+group @1080p", "value": round(F * a.steps / dt, 2), "unit": "frames/s",

@@ -187,7 +187,7 @@ extern "C" LmCtx* lm_ctx_create(int width, int height, int max_batch)
     rc |= lm_alloc(&c->band_roots, (size_t)max_batch * c->nbands);
     rc |= lm_alloc(&c->band_fallback, (size_t)max_batch * c->nbands);
     rc |= lm_alloc(&c->parent, BC);
-    rc |= lm_alloc(&c->final_label, BC);
+    rc |= lm_alloc(&c->final_label, BC);     // lm_k_stats' lm_load4 may read up to 12 bytes past B * cap: inside lm_alloc's 64 bytes of slack
     rc |= lm_alloc(&c->n_labels, (size_t)max_batch);
     rc |= lm_alloc(&c->rootbits, (size_t)max_batch * (c->g.cap / 64));
     rc |= lm_alloc(&c->wordprefix, (size_t)max_batch * (c->g.cap / 64));
@@ -307,7 +307,9 @@ rest:
     static const int fused_middle = [] { const char* e = getenv("LM_LABEL_FUSED_MIDDLE"); return e ? atoi(e) : LM_LABEL_FUSED_MIDDLE_DEFAULT; }();
 #if !LM_HIP_EMULATED
     if (fused_middle) {
-        // seam unions, flatten + flags, numbering in one launch with two per-frame rendezvous (lm_k_middle); one counter set per queue
+        // seam unions, flatten + flags, numbering in one launch with two per-frame rendezvous (lm_k_middle).  Two counter sets: part 0 (on
+        // `st`) uses set 0, the other part (on the aux queue) set 1; each launch zeroes its set first and passes base values of 0
+        // (lm_label_batch caps the parts at two while this switch is on)
         unsigned* sync = c->mid_sync + (size_t)(f0 ? 1 : 0) * (1 + 2 * (size_t)c->max_batch);
         LM_HIP(hipMemsetAsync(sync, 0, (1 + 2 * (size_t)n) * sizeof(unsigned), st));
         hipLaunchKernelGGL(lm_k_middle, dim3((unsigned)nbands * n), dim3(256), 0, st, c->bits + w0, c->starts + w0, c->prefix + w0, c->rowoff + r0,
@@ -362,6 +364,9 @@ static int lm_label_batch_src(LmCtx* c, const LmLabelSrc& src, int n_frames, int
     static const int want_parts = [] { const char* e = getenv("LM_LABEL_PARTS"); const int v = e ? atoi(e) : LM_LABEL_PARTS; return (v >= 1 && v <= 8) ? v : LM_LABEL_PARTS; }();
     int parts = want_parts;
     while (parts > 1 && n_frames / parts < LM_LABEL_PART_MIN) parts--;
+    // the experimental fused middle (LM_LABEL_FUSED_MIDDLE=1) has two rendezvous counter sets, one per queue: a third part would share
+    // a set with a part running concurrently on the other queue (its memset zeroing counters workgroups spin on)
+    if (parts > 2 && getenv("LM_LABEL_FUSED_MIDDLE") && atoi(getenv("LM_LABEL_FUSED_MIDDLE"))) parts = 2;
     if (parts > 1 && !c->aux_stream) {
         LM_HIP(hipStreamCreateWithFlags((hipStream_t*)&c->aux_stream, hipStreamNonBlocking));
         LM_HIP(hipEventCreateWithFlags((hipEvent_t*)&c->ev_fork, hipEventDisableTiming));

@@ -107,8 +107,11 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a, const long l
     constexpr int PLS = (NSLOT * 16 + 255) & ~255;      // LDS bytes per plane: planes a multiple of the 256-B bank row apart, so the 16
                                                         // lanes of a ds_read_b128 service group (16 different pixels of a row, two
                                                         // k-groups) fall on 16 different 16-B slots
-    constexpr int NHL = TERMS >= 2 ? 2 : 1;             // patch planes per octet: hi (, lo)
-    constexpr int NWL = TERMS >= 3 ? 2 : 1;             // weight fragments per tile: hi (, lo)
+    // TERMS names the operand format: 1 = f16 x f16; 2 = weights hi x activations hi + lo; 3 = hi.hi + lo.hi + hi.lo; 4 = weights
+    // hi + lo x activations hi (the input tensor then needs no lo planes at all: half the patch bytes in HBM, DMA and LDS)
+    constexpr bool SPLIT_B = TERMS == 2 || TERMS == 3, SPLIT_A = TERMS >= 3;
+    constexpr int NHL = SPLIT_B ? 2 : 1;                // patch planes per octet: hi (, lo)
+    constexpr int NWL = SPLIT_A ? 2 : 1;                // weight fragments per tile: hi (, lo)
     constexpr int NJ = (NSLOT + 255) / 256;             // DMA instructions per thread and plane
     constexpr int NT = 4;
     const int lane = lm_lane(), wave = LM_UNIFORM((int)(threadIdx.x >> 6)), kg = lane >> 4, col = lane & 15;
@@ -215,12 +218,12 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a, const long l
 #pragma unroll
             for (int n = 0; n < NT; n++) {
                 f.bh[n] = *(const lm_h8*)(pa + n * (PW * 16));
-                if (TERMS >= 2) f.bl[n] = *(const lm_h8*)(pa + n * (PW * 16) + PLS);
+                if (SPLIT_B) f.bl[n] = *(const lm_h8*)(pa + n * (PW * 16) + PLS);
             }
 #pragma unroll
             for (int m = 0; m < MT; m++) {
                 f.ah[m] = *(const lm_h8*)(wa + m * (NWL * 1024));
-                if (TERMS >= 3) f.al[m] = *(const lm_h8*)(wa + m * (NWL * 1024) + 1024);
+                if (SPLIT_A) f.al[m] = *(const lm_h8*)(wa + m * (NWL * 1024) + 1024);
             }
         };
         auto mma = [&](const Frag& f) {
@@ -228,13 +231,13 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a, const long l
             for (int m = 0; m < MT; m++)
 #pragma unroll
                 for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA16(f.ah[m], f.bh[n], acc[m][n]);
-            if (TERMS >= 3) {
+            if (SPLIT_A) {
 #pragma unroll
                 for (int m = 0; m < MT; m++)
 #pragma unroll
                     for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA16(f.al[m], f.bh[n], acc[m][n]);
             }
-            if (TERMS >= 2) {
+            if (SPLIT_B) {
 #pragma unroll
                 for (int m = 0; m < MT; m++)
 #pragma unroll
@@ -611,7 +614,7 @@ extern "C" int lm_fcn2_set_layer(LmFcn2* f, int layer, const int32_t* desc, int 
     l.planes.assign(p, p + (size_t)l.nchunks * l.npc * 2); p += (size_t)l.nchunks * l.npc * 2;
     for (size_t i = 0; i < l.planes.size(); i += 2)
         if (l.planes[i] < 0 || l.planes[i] >= LM_F2_TENSORS || l.planes[i + 1] < 0 || l.planes[i + 1] >= f->t[l.planes[i]].c8 ||
-            (l.terms >= 2 && !f->t[l.planes[i]].lo)) {
+            ((l.terms == 2 || l.terms == 3) && !f->t[l.planes[i]].lo)) {
             lm_set_error("lm_fcn2_set_layer: layer %d reads plane %d of tensor %d (octets %d, lo %d)", layer, l.planes[i + 1], l.planes[i],
                          f->t[l.planes[i] < 0 || l.planes[i] >= LM_F2_TENSORS ? 0 : l.planes[i]].c8, f->t[l.planes[i] < 0 || l.planes[i] >= LM_F2_TENSORS ? 0 : l.planes[i]].lo);
             return LM_ERR_ARG;
@@ -658,13 +661,21 @@ template <int KH, int KW, int TERMS, int MT, int EPI> static int lm_g2_launch_t(
 
 template <int KH, int KW, int EPI, int MT> static int lm_g2_launch_terms(int terms, const LmG2Args& a, dim3 grid, size_t smem, hipStream_t st)
 {
-    return terms >= 3 ? lm_g2_launch_t<KH, KW, 3, MT, EPI>(a, grid, smem, st) : lm_g2_launch_t<KH, KW, 1, MT, EPI>(a, grid, smem, st);
+    // the two-product formats exist for the convolutions proper (the transposed convolutions run below full resolution on f16)
+    if constexpr (EPI != LM_G2_EPI_TC) {
+        if (terms == 4) return lm_g2_launch_t<KH, KW, 4, MT, EPI>(a, grid, smem, st);
+        if (terms == 2) return lm_g2_launch_t<KH, KW, 2, MT, EPI>(a, grid, smem, st);
+    } else if (terms == 2 || terms == 4) {
+        lm_set_error("lm_fcn2: the transposed convolutions take formats 1 and 3");
+        return LM_ERR_ARG;
+    }
+    return terms == 3 ? lm_g2_launch_t<KH, KW, 3, MT, EPI>(a, grid, smem, st) : lm_g2_launch_t<KH, KW, 1, MT, EPI>(a, grid, smem, st);
 }
 
 static int lm_g2_launch(const LmF2Layer& l, const LmG2Args& a, dim3 grid, size_t smem, hipStream_t st)
 {
     const int shape = l.kh * 10 + l.kw;
-    if (l.terms != 1 && l.terms != 3) { lm_set_error("lm_fcn2: operand formats are 1 (f16) or 3 (f16 hi + lo split) products per pair"); return LM_ERR_ARG; }
+    if (l.terms < 1 || l.terms > 4) { lm_set_error("lm_fcn2: operand formats are 1 (f16), 2 (activations split), 3 (both split) or 4 (weights split)"); return LM_ERR_ARG; }
     if (shape == 33 && l.epi == LM_G2_EPI_PO) {
         if (l.mt == 1) return lm_g2_launch_terms<3, 3, LM_G2_EPI_PO, 1>(l.terms, a, grid, smem, st);
         if (l.mt == 2) return lm_g2_launch_terms<3, 3, LM_G2_EPI_PO, 2>(l.terms, a, grid, smem, st);
@@ -708,7 +719,7 @@ static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor*
     }
     if (pool) { a.pool_hi = f->arena + pool->off; a.pool_lo = pool->lo ? a.pool_hi + (long long)pool->c8 * pool->plane : nullptr; a.pool_plane = pool->plane; a.Wp_pool = pool->Wp; a.halo_pool = pool->halo; }
     a.tout = tout; a.ts = ts; a.tn = tn;
-    const int nhl = l.terms >= 2 ? 2 : 1;
+    const int nhl = (l.terms == 2 || l.terms == 3) ? 2 : 1;
     const int PW = 16 + l.kw - 1, PH = 16 + l.kh - 1, PLS = (PH * PW * 16 + 255) & ~255;
     // weight ring: three buffers when they fit beside two resident workgroups (or the layer cannot have two anyway), else two
     const size_t fixed = (size_t)((l.npat * 256 + 255) & ~255) + (size_t)(l.pdouble ? 2 : 1) * l.npc * nhl * PLS;

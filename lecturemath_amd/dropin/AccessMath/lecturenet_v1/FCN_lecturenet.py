@@ -102,9 +102,16 @@ class FCN_LectureNet:
 
     def binarize(self, PIL_image, return_others=False, force_binary=False, binary_treshold=128, apply_sigmoid=True):
         o_width, o_height = PIL_image.size
+        width, height = o_width, o_height
+        if width * height > FCN_LectureNet.MAX_PIXELS and PIL_image.mode not in ("RGB", "L"):
+            # the reference resizes the image in ITS OWN mode and converts afterwards (:434-437); Pillow resamples palette / bilevel images
+            # with NEAREST and premultiplies alpha, which the device resizer (RGB / L bytes) does not restate: those modes take Pillow's path
+            from PIL import Image
+            while width * height > FCN_LectureNet.MAX_PIXELS:
+                PIL_image = PIL_image.resize((int(width / 2), int(height / 2)), Image.LANCZOS)
+                width, height = PIL_image.size
         rgb_full = np.asarray(PIL_image.convert("RGB"), dtype=np.uint8)
         eng0_be = None
-        width, height = o_width, o_height
         if width * height > FCN_LectureNet.MAX_PIXELS:
             # the whole > 2.5 MP branch on the device: one upload of the frame, LANCZOS halving(s), network, threshold, NEAREST enlargement
             from lecturemath_amd.device import Backend

@@ -117,7 +117,7 @@ class FcnEngine:
     # every layer below full resolution on plain f16 operands changes the logits by 3e-5 in all, each of these by 0.5-3e-4 alone)
     MIXED_SPLIT_LAYERS = (L_DOWN, L_UPC + 4, L_TEXT, L_REC, L_PX1, L_PX2, L_OUT)
 
-    def __init__(self, widths, pixel_kernel, kernel, max_h, max_w, lib=None, precision="mixed"):
+    def __init__(self, widths, pixel_kernel, kernel, max_h, max_w, lib=None, precision="mixed", formats=None):
         """precision:
         "mixed" (default) -- the planar engine (csrc/lm_fcn2.hip): f16 hi + lo split operands (three MFMAs per product, ~22 bits per
             operand) in the full-resolution layers, plain f16 operands below; needs the shipped kernel sizes (7x7 pixel branch, 3x3
@@ -126,6 +126,8 @@ class FcnEngine:
         "f16x3" / "f16x2" / "f16" / "fp32" -- the first engine (csrc/lm_fcn.hip): fp32 activations, operands split while staged
             (three, two or one f16 MFMA per product) or exact fp32 MFMA chains."""
         assert precision in ("mixed", "planar-f16x3", "planar-f16", "f16x3", "f16x2", "f16", "fp32")
+        # planar engine only: {layer id: "f16" | "a2" | "w2" | "f16x3"} overriding the precision's assignment (fcn2.FORMAT_NAMES)
+        self.formats = dict(formats or {})
         self.lib = lib or _lib.load()
         self.be = Backend(self.lib)
         self.widths = [int(v) for v in widths]
@@ -165,7 +167,11 @@ class FcnEngine:
         self.lib.check(self.lib.lm_fcn_set_layer(self.handle, layer, w.ctypes.data, w.size, b.ctypes.data, b.size, cin, cout, k, ck))
 
     def layer_terms(self, layer):
-        """MFMA products per operand pair of a layer of the planar engine"""
+        """operand format of a layer of the planar engine (the TERMS parameter of lm_k_g2, fcn2.FORMAT_NAMES)"""
+        from . import fcn2 as f2
+        if layer in self.formats:
+            v = self.formats[layer]
+            return f2.FORMAT_NAMES[v] if isinstance(v, str) else int(v)
         if self.precision == "planar-f16":
             return 1
         if self.precision == "planar-f16x3":
@@ -190,7 +196,7 @@ class FcnEngine:
         # encoder: layer 1 reads the input pair plane (3 channels, two horizontal taps per slot)
         w, b = conv_bn("conv_down_block_1")
         pairs = [f2.pairplane_pair(0, dy, dx, 0, 3) for dy in range(3) for dx in (0, 2)]
-        recipes[L_DOWN] = (f2.build([w], [{"planes": [(f2.T_X0P, 0)], "pairs": pairs}], 3, 3, 3 if T(L_DOWN) > 1 else 1, f2.pick_mt(d1, tiles(0)), f2.EPI_PO), b)
+        recipes[L_DOWN] = (f2.build([w], [{"planes": [(f2.T_X0P, 0)], "pairs": pairs}], 3, 3, T(L_DOWN), f2.pick_mt(d1, tiles(0)), f2.EPI_PO), b)
         cin = [3] + downs
         for n in range(1, 5):
             w, b = conv_bn("conv_down_block_%d" % (n + 1))
@@ -235,7 +241,7 @@ class FcnEngine:
         # a tensor keeps its lo parts when a layer reading it runs the split format
         lo = np.zeros(f2.N_TENSORS, np.int32)
         for (desc, _, _, _), _ in recipes.values():
-            if desc[2] >= 2:
+            if desc[2] in (2, 3):
                 npl = int(desc[5] * desc[6])
                 lo[desc[13:13 + 2 * npl:2]] = 1
         if self.handle2:
@@ -268,7 +274,7 @@ class FcnEngine:
         for r in self.recipes.values():
             lv = level_of[r["first_tensor"]]
             tiles = (((h >> lv) + 15) // 16) * (((w >> lv) + 15) // 16)
-            total += 2.0 * tiles * 256 * r["cout"] * r["slices"] * 32 * r["terms"] * (4 if r["epilogue"] == f2.EPI_TC else (2 if r["epilogue"] == f2.EPI_TC2 else 1))
+            total += 2.0 * tiles * 256 * r["cout"] * r["slices"] * 32 * f2.FORMAT_PRODUCTS[r["terms"]] * (4 if r["epilogue"] == f2.EPI_TC else (2 if r["epilogue"] == f2.EPI_TC2 else 1))
         return total / 1e9
 
     def load_state_dict(self, sd):

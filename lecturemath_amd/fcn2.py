@@ -18,7 +18,12 @@ LDS_TWO_WORKGROUPS = 80 * 1024        # a workgroup's LDS for two of them to sha
 def geom(kh, kw, terms):
     pw, ph = 16 + kw - 1, 16 + kh - 1
     pls = (ph * pw * 16 + 255) & ~255
-    return pw, ph, pls, (2 if terms >= 2 else 1)
+    return pw, ph, pls, (2 if terms in (2, 3) else 1)
+
+
+# operand formats (the TERMS parameter of lm_k_g2): MFMA products per operand pair
+FORMAT_PRODUCTS = {1: 1, 2: 2, 3: 3, 4: 2}
+FORMAT_NAMES = {"f16": 1, "a2": 2, "f16x3": 3, "w2": 4}     # a2: activations hi + lo; w2: weights hi + lo
 
 
 def octet_pair(plane, dy, dx, cbase):

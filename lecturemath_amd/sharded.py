@@ -148,6 +148,10 @@ def piece_bounds(n, pieces):
     return out
 
 
+class _PeerFailed(RuntimeError):
+    """a peer sent a failure header in place of a piece"""
+
+
 class _Wire:
     """point-to-point transfers of flat uint8 device buffers: device to device over RCCL ("nccl"), staged through the host under
     gloo (CPU tests, the one-GPU rehearsal).  Sends are asynchronous; `drain` waits for them (buffers stay referenced until then)."""
@@ -174,15 +178,17 @@ class _Wire:
         self.pending.append((self.dist.isend(head, dst=dst), head))
         self.pending.append((self.dist.isend(t, dst=dst), t))
 
-    def recv(self, src):
+    def recv(self, src, discard=False):
         dev = "cuda" if self.nccl else "cpu"
         head = self.torch.zeros(1, dtype=self.torch.int64, device=dev)
         self.dist.recv(head, src=src)
         n = int(head.item())
         if n < 0:
-            raise RuntimeError("rank %d reported a failure in its share of the stream" % src)
+            raise _PeerFailed("rank %d reported a failure in its share of the stream" % src)
         rb = self.torch.empty(n, dtype=self.torch.uint8, device=dev)
         self.dist.recv(rb, src=src)
+        if discard:
+            return None
         if self.nccl:
             return rb
         if self.be.device:
@@ -237,52 +243,104 @@ class ShardedStream:
 
     def step(self, logits_of, labels=None, stream_wide=None, stream_match=None, schedule=1):
         """logits_of(lo, hi) -> device fp32 [hi - lo, H, W]: the logits of frames lo..hi of THIS rank's range (0-based in the range).
-        labels: optional device int32 [batch, H, W] receiving the label image of every batch in turn."""
-        from . import _lib
-        fs, lib = self.fs, self.lib
+        labels: optional device int32 [batch, H, W] receiving the label image of every batch in turn.
+        stream_wide becomes torch's current stream for the duration of the step: pack / append / match / the transfers all order
+        against the backend's current stream, which must be the one the labelling and record kernels were launched on."""
         ws = self.be.stream() if stream_wide is None else stream_wide
         ms = ws if stream_match is None else stream_match
         if self.failed:
             raise RuntimeError("this ShardedStream failed in an earlier step")
+        if self.be.device and stream_wide is not None:
+            t = self.be.torch
+            with t.cuda.stream(t.cuda.ExternalStream(ws)):
+                return self._step(logits_of, labels, ws, ms, schedule)
+        return self._step(logits_of, labels, ws, ms, schedule)
+
+    def _step(self, logits_of, labels, ws, ms, schedule):
+        from . import _lib
+        fs, lib = self.fs, self.lib
         if self.wire:
             self.wire.drain()                   # the previous step's sends
         fs.reset()
         mine = piece_bounds(self.hi - self.lo, self.pieces)
-        k = 0
-        try:
-            for k, (a, b) in enumerate(mine):
-                lg = logits_of(a, b)
-                lib.check(lib.lm_stream_run_logits(fs.handle, _lib.ptr(lg), b - a, self.B, None, _lib.ptr(labels), 128, 1 if self.rank == 0 else 0,
-                                                   schedule, ws, ms if self.rank == 0 else ws))
-                if self.rank != 0:
+        if self.rank != 0:
+            try:
+                for a, b in mine:
+                    lg = logits_of(a, b)
+                    lib.check(lib.lm_stream_run_logits(fs.handle, _lib.ptr(lg), b - a, self.B, None, _lib.ptr(labels), 128, 0, schedule, ws, ws))
                     self.wire.send(fs.pack(a, b - a), 0)
-        except Exception:
-            if self.rank != 0:
+            except Exception:
                 # ONE failure header in place of the piece that could not be produced: rank 0 receives the pieces sent so far, then the
                 # header, and raises there; waiting for exactly these sends keeps the connection up until it has seen them
                 self.wire.send(None, 0, failed=True)
                 self.wire.drain()
                 self.failed = True
-            raise
-        if self.rank == 0:
+                raise
+            if self.rank == self.group_rank:
+                try:
+                    self.gs.reset()
+                    self.gs.append_packed(self.wire.recv(0))        # raises when rank 0 reports a failure (its own, or another rank's)
+                    self.gs.import_assign(self.wire.recv(0))
+                except Exception:
+                    self.failed = True
+                    raise
+                return self.gs
+            return None
+        # ---- rank 0: its own pieces, then every other rank's in frame order.  Whatever fails here -- its own share, a transfer, a
+        # failure header from a peer -- the ranks that did NOT fail have sends in flight towards rank 0 and group_rank waits for the
+        # matched stream: rank 0 keeps receiving (and discarding) what is still expected, tells group_rank, and only then raises.
+        progress = {"rank": 1, "piece": 0, "dead": set()}
+        try:
+            for a, b in mine:
+                lg = logits_of(a, b)
+                lib.check(lib.lm_stream_run_logits(fs.handle, _lib.ptr(lg), b - a, self.B, None, _lib.ptr(labels), 128, 1, schedule, ws, ms))
             if ms != ws:
                 self._join(ms, ws)
             for r in range(1, self.world):
                 rlo, rhi = frame_range(self.F, r, self.world)
-                for a, b in piece_bounds(rhi - rlo, self.pieces):
-                    fs.append_packed(self.wire.recv(r))
+                for i, (a, b) in enumerate(piece_bounds(rhi - rlo, self.pieces)):
+                    progress["rank"], progress["piece"] = r, i
+                    try:
+                        blk = self.wire.recv(r)
+                    except _PeerFailed:
+                        progress["dead"].add(r)
+                        raise
+                    progress["piece"] = i + 1
+                    fs.append_packed(blk)
                     fs.match(b - a)
+            progress["rank"] = self.world
             if self.group_rank != 0:
                 self.wire.send(fs.pack(0, self.F), self.group_rank)
                 self.wire.send(fs.export_assign(), self.group_rank)
                 return None
             return fs
-        if self.rank == self.group_rank:
-            self.gs.reset()
-            self.gs.append_packed(self.wire.recv(0))
-            self.gs.import_assign(self.wire.recv(0))
-            return self.gs
-        return None
+        except Exception:
+            self.failed = True
+            self._abandon_step(progress)
+            raise
+
+    def _abandon_step(self, progress):
+        """rank 0 after a failure: receive and discard the pieces still expected (a peer that sent a failure header sends nothing
+        after it), report the failure to group_rank unless it is the rank that failed, wait for that send"""
+        for r in range(progress["rank"], self.world):
+            if r in progress["dead"]:
+                continue
+            rlo, rhi = frame_range(self.F, r, self.world)
+            n = len(piece_bounds(rhi - rlo, self.pieces))
+            for _ in range(progress["piece"] if r == progress["rank"] else 0, n):
+                try:
+                    self.wire.recv(r, discard=True)
+                except _PeerFailed:
+                    progress["dead"].add(r)
+                    break
+                except Exception:
+                    break               # the transport itself is gone: nothing more can be received from this rank
+        if self.group_rank != 0 and self.group_rank not in progress["dead"]:
+            try:
+                self.wire.send(None, self.group_rank, failed=True)
+                self.wire.drain()
+            except Exception:
+                pass
 
     def _join(self, side, main):
         """the work queued on the matching stream precedes what follows on the main one"""

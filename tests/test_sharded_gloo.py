@@ -133,3 +133,52 @@ def _failing_worker(rank, world, port, emu_path, out_dir):
 def test_sharded_failure_does_not_hang(emu_lib, tmp_path):
     mp.spawn(_failing_worker, args=(2, _free_port(), emu_lib.path, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "failed_ok_0").exists() and (tmp_path / "failed_ok_1").exists()
+
+
+def _failing_worker3(rank, world, port, emu_path, out_dir, who):
+    """Three ranks, group rank 1, rank `who` fails in its own share.  who = 2: rank 0 meets the failure header while it receives, has to
+    tell rank 1 (blocked waiting for the matched stream).  who = 0: rank 0 fails before it has received anything: it still has to take
+    rank 1's and rank 2's pieces off the wire (their sends would never complete) and tell rank 1.  (both used to hang.)"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    from lecturemath_amd import _lib, sharded, synth
+    lib = _lib.load(emu_path)
+    frames = np.stack(list(synth.binary_stream(15, 96, 160, seed=8, glyphs_per_add=4, max_ext=16)))
+    logits = synth.logits_from_binary(frames, seed=2)
+    f0, f1 = sharded.frame_range(len(frames), rank, world)
+    sh = sharded.ShardedStream(160, 96, len(frames), 4, lib=lib, pieces=3, max_gap=5)
+    assert sh.group_rank == 1
+    calls = [0]
+
+    def produce(a, b):
+        calls[0] += 1
+        if rank == who and calls[0] == 2:
+            raise ValueError("frame source broke")
+        return np.ascontiguousarray(logits[f0 + a:f0 + b])
+    try:
+        sh.step(produce)
+        outcome = "returned"
+    except ValueError:
+        outcome = "producer error"
+    except RuntimeError as e:
+        outcome = "peer failure" if "reported a failure" in str(e) else "other: %s" % e
+    if who == 2:
+        expect = {0: "peer failure", 1: "peer failure", 2: "producer error"}[rank]
+    else:
+        expect = {0: "producer error", 1: "peer failure", 2: "returned"}[rank]
+    assert outcome == expect, (rank, outcome)
+    assert sh.failed == (outcome != "returned")
+    if sh.failed:           # a failed stream refuses another step instead of mixing the old step's pieces into it
+        with pytest.raises(RuntimeError, match="failed in an earlier step"):
+            sh.step(produce)
+    sh.finish()
+    open(os.path.join(out_dir, "failed3_%d_%d" % (who, rank)), "w").write(outcome)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("who", [2, 0])
+def test_sharded_failure_three_ranks(emu_lib, tmp_path, who):
+    mp.spawn(_failing_worker3, args=(3, _free_port(), emu_lib.path, str(tmp_path), who), nprocs=3, join=True)
+    assert all((tmp_path / ("failed3_%d_%d" % (who, r))).exists() for r in range(3))
