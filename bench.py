@@ -144,13 +144,14 @@ def measure_fcn(a, lib, H, W, n_frames, with_oracle):
         if eng.planar:
             # per layer: products per operand pair and the K walk chosen by lecturemath_amd/fcn2.py
             res["engine"] = "planar (csrc/lm_fcn2.hip)"
-            res["layer_formats"] = {str(k): ("f16 hi+lo split, 3 MFMAs per product" if v["terms"] == 3 else "f16, 1 MFMA per product")
+            names = {1: "f16 (1 MFMA per product)", 2: "a2: activations hi+lo (2)", 3: "f16x3: both split (3)", 4: "w2: weights hi+lo (2)"}
+            res["layer_formats"] = {str(k): names[v["terms"]] + (", 16x32 tiles" if v["nc"] == 2 else "") + (", loader wave" if v["loader"] else "")
                                     for k, v in sorted(eng.recipes.items())}
-            res["layer_formats_source"] = "profiles/r03_fcn_layer_precision.json"
+            res["layer_formats_source"] = "profiles/r04_fcn_formats.json (error and binary flips per assignment, 3 seeds), profiles/r03_fcn_layer_precision.json"
             ex = eng.executed_gflop(H, W)
             res.update({"executed_gflop_per_frame": round(ex, 1), "executed_tflops": round(ex / gpu_ms, 2),
                         "frac_of_peak_executed": round(ex / gpu_ms / MFMA_F16_PEAK_TFLOPS, 4),
-                        "mfma_per_product": "3 in the six full-resolution layers, 1 below"})
+                        "mfma_per_product": "per layer (layer_formats): 3 or 2 in the full-resolution layers, 1 below"})
         else:
             k = FCN_MFMA_PER_PRODUCT[a.fcn_precision]
             res.update({"mfma_per_product": k, "executed_tflops": round(k * tflops, 2)})
@@ -165,6 +166,11 @@ def measure_fcn(a, lib, H, W, n_frames, with_oracle):
         res["max_abs_text_diff_vs_oracle"] = float((text.cpu() - t[0, 0]).abs().max())
         res["max_abs_rec_diff_vs_oracle"] = float((rec.cpu() - r[0]).abs().max())
         res["tolerance"] = 1e-3
+        # what the path does with the logits: pixels of the binarised frame that differ from the oracle's binarization of ITS logits
+        from oracle import cc as occ
+        flips = int((occ.threshold_invert(out.cpu().numpy()) != occ.threshold_invert(o[0, 0].numpy())).sum())
+        res["binary_flips_vs_oracle"] = {"count": flips, "fraction": flips / float(H * W), "logit_std": float(o.std()),
+                                         "note": "random-init logits crowd the threshold; three seeds per assignment: profiles/r04_fcn_formats.json"}
         res["cpu_baseline"] = {"value": round(1.0 / cdt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                                "sample": "one 1080p frame, oracle/fcn.py (torch fp32 CPU restatement of FCN_lecturenet.py:260-403)"}
     return res, eng, sd

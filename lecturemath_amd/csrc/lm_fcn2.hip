@@ -17,8 +17,10 @@
 //     column tiles of 16 consecutive pixels) and all MT channel tiles: 4 * MT accumulators of 4 registers;
 //   * K is walked in SLICES of 32: the four 8-wide k-groups of a slice (lane >> 4) are four (plane, tap) pairs chosen by the HOST --
 //     four channel octets of one tap, or two octets of two taps, or taps of a "pair plane" (below) -- so a layer's K needs no padding
-//     beyond its last slice.  The B fragment of k-group g is ONE ds_read_b128 at (pair's slot of the lane's pixel); per slice the
-//     lane's four-way offset pattern comes from a small LDS table, the slice's base offset from a scalar load;
+//     beyond its last slice.  The B fragment of k-group g is ONE ds_read_b128 at (pair's slot of the lane's pixel); the four pairs'
+//     patch offsets of every slice sit in an LDS table (16 bytes per slice, copied once per workgroup): the slice loop issues LDS
+//     operations only, which return in order, so its waits are counted (a scalar load in the loop forced lgkmcnt(0) on every wait:
+//     each slice then paid a full LDS round trip -- 620 cycles per 128 cycles of MFMAs in the deep layers, profiles/r04_fcn_stamps_*);
 //   * weights are the A operand, packed by the host in fragment order per (channel block, weight group, slice, tile, hi | lo);
 //   * staging: the chunk's planes (double-buffered when a layer has several chunks and LDS allows) and the next weight group are
 //     fetched by LDS-DMA while the current group's MFMAs run; one "vmcnt(0) + barrier" per weight group.
@@ -30,35 +32,58 @@
 #if LM_HIP_EMULATED
 lm_f32x4 hipemu_mfma_16x16x32f16(lm_h8 a, lm_h8 b, lm_f32x4 c);
 #define LM_MFMA16(a, b, c) hipemu_mfma_16x16x32f16(a, b, c)
-// the LDS destination is wave-uniform base + lane * 16, the source address is per lane
-#define LM_DMA16(gsrc, lds_base) memcpy((char*)(lds_base) + lm_lane() * 16, (const void*)(gsrc), 16)
+// the LDS destination is wave-uniform base + lane * 16, the source address is base + wave-uniform soff + per-lane voff
+typedef const char* LmRsrc;
+#define LM_MAKE_RSRC(base) ((const char*)(base))
+#define LM_DMA16(rsrc, voff, soff, lds_base) memcpy((char*)(lds_base) + lm_lane() * 16, (rsrc) + (unsigned)(voff) + (unsigned)(soff), 16)
 #define LM_VMWAIT0() ((void)0)
 #else
 #define LM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
-#define LM_DMA16(gsrc, lds_base)                                                                                      \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),                           \
-                                     (__attribute__((address_space(3))) void*)(lds_base), 16, 0, 0)
+// LDS-DMA as `buffer_load_dwordx4 ... offen lds` (a raw buffer over the whole allocation, 32-bit offsets), NOT `global_load_lds_dwordx4`:
+// the compiler's wait-count pass treats a pending global_load_lds as a FLAT access that may return out of order with LDS operations and
+// then waits lgkmcnt(0) before EVERY use of an LDS read -- with weights and patches in flight all through the slice loop, no fragment
+// read was ever left outstanding across an MFMA block (r04: 620 cycles per 128-cycle slice in the deep layers).  The MUBUF form counts
+// on vmcnt only and the loop's LDS waits come out counted.
+typedef __amdgpu_buffer_rsrc_t LmRsrc;
+#define LM_MAKE_RSRC(base) __builtin_amdgcn_make_buffer_rsrc((void*)(base), 0, -1, 0x00020000)
+#define LM_DMA16(rsrc, voff, soff, lds_base) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds_base), 16, (int)(voff), (int)(soff), 0, 0)
 // LDS-DMA is a pending LDS write on the vector-memory counter: the issuing wave waits for its own, the barrier after it covers the
 // other waves' (MI355X_MICROARCH.md, "Two waves per SIMD" item 7)
 #define LM_VMWAIT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 
-// waits until at most n (wave-uniform, 0..6) of the wave's vector-memory operations are outstanding; they retire in issue order, so
+// waits until at most n (wave-uniform) of the wave's vector-memory operations are outstanding; they retire in issue order, so
 // this leaves the n youngest -- the LDS-DMA of the weight group after next -- in flight across the barrier
 LM_DEV void lm_vmwait(int n)
 {
 #if !LM_HIP_EMULATED
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+#define LM_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n < 32 ? n : 32) {      // a smaller count than asked for only waits longer
+        LM_VMW(0) LM_VMW(1) LM_VMW(2) LM_VMW(3) LM_VMW(4) LM_VMW(5) LM_VMW(6) LM_VMW(7) LM_VMW(8) LM_VMW(9) LM_VMW(10) LM_VMW(11) LM_VMW(12) LM_VMW(13)
+        LM_VMW(14) LM_VMW(15) LM_VMW(16) LM_VMW(17) LM_VMW(18) LM_VMW(19) LM_VMW(20) LM_VMW(21) LM_VMW(22) LM_VMW(23) LM_VMW(24) LM_VMW(25) LM_VMW(26)
+        LM_VMW(27) LM_VMW(28) LM_VMW(29) LM_VMW(30) LM_VMW(31)
+        default: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
     }
+#undef LM_VMW
 #endif
 }
+
+// Diagnostic build only (-DLM_G2_STAMPS, tools/variants): per-wave cycle stamps of ONE layer (LM_G2_STAMP_LAYER) into a device buffer that no
+// kernel reads -- where a compute wave's lifetime goes (prologue, slice loops, group barriers, chunk switches, epilogue).
+#ifndef LM_G2_STAMPS
+#define LM_G2_STAMPS 0
+#endif
+#if LM_G2_STAMPS && !LM_HIP_EMULATED
+#define LM_G2_NSTAMP 12
+#define LM_G2_STAMP_WAVES (8192 * 4 * 2)
+__device__ unsigned long long lm_g2_stamp_buf[LM_G2_STAMP_WAVES * LM_G2_NSTAMP];
+#define LM_STAMP_NOW() __builtin_amdgcn_s_memtime()
+#define LM_STAMP_REAL() __builtin_amdgcn_s_memrealtime()
+#else
+#define LM_STAMP_NOW() 0ull
+#define LM_STAMP_REAL() 0ull
+#endif
 
 #define LM_G2_EPI_PO 0      // planar-octet output (+ optional lo planes, + optional 2x2 max-pooled copy), GELU or none
 #define LM_G2_EPI_T 1       // fp32 [pixel][TS] rows of the head row convolutions (lm_k_vsum2_*), no activation
@@ -71,11 +96,10 @@ struct LmG2Args {
     const long long* psrc;          // [nchunks][npc][2] byte offsets of the chunk's planes in the arena: hi, lo
     const char* wpk;                // packed weights: [channel block][wblock_bytes]
     const int4* groups;             // [ngroups] {first slice, slices, chunk, byte offset of the group's weights inside a channel block}
-    const uint2* sdesc;             // [slices] {LDS byte offset of k-group 0's pair inside the patch buffer, pattern}
-    const int* pdelta;              // [npat][4] byte offsets of the k-groups' pairs relative to k-group 0
+    const int4* t4;                 // [slices + 2] LDS byte offsets of the four k-groups' pairs inside the patch buffer (two entries of look-ahead)
     const float* bias;              // [Cout] in the kernel's channel order (= natural order)
     long long wblock_bytes;
-    int nchunks, npc, ngroups, npat;
+    int nchunks, npc, ngroups, nslices;
     int wbuf_bytes;                 // LDS bytes of one weight buffer (largest group)
     int wring;                      // weight buffers (2 or 3): wring - 1 groups are in flight or in use ahead of the one being read
     int pdouble;                    // 1: two patch buffers (next chunk fetched under the current one)
@@ -85,6 +109,7 @@ struct LmG2Args {
     int H, W;                       // output grid of this launch (bounds of the stores; the input grid for EPI_TC)
     int act;                        // LM_ACT_GELU or LM_ACT_NONE
     int tc_merged;                  // EPI_TC: 1 = LM_G2_EPI_TC2 (parity = dy, tile pair q = dx)
+    int stamp;                      // diagnostic builds: this launch writes its stamps
     // EPI_PO / EPI_TC output tensor
     char* out_hi; char* out_lo;     // plane 0 of the hi / lo parts (lo may be null)
     long long out_plane;            // bytes per plane
@@ -94,16 +119,27 @@ struct LmG2Args {
     float* tout; int ts, tn;        // [pixel][ts] floats, the first tn of the 16 rows are stored
 };
 
-// one 16 x 16 pixel tile x MT channel tiles; see the header comment
-template <int KH, int KW, int TERMS, int MT, int EPI>
-__global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a, const long long* __restrict__ t_psrc, const int4* __restrict__ t_groups,
-                                                  const uint2* __restrict__ t_sdesc, const int* __restrict__ t_pdelta, const float* __restrict__ t_bias)
+// one tile of 16 rows x 16 * NC columns x MT channel tiles; see the header comment.
+//   NC      column tiles of 16 pixels per wave row group: the wave's 4 rows x NC x 16 pixels share every weight fragment (2 = a 16 x 32
+//           tile: half the weight bytes fetched and half the A-fragment LDS reads per pixel)
+//   LOADER  1: waves 0..3 compute (LDS reads + MFMAs, no vector-memory instruction in their loop) and wave 4 issues every LDS-DMA of the
+//           workgroup and waits for them; 0: four waves, each issues its quarter of the fetches in front of its slice loop.
+//           r04 stamps (profiles/r04_fcn_stamps_v2.txt): DMA issue -- back-pressured by the CU's fetch rate -- was 50 % of a wave's time in
+//           the deep layers and 15-25 % at full resolution, all of it in front of the MFMAs of the same wave.  The fifth wave costs
+//           registers: with two workgroups per CU one SIMD hosts three waves (<= 168 VGPRs), so the widest instances keep LOADER = 0.
+template <int KH, int KW, int TERMS, int MT, int EPI, int NC, int LOADER>
+__global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 || (MT >= 3 && TERMS != 1)) ? 2 : 3) : 2)
+    lm_k_g2(const LmG2Args a, const long long* __restrict__ t_psrc, const int4* __restrict__ t_groups, const int4* __restrict__ t_t4,
+            const float* __restrict__ t_bias)
 {
     // The tables come as __restrict__ kernel arguments of their own: read-only and never aliased by the kernel's stores, they are read
     // with SCALAR loads.  As members of `a` they were vector loads -- and a wave waits for a vector load's result with vmcnt, which also
     // waits for every LDS-DMA issued before it: one such load per slice serialised the whole fetch pipeline.
     LM_DYN_SMEM(smem);
-    constexpr int PW = 16 + KW - 1, PH = 16 + KH - 1, NSLOT = PH * PW;
+    [[maybe_unused]] const unsigned long long st_t0 = LM_STAMP_NOW(), st_r0 = LM_STAMP_REAL();
+    [[maybe_unused]] unsigned long long st_compute = 0, st_wait = 0, st_switch = 0, st_pro = 0, st_mark = 0, st_issue = 0, st_bar = 0;
+    constexpr int TW = 16 * NC;                         // tile width in pixels
+    constexpr int PW = TW + KW - 1, PH = 16 + KH - 1, NSLOT = PH * PW;
     constexpr int PLS = (NSLOT * 16 + 255) & ~255;      // LDS bytes per plane: planes a multiple of the 256-B bank row apart, so the 16
                                                         // lanes of a ds_read_b128 service group (16 different pixels of a row, two
                                                         // k-groups) fall on 16 different 16-B slots
@@ -112,9 +148,13 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a, const long l
     constexpr bool SPLIT_B = TERMS == 2 || TERMS == 3, SPLIT_A = TERMS >= 3;
     constexpr int NHL = SPLIT_B ? 2 : 1;                // patch planes per octet: hi (, lo)
     constexpr int NWL = SPLIT_A ? 2 : 1;                // weight fragments per tile: hi (, lo)
-    constexpr int NJ = (NSLOT + 255) / 256;             // DMA instructions per thread and plane
-    constexpr int NT = 4;
+    constexpr int NT = 4 * NC;                          // pixel fragments per wave: index c * 4 + r = column tile c, row r
+    constexpr int NIW = LOADER ? 1 : 4;                 // waves that issue DMA
+    constexpr int NTHR = LOADER ? 320 : 256;
+    constexpr int NJ = (NSLOT + 64 * NIW - 1) / (64 * NIW);    // DMA instructions per issuing wave and plane
     const int lane = lm_lane(), wave = LM_UNIFORM((int)(threadIdx.x >> 6)), kg = lane >> 4, col = lane & 15;
+    const bool issuer = LOADER ? wave == 4 : true, computes = wave < 4;
+    const int iw = LOADER ? 0 : wave;
     // Workgroup -> (pixel tile, channel block).  The launch is one-dimensional; consecutive ids go round the 8 XCDs, so id % 8 names
     // the workgroups that share an L2.  Each of them takes a contiguous share of the (channel block, tile) list: an XCD then streams
     // the weights of one or two channel blocks (they stay in its 4 MB L2) instead of every block's (5-10 MB in the deep layers).
@@ -128,45 +168,46 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a, const long l
     const int cby = (EPI == LM_G2_EPI_TC) ? cblk % a.cblocks : cblk, par = (EPI == LM_G2_EPI_TC) ? cblk / a.cblocks : 0;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int pbuf_bytes = a.npc * NHL * PLS;
-    char* const s_pat = smem;                                           // [npat][64] ints: column part + pattern offset of the lane's k-group
-    char* const s_p0 = smem + ((a.npat * 256 + 255) & ~255);
+    char* const s_t4 = smem;                                            // [nslices + 2] int4: the slices' four pair offsets
+    char* const s_p0 = smem + (((a.nslices + 2) * 16 + 255) & ~255);
     char* const s_w0 = s_p0 + (a.pdouble ? 2 : 1) * pbuf_bytes;
-    if (wave == 0)
-        for (int p = 0; p < a.npat; p++) ((int*)s_pat)[p * 64 + lane] = col * 16 + t_pdelta[p * 4 + kg];
+    for (int i = (int)threadIdx.x; i < a.nslices + 2; i += NTHR) ((int4*)s_t4)[i] = t_t4[i];       // visible after the prologue's barrier
     const int wrow = wave * (4 * PW * 16);                              // the wave's first pixel row inside a plane
 
-    // DMA source offsets of the thread's slots inside a plane (the same for every plane and chunk)
+    // DMA source offsets of the lane's slots inside a plane (the same for every plane and chunk)
     int goff[NJ];
     bool gval[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-        const int slot = (j * 4 + wave) * 64 + lane;
+        const int slot = (j * NIW + iw) * 64 + lane;
         const int row = slot / PW, x = slot - row * PW;
         goff[j] = (row * a.Wp_in + x) * 16;
         gval[j] = slot < NSLOT;
     }
-    const long long tile_org = ((long long)(ty * 16) * a.Wp_in + tx * 16 + a.org_in) * 16;
-    const char* const wsrc = a.wpk + ((long long)par * a.cblocks + cby) * a.wblock_bytes;
+    // byte offsets below 4 GB: the arena's size is checked by lm_fcn2_create, a layer's packed weights by lm_fcn2_set_layer
+    const unsigned tile_org = (unsigned)(((long long)(ty * 16) * a.Wp_in + tx * TW + a.org_in) * 16);
+    const unsigned wsrc = (unsigned)(((long long)par * a.cblocks + cby) * a.wblock_bytes);
+    const LmRsrc r_arena = LM_MAKE_RSRC(a.arena), r_w = LM_MAKE_RSRC(a.wpk);
 
     auto issue_patch = [&](int chunk, int buf) {
         char* const dst = s_p0 + buf * pbuf_bytes;
         for (int p = 0; p < a.npc; p++)
 #pragma unroll
             for (int hl = 0; hl < NHL; hl++) {
-                const char* src = a.arena + t_psrc[(chunk * a.npc + p) * 2 + hl] + tile_org;
+                const unsigned src = (unsigned)t_psrc[(chunk * a.npc + p) * 2 + hl] + tile_org;
 #pragma unroll
                 for (int j = 0; j < NJ; j++)
-                    if (gval[j]) LM_DMA16(src + goff[j], dst + (p * NHL + hl) * PLS + (j * 4 + wave) * 1024);
+                    if (gval[j]) LM_DMA16(r_arena, goff[j], src, dst + (p * NHL + hl) * PLS + (j * NIW + iw) * 1024);
             }
     };
-    // returns the number of DMA instructions THIS wave issued (wave-uniform: a group is a whole number of 1-KB fragments)
-    auto issue_weights = [&](const int4 grp, int buf) -> int {
-        const char* src = wsrc + grp.w;
+    // returns the number of DMA instructions THIS wave issued (a group is a whole number of 1-KB fragments)
+    auto issue_weights = [&](const int4 g4, int buf) -> int {
+        const unsigned src = wsrc + (unsigned)g4.w;
         char* const dst = s_w0 + buf * a.wbuf_bytes;
-        const int n16 = grp.y * (MT * NWL * 64);
-        for (int i = (int)threadIdx.x; i < n16; i += 256) LM_DMA16(src + (long long)i * 16, dst + (i - lane) * 16);
-        const int mine = n16 - wave * 64;
-        return mine > 0 ? (mine + 255) >> 8 : 0;
+        const int n = g4.y * (MT * NWL);
+        int cnt = 0;
+        for (int i = iw; i < n; i += NIW, cnt++) LM_DMA16(r_w, lane * 16, src + (unsigned)i * 1024, dst + i * 1024);
+        return cnt;
     };
 
     lm_f32x4 acc[MT][NT];
@@ -178,122 +219,156 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a, const long l
             for (int r = 0; r < 4; r++) acc[m][n][r] = 0.0f;
 
     // Weight groups go through a ring of a.wring buffers: while group g is read, g + 1 has landed or is landing and (ring of 3) g + 2
-    // is being fetched.  Per group: issue the fetches, run the group's MFMAs, wait until only the youngest fetch (the group after
-    // next) is outstanding, barrier.
+    // is being fetched.  Per group: the issuers issue the fetches, the compute waves run the group's MFMAs, the issuers wait until only
+    // their youngest fetches (the group after next) are outstanding, barrier.
     const int ring = a.wring;
     int4 grp = t_groups[0];
-    issue_patch(0, 0);
-    issue_weights(grp, 0);
     int n_ahead = 0;                            // DMA instructions of this wave that may stay in flight across the next barrier
     int4 nxt = grp;
-    if (a.ngroups > 1) { nxt = t_groups[1]; n_ahead = issue_weights(nxt, 1); }
-    if (ring < 3) n_ahead = 0;
-    lm_vmwait(n_ahead);
+    if (a.ngroups > 1) nxt = t_groups[1];
+    if (issuer) {
+        issue_patch(0, 0);
+        issue_weights(grp, 0);
+        if (a.ngroups > 1) n_ahead = issue_weights(nxt, 1);
+        if (ring < 3) n_ahead = 0;
+        lm_vmwait(n_ahead);
+    }
     lm_lds_barrier();
+    st_pro = st_mark = LM_STAMP_NOW();
     int pb = 0, wb = 0, prev_chunk = -1;
     for (int g = 0; g < a.ngroups; g++) {
         const bool more = g + 1 < a.ngroups;
-        int wb2 = wb + 2; if (wb2 >= ring) wb2 -= ring;
-        // first group of a chunk: the next chunk's planes go into the other patch buffer, read last before the barrier that ended the
-        // previous chunk.  Issued BEFORE the weights: it must have landed by the end of this group, the weights need not.
-        if (a.pdouble && grp.z + 1 < a.nchunks && grp.z != prev_chunk) issue_patch(grp.z + 1, pb ^ 1);
-        prev_chunk = grp.z;
-        n_ahead = 0;
-        if (ring >= 3) {
-            if (g + 2 < a.ngroups) n_ahead = issue_weights(t_groups[g + 2], wb2);
-        } else if (more && g > 0) {
-            // ring of 2: group g + 1 goes into the buffer group g - 1 was read from (group 1 was fetched in the prologue)
-            issue_weights(nxt, wb ^ 1);
+        int4 nx2 = nxt;
+        if (g + 2 < a.ngroups) nx2 = t_groups[g + 2];       // scalar load, back long before the group ends
+        if (issuer) {
+            int wb2 = wb + 2; if (wb2 >= ring) wb2 -= ring;
+            // first group of a chunk: the next chunk's planes go into the other patch buffer, read last before the barrier that ended the
+            // previous chunk.  Issued BEFORE the weights: it must have landed by the end of this group, the weights need not.
+            if (a.pdouble && grp.z + 1 < a.nchunks && grp.z != prev_chunk) issue_patch(grp.z + 1, pb ^ 1);
+            n_ahead = 0;
+            if (ring >= 3) {
+                if (g + 2 < a.ngroups) n_ahead = issue_weights(nx2, wb2);
+            } else if (more && g > 0) {
+                // ring of 2: group g + 1 goes into the buffer group g - 1 was read from (group 1 was fetched in the prologue)
+                issue_weights(nxt, wb ^ 1);
+            }
         }
-        const char* const pbase = s_p0 + pb * pbuf_bytes + wrow;
-        const char* const wbase = s_w0 + wb * a.wbuf_bytes + lane * 16;
-        // The group's slices, software-pipelined by hand: the fragments of slice s + 1 are requested before the MFMAs of slice s, its
-        // descriptor (scalar load -> pattern word from LDS -> fragment addresses: three dependent latencies) one slice earlier still.
-        // t_sdesc is padded by two entries, so the look-ahead needs no bounds.
-        struct Frag { lm_h8 bh[NT], bl[NT], ah[MT], al[MT]; };
-        auto pat = [&](const uint2 d) { return ((const int*)s_pat)[(int)d.y * 64 + lane]; };
-        auto load = [&](const uint2 d, int po, int sl, Frag& f) {
-            const char* pa = pbase + d.x + po;
-            const char* wa = wbase + sl * (MT * NWL * 1024);
+        prev_chunk = grp.z;
+#if LM_G2_STAMPS && !LM_HIP_EMULATED
+        { const unsigned long long t = LM_STAMP_NOW(); st_issue += t - st_mark; st_mark = t; }
+#endif
+        if (computes) {
+            const char* const pbase = s_p0 + pb * pbuf_bytes + wrow;
+            const char* const wbase = s_w0 + wb * a.wbuf_bytes + lane * 16;
+            struct Frag { lm_h8 bh[NT], bl[NT], ah[MT], al[MT]; };
+            const int* const tq = (const int*)s_t4 + grp.x * 4 + kg;        // the lane's k-group column of the group's table rows
+            const int lanecol = col * 16;
+            auto load = [&](int po, int sl, Frag& f) {
+                const char* pa = pbase + po + lanecol;
+                const char* wa = wbase + sl * (MT * NWL * 1024);
 #pragma unroll
-            for (int n = 0; n < NT; n++) {
-                f.bh[n] = *(const lm_h8*)(pa + n * (PW * 16));
-                if (SPLIT_B) f.bl[n] = *(const lm_h8*)(pa + n * (PW * 16) + PLS);
-            }
+                for (int c = 0; c < NC; c++)
 #pragma unroll
-            for (int m = 0; m < MT; m++) {
-                f.ah[m] = *(const lm_h8*)(wa + m * (NWL * 1024));
-                if (SPLIT_A) f.al[m] = *(const lm_h8*)(wa + m * (NWL * 1024) + 1024);
-            }
-        };
-        auto mma = [&](const Frag& f) {
+                    for (int r = 0; r < 4; r++) {
+                        f.bh[c * 4 + r] = *(const lm_h8*)(pa + r * (PW * 16) + c * 256);
+                        if (SPLIT_B) f.bl[c * 4 + r] = *(const lm_h8*)(pa + r * (PW * 16) + c * 256 + PLS);
+                    }
 #pragma unroll
-            for (int m = 0; m < MT; m++)
-#pragma unroll
-                for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA16(f.ah[m], f.bh[n], acc[m][n]);
-            if (SPLIT_A) {
-#pragma unroll
-                for (int m = 0; m < MT; m++)
-#pragma unroll
-                    for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA16(f.al[m], f.bh[n], acc[m][n]);
-            }
-            if (SPLIT_B) {
+                for (int m = 0; m < MT; m++) {
+                    f.ah[m] = *(const lm_h8*)(wa + m * (NWL * 1024));
+                    if (SPLIT_A) f.al[m] = *(const lm_h8*)(wa + m * (NWL * 1024) + 1024);
+                }
+            };
+            auto mma = [&](const Frag& f) {
 #pragma unroll
                 for (int m = 0; m < MT; m++)
 #pragma unroll
-                    for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA16(f.ah[m], f.bl[n], acc[m][n]);
-            }
-        };
-        {
-            const uint2* dsc = t_sdesc + grp.x;
+                    for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA16(f.ah[m], f.bh[n], acc[m][n]);
+                if (SPLIT_A) {
+#pragma unroll
+                    for (int m = 0; m < MT; m++)
+#pragma unroll
+                        for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA16(f.al[m], f.bh[n], acc[m][n]);
+                }
+                if (SPLIT_B) {
+#pragma unroll
+                    for (int m = 0; m < MT; m++)
+#pragma unroll
+                        for (int n = 0; n < NT; n++) acc[m][n] = LM_MFMA16(f.ah[m], f.bl[n], acc[m][n]);
+                }
+            };
+            // The group's slices, software-pipelined by hand with an UNCONDITIONAL body: the fragments of slice s + 1 are requested
+            // before the MFMAs of slice s, the table word of slice s + 2 before that (the table is padded, the look-ahead needs no bounds).
             const int ns = grp.y;
             Frag f0, f1;
-            uint2 dn = dsc[1];
-            int pn = pat(dn);
-            load(dsc[0], pat(dsc[0]), 0, f0);
+            int o1 = tq[4];
+            load(tq[0], 0, f0);
             int sl = 0;
-            for (; sl + 1 < ns; sl += 2) {
-                const uint2 d2 = dsc[sl + 2];
-                const int p2 = pat(d2);
-                load(dn, pn, sl + 1, f1);
-                LM_SCHED_BARRIER();         // the requests stay IN FRONT of the MFMAs they hide behind (left alone, the scheduler sank them to the
-                mma(f0);                    // end of the MFMA block, right before the wait for them)
-                dn = dsc[sl + 3];
-                pn = pat(dn);
-                if (sl + 2 < ns) load(d2, p2, sl + 2, f0);
+            for (; sl + 2 < ns; sl += 2) {
+                const int o2 = tq[(sl + 2) * 4];
+                load(o1, sl + 1, f1);
+                LM_SCHED_BARRIER();         // the requests stay IN FRONT of the MFMAs they hide behind (left alone, the scheduler sank them to
+                mma(f0);                    // the end of the MFMA block, right before the wait for them)
+                o1 = tq[(sl + 3) * 4];
+                load(o2, sl + 2, f0);
                 LM_SCHED_BARRIER();
                 mma(f1);
             }
-            if (sl < ns) mma(f0);
+            if (sl + 1 < ns) {
+                load(o1, sl + 1, f1);
+                LM_SCHED_BARRIER();
+                mma(f0);
+                mma(f1);
+            } else
+                mma(f0);
         }
-        lm_vmwait(n_ahead);
+#if LM_G2_STAMPS && !LM_HIP_EMULATED
+        { const unsigned long long t = LM_STAMP_NOW(); st_compute += t - st_mark; st_mark = t; }
+#endif
+        if (issuer) lm_vmwait(n_ahead);
+#if LM_G2_STAMPS && !LM_HIP_EMULATED
+        { const unsigned long long t = LM_STAMP_NOW(); st_wait += t - st_mark; st_mark = t; }
+#endif
         lm_lds_barrier();       // this group's buffer is free; the next group's weights (and the next chunk's planes) have landed
+#if LM_G2_STAMPS && !LM_HIP_EMULATED
+        { const unsigned long long t = LM_STAMP_NOW(); st_bar += t - st_mark; st_mark = t; }
+#endif
         if (++wb >= ring) wb = 0;
         if (more) {
             const int4 cur = grp;
             grp = nxt;
-            if (g + 2 < a.ngroups) nxt = t_groups[g + 2];
+            nxt = nx2;
             if (grp.z != cur.z) {
                 if (a.pdouble) pb ^= 1;
                 else {              // one patch buffer: the next chunk's planes are fetched now, in the open
-                    issue_patch(grp.z, 0);
-                    LM_VMWAIT0();
+                    if (issuer) {
+                        issue_patch(grp.z, 0);
+                        LM_VMWAIT0();
+                    }
                     lm_lds_barrier();
+#if LM_G2_STAMPS && !LM_HIP_EMULATED
+                    { const unsigned long long t = LM_STAMP_NOW(); st_switch += t - st_mark; st_mark = t; }
+#endif
                 }
             }
         }
     }
+    if (!computes) return;
 
     // ---------------------------------------------------------------- epilogues
-    // D[row = 4 * kg + r][col]: row = channel of the tile, col = pixel `col` of the wave's row n
-    const int y0 = ty * 16 + wave * 4, x = tx * 16 + col;
+    // D[row = 4 * kg + r][col]: row = channel of the tile, col = pixel `col` of the wave's row r in column tile c
+    const int y0 = ty * 16 + wave * 4;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+    const int x = tx * TW + c * 16 + col;
     if constexpr (EPI == LM_G2_EPI_T) {
         static_assert(MT == 1, "the head rows have at most 16 outputs");
         if (4 * kg < a.tn && x < a.W) {
 #pragma unroll
-            for (int n = 0; n < NT; n++) {
+            for (int n = 0; n < 4; n++) {
                 const int y = y0 + n;
-                if (y < a.H) *(float4*)(a.tout + ((long long)y * a.W + x) * a.ts + 4 * kg) = make_float4(acc[0][n][0], acc[0][n][1], acc[0][n][2], acc[0][n][3]);
+                const lm_f32x4 v = acc[0][c * 4 + n];
+                if (y < a.H) *(float4*)(a.tout + ((long long)y * a.W + x) * a.ts + 4 * kg) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
     } else {
@@ -311,16 +386,16 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a, const long l
             const float4 b0 = *(const float4*)(t_bias + ch), b1 = *(const float4*)(t_bias + ch + 4);
             const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
             const long long oplane = (long long)(ch >> 3) * a.out_plane;
-            float v[NT][8];
+            float v[4][8];
 #pragma unroll
-            for (int n = 0; n < NT; n++)
+            for (int n = 0; n < 4; n++)
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const float t = acc[2 * q + (j >> 2)][n][j & 3] + bb[j];
+                    const float t = acc[2 * q + (j >> 2)][c * 4 + n][j & 3] + bb[j];
                     v[n][j] = gelu ? lm_gelu(t) : t;
                 }
 #pragma unroll
-            for (int n = 0; n < NT; n++) {
+            for (int n = 0; n < 4; n++) {
                 const int y = y0 + n;
                 if (y >= a.H || x >= a.W) continue;
                 lm_h8 hi, lo;
@@ -333,7 +408,7 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a, const long l
             if constexpr (EPI == LM_G2_EPI_PO) {
                 if (a.pool_hi) {        // 2x2 / stride 2 max pooling (floor): rows (n, n + 1), columns (col, col ^ 1)
 #pragma unroll
-                    for (int n = 0; n < NT; n += 2) {
+                    for (int n = 0; n < 4; n += 2) {
                         lm_h8 ph, pl;
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
@@ -358,16 +433,16 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a, const long l
             const float4 b0 = *(const float4*)(t_bias + ch);
             const float bb[4] = {b0.x, b0.y, b0.z, b0.w};
             const long long oplane = (long long)(ch >> 3) * a.out_plane + (kg & 1) * 8;
-            float v[NT][4];
+            float v[4][4];
 #pragma unroll
-            for (int n = 0; n < NT; n++)
+            for (int n = 0; n < 4; n++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const float t = acc[m][n][j] + bb[j];
+                    const float t = acc[m][c * 4 + n][j] + bb[j];
                     v[n][j] = gelu ? lm_gelu(t) : t;
                 }
 #pragma unroll
-            for (int n = 0; n < NT; n++) {
+            for (int n = 0; n < 4; n++) {
                 const int y = y0 + n;
                 if (y >= a.H || x >= a.W) continue;
                 lm_h4 hi, lo;
@@ -380,7 +455,7 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a, const long l
             if constexpr (EPI == LM_G2_EPI_PO) {
                 if (a.pool_hi) {
 #pragma unroll
-                    for (int n = 0; n < NT; n += 2) {
+                    for (int n = 0; n < 4; n += 2) {
                         lm_h4 ph, pl;
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
@@ -399,6 +474,19 @@ __global__ void __launch_bounds__(256, 2) lm_k_g2(const LmG2Args a, const long l
             }
         }
     }
+    }
+#if LM_G2_STAMPS && !LM_HIP_EMULATED
+    if (a.stamp && lane == 0) {
+        const unsigned long long t_loop = st_mark;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = LM_STAMP_NOW();
+        const size_t w = (size_t)blockIdx.x * 4 + wave;
+        if (w < LM_G2_STAMP_WAVES) {
+            unsigned long long* o = lm_g2_stamp_buf + w * LM_G2_NSTAMP;
+            o[0] = st_t0; o[1] = st_pro; o[2] = st_compute; o[3] = st_wait; o[4] = st_switch; o[5] = t_loop; o[6] = t_end; o[7] = __builtin_amdgcn_s_memrealtime(); o[8] = st_r0; o[9] = st_issue; o[10] = st_bar; o[11] = 0;
+        }
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -515,11 +603,11 @@ struct LmF2Tensor {
 };
 
 struct LmF2Layer {
-    int kh = 0, kw = 0, terms = 0, mt = 0, epi = 0, nchunks = 0, npc = 0, ngroups = 0, nslices = 0, npat = 0, pdouble = 0, wbuf_bytes = 0, cout = 0;
+    int kh = 0, kw = 0, terms = 0, mt = 0, epi = 0, nchunks = 0, npc = 0, ngroups = 0, nslices = 0, pdouble = 0, wbuf_bytes = 0, cout = 0, nc = 1, loader = 0;
     std::vector<int> planes;            // [nchunks * npc][2] tensor id, octet
     long long wblock_bytes = 0;
     char* d_w = nullptr; float* d_bias = nullptr;
-    int4* d_groups = nullptr; uint2* d_sdesc = nullptr; int* d_pdelta = nullptr; long long* d_psrc = nullptr;
+    int4* d_groups = nullptr; int4* d_t4 = nullptr; long long* d_psrc = nullptr;
     bool set = false;
 };
 
@@ -540,7 +628,7 @@ static void lm_f2_geometry(LmFcn2* f, int h, int w)
 {
     for (auto& t : f->t) {
         t.H = h >> t.level; t.W = w >> t.level; t.halo = lm_f2_halo(t.level);
-        t.Hp = ((t.H + 15) & ~15) + 2 * t.halo; t.Wp = ((t.W + 15) & ~15) + 2 * t.halo;
+        t.Hp = ((t.H + 15) & ~15) + 2 * t.halo; t.Wp = ((t.W + 31) & ~31) + 2 * t.halo;     // whole 16 x 32 tiles
         t.plane = (long long)t.Hp * t.Wp * 16;
     }
 }
@@ -551,7 +639,7 @@ extern "C" void lm_fcn2_destroy(LmFcn2* f)
     if (f->arena) (void)hipFree(f->arena);
     for (float* p : {f->tbuf, f->text, f->rec4, f->outl}) if (p) (void)hipFree(p);
     for (auto& l : f->layer)
-        for (void* p : {(void*)l.d_w, (void*)l.d_bias, (void*)l.d_groups, (void*)l.d_sdesc, (void*)l.d_pdelta, (void*)l.d_psrc}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)l.d_w, (void*)l.d_bias, (void*)l.d_groups, (void*)l.d_t4, (void*)l.d_psrc}) if (p) (void)hipFree(p);
     delete f;
 }
 
@@ -579,6 +667,11 @@ extern "C" LmFcn2* lm_fcn2_create(const int32_t* widths18, const int32_t* lo25, 
     long long off = 0;
     for (auto& t : f->t) { t.off = off; off += (long long)t.c8 * (1 + t.lo) * t.plane + 4096; }
     f->arena_bytes = off;
+    if (off >= (1ll << 32) - (1 << 20)) {        // lm_k_g2 addresses the arena through ONE raw buffer with 32-bit offsets
+        lm_set_error("lm_fcn2_create: %lld MB of activations for %dx%d frames exceed the 4 GB one buffer addresses (the network runs at <= 2.5 MP)", off >> 20, max_w, max_h);
+        delete f;
+        return nullptr;
+    }
     const size_t px = (size_t)max_h * max_w;
     if (hipMalloc((void**)&f->arena, (size_t)off) != hipSuccess || hipMalloc((void**)&f->tbuf, px * 16 * 4) != hipSuccess ||
         hipMalloc((void**)&f->text, px * 4) != hipSuccess || hipMalloc((void**)&f->rec4, px * 16) != hipSuccess ||
@@ -591,7 +684,7 @@ extern "C" LmFcn2* lm_fcn2_create(const int32_t* widths18, const int32_t* lo25, 
 }
 
 // One layer's recipe (lecturemath_amd/fcn2.py builds it and documents the layout).  desc: kh, kw, terms, mt, epi, nchunks, npc, ngroups,
-// nslices, npat, pdouble, wbuf_bytes, cout, then planes [nchunks * npc][2], groups [ngroups][3], sdesc [nslices][2], pdelta [npat][4].
+// nslices, flags (bits 0-3: column tiles per wave, 1 or 2; bit 8: loader wave), pdouble, wbuf_bytes, cout, then planes [nchunks * npc][2], groups [ngroups][3], slice table [nslices][4].
 // HOST pointers.  wblocks = channel blocks (x 4 parities for a transposed convolution) of wbytes / wblocks bytes each.
 extern "C" int lm_fcn2_set_layer(LmFcn2* f, int layer, const int32_t* desc, int ndesc, const void* h_w, int64_t wbytes, int wblocks, const float* h_bias,
                                  int nbias)
@@ -601,12 +694,12 @@ extern "C" int lm_fcn2_set_layer(LmFcn2* f, int layer, const int32_t* desc, int 
         return LM_ERR_ARG;
     }
     LmF2Layer& l = f->layer[layer];
-    for (void* p : {(void*)l.d_w, (void*)l.d_bias, (void*)l.d_groups, (void*)l.d_sdesc, (void*)l.d_pdelta, (void*)l.d_psrc}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)l.d_w, (void*)l.d_bias, (void*)l.d_groups, (void*)l.d_t4, (void*)l.d_psrc}) if (p) (void)hipFree(p);
     l = LmF2Layer();
     l.kh = desc[0]; l.kw = desc[1]; l.terms = desc[2]; l.mt = desc[3]; l.epi = desc[4]; l.nchunks = desc[5]; l.npc = desc[6]; l.ngroups = desc[7];
-    l.nslices = desc[8]; l.npat = desc[9]; l.pdouble = desc[10]; l.wbuf_bytes = desc[11]; l.cout = desc[12];
-    const long long need = 13 + (long long)l.nchunks * l.npc * 2 + (long long)l.ngroups * 3 + (long long)l.nslices * 2 + (long long)l.npat * 4;
-    if (l.nchunks <= 0 || l.npc <= 0 || l.ngroups <= 0 || l.nslices <= 0 || l.npat <= 0 || l.npat > 16 || need != ndesc || wbytes % wblocks) {
+    l.nslices = desc[8]; l.nc = (desc[9] & 15) ? (desc[9] & 15) : 1; l.loader = (desc[9] >> 8) & 1; l.pdouble = desc[10]; l.wbuf_bytes = desc[11]; l.cout = desc[12];
+    const long long need = 13 + (long long)l.nchunks * l.npc * 2 + (long long)l.ngroups * 3 + (long long)l.nslices * 4;
+    if (l.nchunks <= 0 || l.npc <= 0 || l.ngroups <= 0 || l.nslices <= 0 || need != ndesc || wbytes % wblocks || wbytes >= (1ll << 31) || l.nc < 1 || l.nc > 2) {
         lm_set_error("lm_fcn2_set_layer: inconsistent recipe for layer %d", layer);
         return LM_ERR_ARG;
     }
@@ -630,72 +723,82 @@ extern "C" int lm_fcn2_set_layer(LmFcn2* f, int layer, const int32_t* desc, int 
         }
     }
     if ((long long)l.nslices * l.mt * nwl * 1024 != l.wblock_bytes) { lm_set_error("lm_fcn2_set_layer: layer %d: weight bytes do not match the slices", layer); return LM_ERR_ARG; }
-    const int32_t* h_sdesc = p; p += (size_t)l.nslices * 2;
-    const int32_t* h_pdelta = p;
+    // slice table: every offset must leave the lane's reads (16 x 16 pixels, four rows per wave) inside the chunk's patch planes
+    std::vector<int4> t4((size_t)l.nslices + 2);
+    {
+        const int PW = 16 * l.nc + l.kw - 1, PH = 16 + l.kh - 1, PLS = (PH * PW * 16 + 255) & ~255, nhl = (l.terms == 2 || l.terms == 3) ? 2 : 1;
+        for (int i = 0; i < l.nslices; i++, p += 4) {
+            t4[i] = make_int4(p[0], p[1], p[2], p[3]);
+            for (int k = 0; k < 4; k++) {
+                const int plane = p[k] / (nhl * PLS), rest = p[k] - plane * nhl * PLS;
+                if (p[k] < 0 || plane >= l.npc || rest % 16 || rest / 16 / PW > l.kh - 1 || rest / 16 % PW > l.kw - 1) {
+                    lm_set_error("lm_fcn2_set_layer: slice %d of layer %d reads outside its patch", i, layer);
+                    return LM_ERR_ARG;
+                }
+            }
+        }
+        t4[l.nslices] = t4[l.nslices + 1] = t4[l.nslices - 1];
+    }
     LM_HIP(hipMalloc((void**)&l.d_w, (size_t)wbytes));
     LM_HIP(hipMalloc((void**)&l.d_bias, (size_t)nbias * 4));
     LM_HIP(hipMalloc((void**)&l.d_groups, groups.size() * sizeof(int4)));
-    LM_HIP(hipMalloc((void**)&l.d_sdesc, (size_t)(l.nslices + 2) * 8));      // + 2: the kernel's descriptor look-ahead
-    LM_HIP(hipMalloc((void**)&l.d_pdelta, (size_t)l.npat * 16));
+    LM_HIP(hipMalloc((void**)&l.d_t4, t4.size() * sizeof(int4)));             // + 2: the kernel's look-ahead
     LM_HIP(hipMalloc((void**)&l.d_psrc, (size_t)l.nchunks * l.npc * 16));
     LM_HIP(hipMemcpy(l.d_w, h_w, (size_t)wbytes, hipMemcpyHostToDevice));
     LM_HIP(hipMemcpy(l.d_bias, h_bias, (size_t)nbias * 4, hipMemcpyHostToDevice));
     LM_HIP(hipMemcpy(l.d_groups, groups.data(), groups.size() * sizeof(int4), hipMemcpyHostToDevice));
-    LM_HIP(hipMemcpy(l.d_sdesc, h_sdesc, (size_t)l.nslices * 8, hipMemcpyHostToDevice));
-    for (int k = 0; k < 2; k++) LM_HIP(hipMemcpy(l.d_sdesc + l.nslices + k, h_sdesc + (size_t)(l.nslices - 1) * 2, 8, hipMemcpyHostToDevice));
-    LM_HIP(hipMemcpy(l.d_pdelta, h_pdelta, (size_t)l.npat * 16, hipMemcpyHostToDevice));
+    LM_HIP(hipMemcpy(l.d_t4, t4.data(), t4.size() * sizeof(int4), hipMemcpyHostToDevice));
     l.set = true;
     f->cur_h = f->cur_w = 0;        // plane tables are rebuilt by the next forward
     return LM_OK;
 }
 
-template <int KH, int KW, int TERMS, int MT, int EPI> static int lm_g2_launch_t(const LmG2Args& a, dim3 grid, size_t smem, hipStream_t st)
+template <int KH, int KW, int TERMS, int MT, int EPI, int NC, int LOADER> static int lm_g2_launch_t(const LmG2Args& a, dim3 grid, size_t smem, hipStream_t st)
 {
 #if !LM_HIP_EMULATED
-    LM_HIP(hipFuncSetAttribute((const void*)lm_k_g2<KH, KW, TERMS, MT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    LM_HIP(hipFuncSetAttribute((const void*)lm_k_g2<KH, KW, TERMS, MT, EPI, NC, LOADER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 #endif
-    hipLaunchKernelGGL((lm_k_g2<KH, KW, TERMS, MT, EPI>), grid, dim3(256), smem, st, a, a.psrc, a.groups, a.sdesc, a.pdelta, a.bias);
+    hipLaunchKernelGGL((lm_k_g2<KH, KW, TERMS, MT, EPI, NC, LOADER>), grid, dim3(LOADER ? 320 : 256), smem, st, a, a.psrc, a.groups, a.t4, a.bias);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }
 
-template <int KH, int KW, int EPI, int MT> static int lm_g2_launch_terms(int terms, const LmG2Args& a, dim3 grid, size_t smem, hipStream_t st)
-{
-    // the two-product formats exist for the convolutions proper (the transposed convolutions run below full resolution on f16)
-    if constexpr (EPI != LM_G2_EPI_TC) {
-        if (terms == 4) return lm_g2_launch_t<KH, KW, 4, MT, EPI>(a, grid, smem, st);
-        if (terms == 2) return lm_g2_launch_t<KH, KW, 2, MT, EPI>(a, grid, smem, st);
-    } else if (terms == 2 || terms == 4) {
-        lm_set_error("lm_fcn2: the transposed convolutions take formats 1 and 3");
-        return LM_ERR_ARG;
-    }
-    return terms == 3 ? lm_g2_launch_t<KH, KW, 3, MT, EPI>(a, grid, smem, st) : lm_g2_launch_t<KH, KW, 1, MT, EPI>(a, grid, smem, st);
-}
-
+// The instances that exist (each is a kernel of its own in the code object; lecturemath_amd/fcn2.py only asks for these):
+//   variant 0 = 16 x 16 tile, four waves;  1 = 16 x 16 tile + loader wave;  2 = 16 x 32 tile, four waves
+//   3 x 3 convolutions: formats 1 / 3 / 4, 1..4 channel tiles (loader: <= 2 tiles, formats 1 / 4; wide: <= 3 tiles)
+//   7 x 7 convolutions: formats 1..4, 1..2 channel tiles, all variants;  1 x 7 head rows: formats 1..4, variants 0 and 2
+//   transposed convolutions: formats 1 / 3, 1..4 channel tiles, variant 0
+#define LM_G2_TRY(KH, KW, T, M, E, N, L) \
+    if (l.terms == T && l.mt == M && l.nc == N && l.loader == L) return lm_g2_launch_t<KH, KW, T, M, E, N, L>(a, grid, smem, st);
+#define LM_G2_TRY_MT4(KH, KW, T, E, N, L) LM_G2_TRY(KH, KW, T, 1, E, N, L) LM_G2_TRY(KH, KW, T, 2, E, N, L) LM_G2_TRY(KH, KW, T, 3, E, N, L) LM_G2_TRY(KH, KW, T, 4, E, N, L)
 static int lm_g2_launch(const LmF2Layer& l, const LmG2Args& a, dim3 grid, size_t smem, hipStream_t st)
 {
     const int shape = l.kh * 10 + l.kw;
     if (l.terms < 1 || l.terms > 4) { lm_set_error("lm_fcn2: operand formats are 1 (f16), 2 (activations split), 3 (both split) or 4 (weights split)"); return LM_ERR_ARG; }
     if (shape == 33 && l.epi == LM_G2_EPI_PO) {
-        if (l.mt == 1) return lm_g2_launch_terms<3, 3, LM_G2_EPI_PO, 1>(l.terms, a, grid, smem, st);
-        if (l.mt == 2) return lm_g2_launch_terms<3, 3, LM_G2_EPI_PO, 2>(l.terms, a, grid, smem, st);
-        if (l.mt == 3) return lm_g2_launch_terms<3, 3, LM_G2_EPI_PO, 3>(l.terms, a, grid, smem, st);
-        if (l.mt == 4) return lm_g2_launch_terms<3, 3, LM_G2_EPI_PO, 4>(l.terms, a, grid, smem, st);
+        LM_G2_TRY_MT4(3, 3, 1, LM_G2_EPI_PO, 1, 0) LM_G2_TRY_MT4(3, 3, 3, LM_G2_EPI_PO, 1, 0) LM_G2_TRY_MT4(3, 3, 4, LM_G2_EPI_PO, 1, 0)
+        LM_G2_TRY(3, 3, 1, 1, LM_G2_EPI_PO, 1, 1) LM_G2_TRY(3, 3, 1, 2, LM_G2_EPI_PO, 1, 1) LM_G2_TRY(3, 3, 4, 1, LM_G2_EPI_PO, 1, 1) LM_G2_TRY(3, 3, 4, 2, LM_G2_EPI_PO, 1, 1)
+        LM_G2_TRY(3, 3, 1, 1, LM_G2_EPI_PO, 2, 0) LM_G2_TRY(3, 3, 1, 2, LM_G2_EPI_PO, 2, 0) LM_G2_TRY(3, 3, 1, 3, LM_G2_EPI_PO, 2, 0)
+        LM_G2_TRY(3, 3, 3, 1, LM_G2_EPI_PO, 2, 0) LM_G2_TRY(3, 3, 3, 2, LM_G2_EPI_PO, 2, 0) LM_G2_TRY(3, 3, 3, 3, LM_G2_EPI_PO, 2, 0)
+        LM_G2_TRY(3, 3, 4, 1, LM_G2_EPI_PO, 2, 0) LM_G2_TRY(3, 3, 4, 2, LM_G2_EPI_PO, 2, 0) LM_G2_TRY(3, 3, 4, 3, LM_G2_EPI_PO, 2, 0)
     } else if (shape == 11 && (l.epi == LM_G2_EPI_TC || l.epi == LM_G2_EPI_TC2)) {
         if (l.epi == LM_G2_EPI_TC2 && l.mt != 4) { lm_set_error("lm_fcn2: the merged transposed convolution runs four channel tiles per workgroup"); return LM_ERR_ARG; }
-        if (l.mt == 1) return lm_g2_launch_terms<1, 1, LM_G2_EPI_TC, 1>(l.terms, a, grid, smem, st);
-        if (l.mt == 2) return lm_g2_launch_terms<1, 1, LM_G2_EPI_TC, 2>(l.terms, a, grid, smem, st);
-        if (l.mt == 3) return lm_g2_launch_terms<1, 1, LM_G2_EPI_TC, 3>(l.terms, a, grid, smem, st);
-        if (l.mt == 4) return lm_g2_launch_terms<1, 1, LM_G2_EPI_TC, 4>(l.terms, a, grid, smem, st);
+        LM_G2_TRY_MT4(1, 1, 1, LM_G2_EPI_TC, 1, 0) LM_G2_TRY_MT4(1, 1, 3, LM_G2_EPI_TC, 1, 0)
     } else if (shape == 17 && l.epi == LM_G2_EPI_T) {
-        if (l.mt == 1) return lm_g2_launch_terms<1, 7, LM_G2_EPI_T, 1>(l.terms, a, grid, smem, st);
+        LM_G2_TRY(1, 7, 1, 1, LM_G2_EPI_T, 1, 0) LM_G2_TRY(1, 7, 2, 1, LM_G2_EPI_T, 1, 0) LM_G2_TRY(1, 7, 3, 1, LM_G2_EPI_T, 1, 0) LM_G2_TRY(1, 7, 4, 1, LM_G2_EPI_T, 1, 0)
+        LM_G2_TRY(1, 7, 1, 1, LM_G2_EPI_T, 2, 0) LM_G2_TRY(1, 7, 2, 1, LM_G2_EPI_T, 2, 0) LM_G2_TRY(1, 7, 3, 1, LM_G2_EPI_T, 2, 0) LM_G2_TRY(1, 7, 4, 1, LM_G2_EPI_T, 2, 0)
     } else if (shape == 77 && l.epi == LM_G2_EPI_PO) {
-        if (l.mt == 1) return lm_g2_launch_terms<7, 7, LM_G2_EPI_PO, 1>(l.terms, a, grid, smem, st);
-        if (l.mt == 2) return lm_g2_launch_terms<7, 7, LM_G2_EPI_PO, 2>(l.terms, a, grid, smem, st);
+#define LM_G2_TRY77(N, L) \
+        LM_G2_TRY(7, 7, 1, 1, LM_G2_EPI_PO, N, L) LM_G2_TRY(7, 7, 2, 1, LM_G2_EPI_PO, N, L) LM_G2_TRY(7, 7, 3, 1, LM_G2_EPI_PO, N, L) LM_G2_TRY(7, 7, 4, 1, LM_G2_EPI_PO, N, L) \
+        LM_G2_TRY(7, 7, 1, 2, LM_G2_EPI_PO, N, L) LM_G2_TRY(7, 7, 2, 2, LM_G2_EPI_PO, N, L) LM_G2_TRY(7, 7, 3, 2, LM_G2_EPI_PO, N, L) LM_G2_TRY(7, 7, 4, 2, LM_G2_EPI_PO, N, L)
+        LM_G2_TRY77(1, 0) LM_G2_TRY77(1, 1) LM_G2_TRY77(2, 0)
+#undef LM_G2_TRY77
     }
-    lm_set_error("lm_fcn2: no kernel for a %dx%d layer with %d channel tiles, epilogue %d", l.kh, l.kw, l.mt, l.epi);
+    lm_set_error("lm_fcn2: no kernel for a %dx%d layer: format %d, %d channel tiles, epilogue %d, %d column tiles, loader %d", l.kh, l.kw, l.terms, l.mt, l.epi, l.nc, l.loader);
     return LM_ERR_ARG;
 }
+#undef LM_G2_TRY
+#undef LM_G2_TRY_MT4
 
 // launches layer `li`: input planes per the recipe; `out` (EPI_PO / EPI_TC) with an optional pooled copy, or the T rows (EPI_T)
 static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor* pool, int act, float* tout, int ts, int tn, hipStream_t st)
@@ -705,12 +808,12 @@ static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor*
     const LmF2Tensor& in = f->t[l.planes[0]];
     LmG2Args a;
     memset(&a, 0, sizeof(a));
-    a.arena = f->arena; a.psrc = l.d_psrc; a.wpk = l.d_w; a.groups = l.d_groups; a.sdesc = l.d_sdesc; a.pdelta = l.d_pdelta; a.bias = l.d_bias;
-    a.wblock_bytes = l.wblock_bytes; a.nchunks = l.nchunks; a.npc = l.npc; a.ngroups = l.ngroups; a.npat = l.npat; a.wbuf_bytes = l.wbuf_bytes;
+    a.arena = f->arena; a.psrc = l.d_psrc; a.wpk = l.d_w; a.groups = l.d_groups; a.t4 = l.d_t4; a.bias = l.d_bias;
+    a.wblock_bytes = l.wblock_bytes; a.nchunks = l.nchunks; a.npc = l.npc; a.ngroups = l.ngroups; a.nslices = l.nslices; a.wbuf_bytes = l.wbuf_bytes;
     a.pdouble = l.pdouble; a.Wp_in = in.Wp;
     a.org_in = (in.halo - (l.kh - 1) / 2) * in.Wp + in.halo - (l.kw - 1) / 2;
     a.H = in.H; a.W = in.W;         // a convolution's output grid is its input grid; EPI_TC bounds its stores by the input grid
-    a.tiles_x = (in.W + 15) / 16;
+    a.tiles_x = (in.W + 16 * l.nc - 1) / (16 * l.nc);
     a.act = act;
     if (out) {
         a.out_hi = f->arena + out->off; a.out_lo = out->lo ? a.out_hi + (long long)out->c8 * out->plane : nullptr;
@@ -720,9 +823,9 @@ static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor*
     if (pool) { a.pool_hi = f->arena + pool->off; a.pool_lo = pool->lo ? a.pool_hi + (long long)pool->c8 * pool->plane : nullptr; a.pool_plane = pool->plane; a.Wp_pool = pool->Wp; a.halo_pool = pool->halo; }
     a.tout = tout; a.ts = ts; a.tn = tn;
     const int nhl = (l.terms == 2 || l.terms == 3) ? 2 : 1;
-    const int PW = 16 + l.kw - 1, PH = 16 + l.kh - 1, PLS = (PH * PW * 16 + 255) & ~255;
+    const int PW = 16 * l.nc + l.kw - 1, PH = 16 + l.kh - 1, PLS = (PH * PW * 16 + 255) & ~255;
     // weight ring: three buffers when they fit beside two resident workgroups (or the layer cannot have two anyway), else two
-    const size_t fixed = (size_t)((l.npat * 256 + 255) & ~255) + (size_t)(l.pdouble ? 2 : 1) * l.npc * nhl * PLS;
+    const size_t fixed = (size_t)(((l.nslices + 2) * 16 + 255) & ~255) + (size_t)(l.pdouble ? 2 : 1) * l.npc * nhl * PLS;
     static const int ring_env = [] { const char* e = getenv("LM_FCN2_RING"); return e ? atoi(e) : 0; }();
     int ring = l.ngroups > 2 ? 3 : (l.ngroups > 1 ? 2 : 1);
     if (ring == 3 && fixed + 3 * (size_t)l.wbuf_bytes > 80 * 1024 && fixed + 2 * (size_t)l.wbuf_bytes <= 80 * 1024) ring = 2;
@@ -736,8 +839,20 @@ static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor*
     if (blocks * 16 * l.mt != l.cout) { lm_set_error("lm_fcn2_forward: layer %d: %d outputs are not whole blocks of %d tiles", li, l.cout, l.mt); return LM_ERR_STATE; }
     a.cblocks = blocks;
     a.tc_merged = l.epi == LM_G2_EPI_TC2 ? 1 : 0;
+    static const int stamp_layer = [] { const char* e = getenv("LM_G2_STAMP_LAYER"); return e ? atoi(e) : -1; }();
+    a.stamp = li == stamp_layer;
     return lm_g2_launch(l, a, dim3((unsigned)tiles * blocks * (l.epi == LM_G2_EPI_TC ? 4 : (l.epi == LM_G2_EPI_TC2 ? 2 : 1))), smem, st);
 }
+
+#if LM_G2_STAMPS && !LM_HIP_EMULATED
+// diagnostic builds: copies the stamp buffer (LM_G2_STAMP_WAVES x LM_G2_NSTAMP u64) to the host
+extern "C" int lm_debug_g2_read_stamps(unsigned long long* dst, int64_t n)
+{
+    LM_HIP(hipDeviceSynchronize());
+    LM_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(lm_g2_stamp_buf), (size_t)n * 8, 0, hipMemcpyDeviceToHost));
+    return LM_OK;
+}
+#endif
 
 extern "C" int lm_fcn2_forward(LmFcn2* f, const uint8_t* d_rgb, int h, int w, float* d_out, float* d_text, float* d_rec, void* stream)
 {

@@ -5,6 +5,7 @@ eval, cuda, binarize :430-505) so the step-01 worker and test_FCN_binarizer.py c
 All convolution arithmetic runs in liblecturemath_hip.so (lm_fcn.hip); numpy here only rearranges weights once.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -113,9 +114,20 @@ def _pad8(c):
 class FcnEngine:
     """Device network built from a reference state_dict."""
 
-    # layers that keep the f16 hi + lo split in the "mixed" assignment: the full-resolution ones (profiles/r03_fcn_layer_precision.*:
-    # every layer below full resolution on plain f16 operands changes the logits by 3e-5 in all, each of these by 0.5-3e-4 alone)
-    MIXED_SPLIT_LAYERS = (L_DOWN, L_UPC + 4, L_TEXT, L_REC, L_PX1, L_PX2, L_OUT)
+    # Operand formats of the "mixed" assignment (fcn2.FORMAT_NAMES).  Below full resolution: plain f16 (all 14 layers together change the
+    # logits by 3e-5, profiles/r03_fcn_layer_precision.*).  The six full-resolution layers change them by 0.5-3e-4 EACH on plain f16:
+    # round 3 kept all of them on the three-product split (2.6e-5 in all); round 4 measured every assignment by what the path does with
+    # the logits -- max |logit - oracle| and BINARY FLIPS against the oracle's binarization, 3 seeds at 1920x1080
+    # (profiles/r04_fcn_formats.*) -- and moved conv_up_1, the text / reconstruction heads and conv_pixels_1 to "w2" (weights hi + lo,
+    # activations hi: two products, and their input tensors need no lo planes at all): 2.1e-4 (bar 1e-3), flips 392 / 26 / 9 of 2.07 M
+    # pixels on random-init logits that crowd the threshold (std 0.06-0.12; all-f16x3: 45 / 2 / 1; all-f16: 1034 / 70 / 47).
+    # conv_pixels_2 and conv_out stay on the split: each alone costs 1.5-3e-4 on two products.
+    MIXED_FORMATS = {L_DOWN: "f16x3", L_UPC + 4: "w2", L_TEXT: "w2", L_REC: "w2", L_PX1: "w2", L_PX2: "f16x3", L_OUT: "f16x3"}
+
+    # kernel variant per layer, (column tiles per wave, loader wave), measured per layer at 1920x1080 (profiles/r04_variants_*.txt): 16 x 32
+    # tiles where the weights are re-fetched per tile at full resolution and the instance keeps two workgroups per CU; the loader wave
+    # in the two layers with one workgroup per CU and two channel tiles
+    DEFAULT_VARIANTS = {L_UPC + 4: (2, 0), L_TEXT: (2, 0), L_PX1: (2, 0), L_MID: (1, 1), L_UPC: (1, 1)}
 
     def __init__(self, widths, pixel_kernel, kernel, max_h, max_w, lib=None, precision="mixed", formats=None):
         """precision:
@@ -127,7 +139,15 @@ class FcnEngine:
             (three, two or one f16 MFMA per product) or exact fp32 MFMA chains."""
         assert precision in ("mixed", "planar-f16x3", "planar-f16", "f16x3", "f16x2", "f16", "fp32")
         # planar engine only: {layer id: "f16" | "a2" | "w2" | "f16x3"} overriding the precision's assignment (fcn2.FORMAT_NAMES)
+        if formats is None and os.environ.get("LM_FCN_FORMATS"):        # experiments: "15=w2,18=a2"
+            formats = {int(k): v for k, v in (kv.split("=") for kv in os.environ["LM_FCN_FORMATS"].split(","))}
         self.formats = dict(formats or {})
+        # planar engine only: {layer id: (column tiles per wave 1 | 2, loader wave 0 | 1)} -- the kernel variant of a layer (lm_k_g2's NC, LOADER)
+        self.variants = dict(self.DEFAULT_VARIANTS)
+        if os.environ.get("LM_FCN_VARIANTS"):                           # experiments: "18=2:0,5=1:1"
+            for kv in os.environ["LM_FCN_VARIANTS"].split(","):
+                k, v = kv.split("=")
+                self.variants[int(k)] = tuple(int(x) for x in v.split(":"))
         self.lib = lib or _lib.load()
         self.be = Backend(self.lib)
         self.widths = [int(v) for v in widths]
@@ -176,7 +196,7 @@ class FcnEngine:
             return 1
         if self.precision == "planar-f16x3":
             return 3
-        return 3 if layer in self.MIXED_SPLIT_LAYERS else 1
+        return f2.FORMAT_NAMES[self.MIXED_FORMATS.get(layer, "f16")]
 
     def _load_planar(self, sd):
         """recipes of csrc/lm_fcn2.hip (lecturemath_amd/fcn2.py)"""
@@ -192,17 +212,21 @@ class FcnEngine:
             return (((self.max_h >> level) + 15) // 16) * (((self.max_w >> level) + 15) // 16)
 
         T = self.layer_terms
+
+        def V(layer):
+            nc, loader = self.variants.get(layer, (1, 0))
+            return {"nc": nc, "loader": loader}
         recipes = {}
         # encoder: layer 1 reads the input pair plane (3 channels, two horizontal taps per slot)
         w, b = conv_bn("conv_down_block_1")
         pairs = [f2.pairplane_pair(0, dy, dx, 0, 3) for dy in range(3) for dx in (0, 2)]
-        recipes[L_DOWN] = (f2.build([w], [{"planes": [(f2.T_X0P, 0)], "pairs": pairs}], 3, 3, T(L_DOWN), f2.pick_mt(d1, tiles(0)), f2.EPI_PO), b)
+        recipes[L_DOWN] = (f2.build([w], [{"planes": [(f2.T_X0P, 0)], "pairs": pairs}], 3, 3, T(L_DOWN), f2.pick_mt(d1, tiles(0) // V(L_DOWN)["nc"]), f2.EPI_PO, **V(L_DOWN)), b)
         cin = [3] + downs
         for n in range(1, 5):
             w, b = conv_bn("conv_down_block_%d" % (n + 1))
-            recipes[L_DOWN + n] = (f2.conv_layer(w, [(f2.T_POOL0 + n - 1, cin[n] // 8)], T(L_DOWN + n), tiles(n)), b)
+            recipes[L_DOWN + n] = (f2.conv_layer(w, [(f2.T_POOL0 + n - 1, cin[n] // 8)], T(L_DOWN + n), tiles(n), **V(L_DOWN + n)), b)
         w, b = conv_bn("mid_block")
-        recipes[L_MID] = (f2.conv_layer(w, [(f2.T_POOL0 + 4, d5 // 8)], T(L_MID), tiles(5)), b)
+        recipes[L_MID] = (f2.conv_layer(w, [(f2.T_POOL0 + 4, d5 // 8)], T(L_MID), tiles(5), **V(L_MID)), b)
         ups = {5: (mid, u5, c5, d5), 4: (c5, u4, c4, d4), 3: (c4, u3, c3, d3), 2: (c3, u2, c2, d2), 1: (c2, u1, c1, d1)}
         for i, lvl in enumerate((5, 4, 3, 2, 1)):
             tin, u, c, skip = ups[lvl]
@@ -224,19 +248,19 @@ class FcnEngine:
                 w4 = [np.ascontiguousarray(wt[:, :, dy, dx].T)[:, :, None, None] for dy in (0, 1) for dx in (0, 1)]
                 recipes[L_UPT + i] = (f2.build(w4, chunks, 1, 1, T(L_UPT + i), f2.pick_mt(u, tiles(lvl)), f2.EPI_TC), bt)
             w, b = conv_bn("conv_up_block_%d" % lvl)                                      # input = cat(up, skip_pre)
-            recipes[L_UPC + i] = (f2.conv_layer(w, [(f2.T_UPT0 + i, u // 8), (f2.T_PRE0 + lvl - 1, skip // 8)], T(L_UPC + i), tiles(lvl - 1)), b)
+            recipes[L_UPC + i] = (f2.conv_layer(w, [(f2.T_UPT0 + i, u // 8), (f2.T_PRE0 + lvl - 1, skip // 8)], T(L_UPC + i), tiles(lvl - 1), **V(L_UPC + i)), b)
         # heads
         wt, bt = conv_bn("conv_text_mask_out")
         wr, br = conv_bn("conv_reconstruct")
         rows = f2.text_rec_rows(wt, wr)
-        recipes[L_TEXT] = (f2.build([rows], f2.conv_chunks([(f2.T_XUP, c1 // 8)], 1, 7, c1 // 8), 1, 7, T(L_TEXT), 1, f2.EPI_T),
+        recipes[L_TEXT] = (f2.build([rows], f2.conv_chunks([(f2.T_XUP, c1 // 8)], 1, 7, c1 // 8), 1, 7, T(L_TEXT), 1, f2.EPI_T, **V(L_TEXT)),
                            np.concatenate([np.zeros(16, np.float32), bt, br]))
         w, b = conv_bn("conv_pixels_1")
-        recipes[L_PX1] = (f2.build([w], f2.pixel_chunks(f2.T_XUP, c1 // 8, f2.T_DP, 7, 7), 7, 7, T(L_PX1), 2 if pm1 % 32 == 0 else 1, f2.EPI_PO, pdouble=False), b)
+        recipes[L_PX1] = (f2.build([w], f2.pixel_chunks(f2.T_XUP, c1 // 8, f2.T_DP, 7, 7), 7, 7, T(L_PX1), 2 if pm1 % 32 == 0 else 1, f2.EPI_PO, pdouble=False, **V(L_PX1)), b)
         w, b = conv_bn("conv_pixels_2")
-        recipes[L_PX2] = (f2.build([w], f2.pixel_chunks(f2.T_P1, pm1 // 8, f2.T_DP, 7, 7), 7, 7, T(L_PX2), 2 if pm2 % 32 == 0 else 1, f2.EPI_PO, pdouble=False), b)
+        recipes[L_PX2] = (f2.build([w], f2.pixel_chunks(f2.T_P1, pm1 // 8, f2.T_DP, 7, 7), 7, 7, T(L_PX2), 2 if pm2 % 32 == 0 else 1, f2.EPI_PO, pdouble=False, **V(L_PX2)), b)
         w, b = conv_bn("conv_out")
-        recipes[L_OUT] = (f2.build([f2.out_rows(w)], f2.pixel_chunks(f2.T_P2, pm2 // 8, f2.T_DP, 1, 7), 1, 7, T(L_OUT), 1, f2.EPI_T, pdouble=False),
+        recipes[L_OUT] = (f2.build([f2.out_rows(w)], f2.pixel_chunks(f2.T_P2, pm2 // 8, f2.T_DP, 1, 7), 1, 7, T(L_OUT), 1, f2.EPI_T, pdouble=False, **V(L_OUT)),
                           np.concatenate([np.zeros(16, np.float32), b]))
         # a tensor keeps its lo parts when a layer reading it runs the split format
         lo = np.zeros(f2.N_TENSORS, np.int32)
@@ -256,8 +280,8 @@ class FcnEngine:
             self.lib.check(self.lib.lm_fcn2_set_layer(self.handle2, layer, desc.ctypes.data, desc.size, wpk.ctypes.data, wpk.nbytes, wblocks,
                                                       bias.ctypes.data, bias.size))
             self.recipes[layer] = {"kh": int(desc[0]), "kw": int(desc[1]), "terms": int(desc[2]), "mt": int(desc[3]), "chunks": int(desc[5]),
-                                   "planes_per_chunk": int(desc[6]), "groups": int(desc[7]), "slices": int(desc[8]), "patterns": int(desc[9]),
-                                   "lds_bytes": int(need), "cout": int(desc[12]), "epilogue": int(desc[4]), "first_tensor": int(desc[13])}
+                                   "planes_per_chunk": int(desc[6]), "groups": int(desc[7]), "slices": int(desc[8]),
+                                   "lds_bytes": int(need), "cout": int(desc[12]), "nc": int(desc[9]) & 15, "loader": (int(desc[9]) >> 8) & 1, "epilogue": int(desc[4]), "first_tensor": int(desc[13])}
 
     def executed_gflop(self, h, w):
         """MFMA flops the planar engine EXECUTES for one h x w frame (whole 16 x 16 tiles, whole 32-deep slices, three products per

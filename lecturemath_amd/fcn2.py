@@ -15,8 +15,8 @@ T_X0P, T_PRE0, T_POOL0, T_MID, T_UPT0, T_CU0, T_XUP, T_DP, T_P1, T_P2, N_TENSORS
 LDS_TWO_WORKGROUPS = 80 * 1024        # a workgroup's LDS for two of them to share a CU's 160 KB
 
 
-def geom(kh, kw, terms):
-    pw, ph = 16 + kw - 1, 16 + kh - 1
+def geom(kh, kw, terms, nc=1):
+    pw, ph = 16 * nc + kw - 1, 16 + kh - 1
     pls = (ph * pw * 16 + 255) & ~255
     return pw, ph, pls, (2 if terms in (2, 3) else 1)
 
@@ -45,21 +45,46 @@ def row_channel(mt, m, r, epi):
     return 16 * m + r
 
 
-def lds_bytes(kh, kw, terms, npc, npat, pdouble, wbuf, ngroups):
-    _, _, pls, nhl = geom(kh, kw, terms)
-    return ((npat * 256 + 255) & ~255) + (2 if pdouble else 1) * npc * nhl * pls + (2 if ngroups > 1 else 1) * wbuf
+def have_instance(kh, kw, terms, mt, epi, nc=1, loader=0):
+    """the kernel instances csrc/lm_fcn2.hip compiles (lm_g2_launch)"""
+    v = (nc, loader)
+    if (kh, kw) == (3, 3) and epi == EPI_PO:
+        if v == (1, 0):
+            return terms in (1, 3, 4) and 1 <= mt <= 4
+        if v == (1, 1):
+            return terms in (1, 4) and mt in (1, 2)
+        return v == (2, 0) and terms in (1, 3, 4) and 1 <= mt <= 3
+    if (kh, kw) == (1, 1) and epi in (EPI_TC, EPI_TC2):
+        return v == (1, 0) and terms in (1, 3) and 1 <= mt <= 4
+    if (kh, kw) == (1, 7) and epi == EPI_T:
+        return v in ((1, 0), (2, 0)) and 1 <= terms <= 4 and mt == 1
+    if (kh, kw) == (7, 7) and epi == EPI_PO:
+        return v in ((1, 0), (1, 1), (2, 0)) and 1 <= terms <= 4 and mt in (1, 2)
+    return False
 
 
-def build(w_list, chunks, kh, kw, terms, mt, epi, gsize=None, pdouble=None):
+def table_bytes(nslices):
+    """LDS bytes of the slice table: 16 bytes per slice (the four k-groups' patch offsets) + two entries of look-ahead"""
+    return ((nslices + 2) * 16 + 255) & ~255
+
+
+def lds_bytes(kh, kw, terms, npc, nslices, pdouble, wbuf, ngroups, nc=1):
+    _, _, pls, nhl = geom(kh, kw, terms, nc)
+    return table_bytes(nslices) + (2 if pdouble else 1) * npc * nhl * pls + (2 if ngroups > 1 else 1) * wbuf
+
+
+def build(w_list, chunks, kh, kw, terms, mt, epi, gsize=None, pdouble=None, lds_target=LDS_TWO_WORKGROUPS, nc=1, loader=0):
     """w_list: one [cout][cin][KH][KW] float32 array (or four, one per (dy, dx) of a transposed convolution).
     chunks: [{"planes": [(tensor, octet), ...], "pairs": [pair, ...]}], every chunk with the same number of planes.
     Returns (desc int32 array for lm_fcn2_set_layer, packed weights as bytes array, wblocks)."""
-    pw, ph, pls, nhl = geom(kh, kw, terms)
+    if not have_instance(kh, kw, terms, mt, epi, nc, loader):       # a variant the library does not hold: the plain one
+        nc, loader = 1, 0
+    pw, ph, pls, nhl = geom(kh, kw, terms, nc)
     nwl = 2 if terms >= 3 else 1
     cout = w_list[0].shape[0]
     assert cout % (16 * mt) == 0, (cout, mt)
     npc = len(chunks[0]["planes"])
-    slices, patterns, kidx = [], [], []          # slices: (lds offset, pattern, chunk)
+    slices, kidx = [], []                        # slices: (four LDS offsets, chunk)
     wshape = w_list[0].shape
     for ci, ch in enumerate(chunks):
         assert len(ch["planes"]) == npc
@@ -70,17 +95,13 @@ def build(w_list, chunks, kh, kw, terms, mt, epi, gsize=None, pdouble=None):
                 four.append({"plane": four[0]["plane"], "dy": four[0]["dy"], "dx": four[0]["dx"], "kmap": [None] * 8})
             offs = [p["plane"] * nhl * pls + (p["dy"] * pw + p["dx"]) * 16 for p in four]
             assert all(0 <= p["dy"] < kh and 0 <= p["dx"] < kw and 0 <= p["plane"] < npc for p in four)
-            delta = tuple(o - offs[0] for o in offs)
-            if delta not in patterns:
-                patterns.append(delta)
-            slices.append((offs[0], patterns.index(delta), ci))
+            slices.append((offs, ci))
             idx = np.full(32, -1, np.int64)
             for g, p in enumerate(four):
                 for j, km in enumerate(p["kmap"]):
                     if km is not None:
                         idx[g * 8 + j] = (km[0] * wshape[2] + km[1]) * wshape[3] + km[2]
             kidx.append(idx)
-    assert len(patterns) <= 16, len(patterns)
     nslices = len(slices)
     kidx = np.stack(kidx)                                           # [nslices][32]
     # weight groups: consecutive slices of one chunk
@@ -90,18 +111,18 @@ def build(w_list, chunks, kh, kw, terms, mt, epi, gsize=None, pdouble=None):
     if gsize is None:
         gsize = 1
         for cand in range(2, 17):
-            if lds_bytes(kh, kw, terms, npc, len(patterns), pdouble, cand * per_slice, 2) <= LDS_TWO_WORKGROUPS:
+            if lds_bytes(kh, kw, terms, npc, nslices, pdouble, cand * per_slice, 2, nc) <= lds_target:
                 gsize = cand
     groups = []
     s = 0
     while s < nslices:                       # per chunk: as few groups as gsize allows, sizes as even as possible
         n = 1
-        while s + n < nslices and slices[s + n][2] == slices[s][2]:
+        while s + n < nslices and slices[s + n][1] == slices[s][1]:
             n += 1
         k = (n + gsize - 1) // gsize
         for i in range(k):
             cnt = n // k + (1 if i < n % k else 0)
-            groups.append([s, cnt, slices[s][2]])
+            groups.append([s, cnt, slices[s][1]])
             s += cnt
     wbuf = max(g[1] for g in groups) * per_slice
     # weights: [parity][block][slice][tile][hi|lo][lane = kgroup * 16 + row][8]
@@ -121,9 +142,9 @@ def build(w_list, chunks, kh, kw, terms, mt, epi, gsize=None, pdouble=None):
         packed.append(np.stack(parts, axis=3).reshape(nblocks, nslices, mt, nwl, 64, 8))
     wpk = np.ascontiguousarray(np.stack(packed))                    # [parity][block]...
     planes = [v for ch in chunks for pl in ch["planes"] for v in pl]
-    desc = [kh, kw, terms, mt, epi, len(chunks), npc, len(groups), nslices, len(patterns), 1 if pdouble else 0, wbuf, cout]
-    desc += planes + [v for g in groups for v in g] + [v for s_ in slices for v in s_[:2]] + [v for p in patterns for v in p]
-    need = lds_bytes(kh, kw, terms, npc, len(patterns), pdouble, wbuf, len(groups))
+    desc = [kh, kw, terms, mt, epi, len(chunks), npc, len(groups), nslices, nc | (loader << 8), 1 if pdouble else 0, wbuf, cout]
+    desc += planes + [v for g in groups for v in g] + [v for s_ in slices for v in s_[0]]
+    need = lds_bytes(kh, kw, terms, npc, nslices, pdouble, wbuf, len(groups), nc)
     return np.asarray(desc, np.int32), wpk, len(w_list) * nblocks, need
 
 
@@ -154,9 +175,12 @@ def pick_mt(cout, tiles, prefer=(4, 3, 2)):
     return ok[-1]
 
 
-def conv_layer(w, inputs, terms, tiles, mt=None):
+def conv_layer(w, inputs, terms, tiles, mt=None, nc=1, loader=0, lds_target=LDS_TWO_WORKGROUPS):
+    """tiles: 16 x 16 pixel tiles of the layer's grid (a 16 x 32 tile counts as two)"""
     cout, _, kh, kw = w.shape
-    mt = mt or pick_mt(cout, tiles)
+    if not have_instance(kh, kw, terms, mt or pick_mt(cout, tiles // nc), EPI_PO, nc, loader):
+        nc, loader = 1, 0
+    mt = mt or pick_mt(cout, tiles // nc)
     total = sum(n for _, n in inputs)
     best = None
     for co in (4, 3, 2, 1):
@@ -164,8 +188,8 @@ def conv_layer(w, inputs, terms, tiles, mt=None):
             continue
         chunks = conv_chunks(inputs, kh, kw, co)
         pd = len(chunks) > 1
-        r = build([w], chunks, kh, kw, terms, mt, EPI_PO, pdouble=pd)
-        key = (r[3] > LDS_TWO_WORKGROUPS, int(r[0][8]))      # room for two workgroups per CU first, then the fewest slices
+        r = build([w], chunks, kh, kw, terms, mt, EPI_PO, pdouble=pd, nc=nc, loader=loader, lds_target=lds_target)
+        key = (r[3] > lds_target, int(r[0][8]))      # room for two workgroups per CU first, then the fewest slices
         if best is None or key < best[0]:
             best = (key, r)
     return best[1]

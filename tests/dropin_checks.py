@@ -274,6 +274,24 @@ def check_labeler(lib):
     assert [(c.cc_id, c.size) for c in pre] == [(c.cc_id, c.size) for c in ref]
 
 
+FCN_EDGE = 0.0078433            # trunc(sigmoid(x) * 255) >= 128 flips at x = ln(128 / 127)
+FCN_EDGE_TOL_F16X3 = 1e-4       # the first engine / planar-f16x3 (measured 2e-6) -- the tiny G5 networks run on it
+FCN_EDGE_TOL_MIXED = 2.5e-4     # the shipped per-layer assignment of the planar engine (profiles/r04_fcn_formats.*: <= 2.1e-4 at 1080p)
+
+
+def assert_binarization(got, exp, logits, tol, what="binary"):
+    """A thresholded output may differ from the reference's ONLY where the reference's logit lies within `tol` -- the engine's own error
+    bound, not the 1e-3 bar -- of the decision edge.  Returns the number of such flips (exempted AND different)."""
+    diff = np.asarray(got) != np.asarray(exp)
+    band = np.abs(np.asarray(logits, np.float64) - FCN_EDGE) < tol
+    away = diff & ~band
+    if away.any():
+        ys, xs = np.nonzero(away)
+        raise AssertionError("%s: %d of %d pixels differ outside the %.1e band around the threshold edge; first at (%d, %d), logit %r" % (
+            what, int(away.sum()), diff.size, tol, ys[0], xs[0], float(np.asarray(logits)[ys[0], xs[0]])))
+    return int(diff.sum())
+
+
 def check_fcn_class(lib, name="k7_70x94", worker=True):
     """FCN_LectureNet.CreateFromConfig / load_state_dict / binarize and the step-01 worker vs the reference's outputs."""
     use_library(lib)
@@ -290,10 +308,9 @@ def check_fcn_class(lib, name="k7_70x94", worker=True):
     net = net.eval().cuda()
     binary, text_mask, rec_img = net.binarize(PIL.Image.fromarray(g["rgb"]), return_others=True, force_binary=True)
     # thresholded outputs may differ only where the logit sits within the fp32 tolerance of the decision edge
-    edge = np.abs(g["out"][0, 0] - 0.0078433) < 2e-3
-    assert ((binary == g["binary"]) | edge).all()
-    edge_t = np.abs(g["text"][0, 0] - 0.0078433) < 2e-3
-    assert ((text_mask == g["text_mask"]) | edge_t).all()
+    tol = FCN_EDGE_TOL_MIXED if net._get_engine(*g["rgb"].shape[:2]).planar else FCN_EDGE_TOL_F16X3
+    flips = assert_binarization(binary, g["binary"], g["out"][0, 0], tol) + assert_binarization(text_mask, g["text_mask"], g["text"][0, 0], tol, "text mask")
+    assert flips <= 4, flips          # of ~6,600 pixels
     assert np.abs(rec_img.astype(np.int32) - g["rec_img"].astype(np.int32)).max() <= 1
     if not worker:
         return
@@ -302,7 +319,7 @@ def check_fcn_class(lib, name="k7_70x94", worker=True):
     worker.handleFrame(np.ascontiguousarray(g["rgb"][:, :, ::-1]), None, 0, 1000.0, 1000.0, 30)
     assert worker.frame_times == [1000.0] and worker.frame_indices == [30] and worker.getWorkName()
     dec = png.decode_gray8(worker.compressed_frames[0])
-    assert ((dec == 255 - g["binary"]) | edge).all()
+    assert_binarization(dec, 255 - g["binary"], g["out"][0, 0], tol, "worker frame")
 
 
 def check_step01_entry_points(lib, tmp_dir, name="k7_70x94", n_frames=3, tool=True):
@@ -334,7 +351,7 @@ def check_step01_entry_points(lib, tmp_dir, name="k7_70x94", n_frames=3, tool=Tr
         spec.loader.exec_module(mod)
         return mod
 
-    edge = np.abs(g["out"][0, 0] - 0.0078433) < 2e-3        # pixels whose logit sits within the fp32 tolerance of the decision edge
+    tol = FCN_EDGE_TOL_F16X3 if any(int(v) % 16 for v in g["widths"]) else FCN_EDGE_TOL_MIXED     # which engine the network gets
     # ---- step 01
     s01 = script("pre_ST3D_v3.0_01_binarize.py")
     process = types.SimpleNamespace(configuration=Configuration.from_file(conf_path), params={})
@@ -355,7 +372,7 @@ def check_step01_entry_points(lib, tmp_dir, name="k7_70x94", n_frames=3, tool=Tr
     assert times == [1000.0 * (k + 1) for k in range(n_frames)] and indices == [30 * (k + 1) for k in range(n_frames)]
     assert len(compressed) == n_frames and not hasattr(worker, "lecture_net")
     for c in compressed:
-        assert ((png.decode_gray8(c) == 255 - g["binary"]) | edge).all()
+        assert assert_binarization(png.decode_gray8(c), 255 - g["binary"], g["out"][0, 0], tol, "step-01 frame") <= 4
     if not tool:
         return
     # ---- test_FCN_binarizer.py
@@ -371,8 +388,8 @@ def check_step01_entry_points(lib, tmp_dir, name="k7_70x94", n_frames=3, tool=Tr
     binary = np.asarray(PIL.Image.open(os.path.join(tmp_dir, "out_BIN.png")))
     text = np.asarray(PIL.Image.open(os.path.join(tmp_dir, "out_text.png")))
     bg = np.asarray(PIL.Image.open(os.path.join(tmp_dir, "out_bg.png")).convert("RGB"))
-    assert ((binary == g["binary"]) | edge).all()
-    assert ((text == g["text_mask"]) | (np.abs(g["text"][0, 0] - 0.0078433) < 2e-3)).all()
+    assert assert_binarization(binary, g["binary"], g["out"][0, 0], tol, "tool binary") <= 4
+    assert assert_binarization(text, g["text_mask"], g["text"][0, 0], tol, "tool text mask") <= 4
     assert np.abs(bg[:, :, ::-1].astype(np.int32) - g["rec_img"].astype(np.int32)).max() <= 1       # the tool writes RGB, rec_img is BGR
 
 
@@ -438,8 +455,8 @@ def check_resize_golden(lib):
 def check_fcn_4k_resize_branch(lib, shipped=False):
     """binarize() on a 3840x2160 frame (> 2.5 MP, FCN_lecturenet.py:435-437,481-494): PIL LANCZOS halving, FCN at 1080p,
     NEAREST x2 back -- against the oracle's torch forward on the same halved image.  Tiny network by default (the branch is
-    about the resize plumbing), the shipped widths with shipped=True; pixels whose logit is within the fp32 tolerance of the
-    threshold edge are exempt."""
+    about the resize plumbing), the shipped widths with shipped=True; a pixel may differ only where the oracle's logit lies within
+    the ENGINE's error bound of the threshold edge, and the flips are counted."""
     use_library(lib)
     import PIL.Image
     import torch
@@ -465,11 +482,6 @@ def check_fcn_4k_resize_branch(lib, shipped=False):
     with torch.no_grad():
         o, t, r = ofcn.forward(sd, ofcn.prepare_image(half))
     exp = ((torch.sigmoid(o)[0, 0].numpy() * 255).astype(np.uint8) >= 128).astype(np.uint8) * 255
-    edge = np.abs(o[0, 0].numpy() - 0.0078433) < 2e-3
-    up = lambda a: a[np.arange(2160) // 2][:, np.arange(3840) // 2]
-    bad = ~((binary == up(exp)) | up(edge))
-    if bad.any():
-        ys, xs = np.nonzero(bad)
-        raise AssertionError("%d of %d pixels differ away from the threshold edge; first at (%d, %d): oracle logit %r, device binary %d" % (
-            int(bad.sum()), bad.size, ys[0], xs[0], float(o[0, 0, ys[0] // 2, xs[0] // 2]), int(binary[ys[0], xs[0]])))
-    assert (binary[::2, ::2] == binary[1::2, 1::2]).all()          # NEAREST x2 structure
+    assert (binary[::2, ::2] == binary[1::2, 1::2]).all() and (binary[::2, ::2] == binary[::2, 1::2]).all()          # NEAREST x2 structure
+    flips = assert_binarization(binary[::2, ::2], exp, o[0, 0].numpy(), FCN_EDGE_TOL_MIXED if shipped else FCN_EDGE_TOL_F16X3, "4K binary")
+    assert flips <= (1000 if shipped else 8), flips        # random-init logits crowd the edge (std ~0.1): 5e-4 of the 1080p frame at most

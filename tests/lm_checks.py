@@ -516,15 +516,16 @@ def check_legacy_exports(lib, big=False):
             assert outs[0] == outs[1], (h, w, thr, jump, outs)
 
 
-def check_fcn_golden(lib, name, tol=1e-3, precision="f16x3"):
+def check_fcn_golden(lib, name, tol=1e-3, precision="f16x3", require_planar=False, formats=None):
     """HIP FCN forward vs the reference module's outputs (G5 fixture); tolerance 1e-3 on logits (BASELINE.json)."""
     from lecturemath_amd import fcn
     g = np.load(os.path.join(GOLD, "g5_fcn_%s.npz" % name))
     sd = {k[3:]: g[k] for k in g.files if k.startswith("sd.")}
     rgb = g["rgb"]
     h, w = rgb.shape[:2]
-    eng = fcn.FcnEngine(g["widths"], int(g["pk"]), 3, h, w, lib, precision=precision)
+    eng = fcn.FcnEngine(g["widths"], int(g["pk"]), 3, h, w, lib, precision=precision, formats=formats)
     try:
+        assert eng.planar or not require_planar, "the planar engine refused this network"
         eng.load_state_dict(sd)
         out, text, rec = (eng.be.to_host(t) for t in eng.forward(rgb))
         assert np.abs(out - g["out"][0, 0]).max() <= tol

@@ -220,6 +220,13 @@ def test_fcn_golden(hip_lib, name, precision):
     assert lm_checks.check_fcn_golden(hip_lib, name, precision=precision) < 1e-4
 
 
+@pytest.mark.parametrize("precision,tol", [("mixed", 5e-4), ("planar-f16x3", 1e-5), ("planar-f16", 1e-3)])
+def test_fcn_golden_planar_engine(hip_lib, precision, tol):
+    """The DEFAULT engine (csrc/lm_fcn2.hip, the one bench.py times) against the reference module's own outputs: G5's wide case has every
+    width a multiple of 16, so the planar engine takes it.  mixed = the shipped per-layer format assignment."""
+    assert lm_checks.check_fcn_golden(hip_lib, "k7_66x130_wide", tol=tol, precision=precision, require_planar=True) <= tol
+
+
 @pytest.mark.parametrize("precision", ["mixed", "planar-f16x3", "f16x3", "fp32"])
 def test_fcn_shipped_config_vs_oracle(hip_lib, precision):
     """The shipped network widths (configs/FCN_LectureNet.conf:109-132, 15.8 M parameters, 7x7 pixel convs) on an
@@ -253,12 +260,14 @@ def fcn_1080p_oracle():
     return sd, rgb, o[0, 0].numpy(), t[0, 0].numpy(), r[0].numpy()
 
 
-@pytest.mark.parametrize("precision,tol", [("mixed", 1e-4), ("planar-f16x3", 1e-5), ("planar-f16", 1e-3), ("f16x3", 1e-4), ("fp32", 1e-4), ("f16x2", 1e-3),
+@pytest.mark.parametrize("precision,tol", [("mixed", 2.5e-4), ("planar-f16x3", 1e-5), ("planar-f16", 1e-3), ("f16x3", 1e-4), ("fp32", 1e-4), ("f16x2", 1e-3),
                                            ("f16", 1e-3)])
 def test_fcn_shipped_config_1080p_vs_oracle(hip_lib, fcn_1080p_oracle, precision, tol):
     """BASELINE configs[1] at its size: the shipped network on one 1920x1080 frame against the oracle.  The bar is 1e-3 on the
-    logits (north_star); the default ("mixed": the planar engine with its per-layer operand formats), the all-split formats of both
-    engines and fp32 are held to 1e-4 or tighter, the cheaper operand formats to the bar itself."""
+    logits (north_star); the default ("mixed": the planar engine with its per-layer operand formats, chosen in round 4 by measured error AND
+    binary flips, profiles/r04_fcn_formats.*) is held to 2.5e-4, the all-split formats of both engines and fp32 to 1e-4 or tighter, the
+    cheaper operand formats to the bar itself.  For the default the BINARY FLIPS against the oracle's binarization are counted too:
+    random-init logits crowd the threshold (std 0.12 here), 392 of 2,073,600 pixels flip in this frame."""
     from lecturemath_amd import fcn
     sd, rgb, o, t, r = fcn_1080p_oracle
     eng = fcn.FcnEngine(synth.FCN_SHIPPED_WIDTHS, 7, 3, 1080, 1920, hip_lib, precision=precision)
@@ -266,11 +275,16 @@ def test_fcn_shipped_config_1080p_vs_oracle(hip_lib, fcn_1080p_oracle, precision
     out, text, rec = (x.cpu().numpy() for x in eng.forward(rgb))
     eng.close()
     assert np.abs(out - o).max() <= tol and np.abs(text - t).max() <= tol and np.abs(rec - r).max() <= tol
+    if precision == "mixed":
+        from oracle import cc as occ
+        flips = int((occ.threshold_invert(out) != occ.threshold_invert(o)).sum())
+        band = int((np.abs(o - 0.0078433) < tol).sum())           # a pixel can only flip where the oracle's logit is within the engine's error of the edge
+        assert flips <= 600 and flips <= band, (flips, band)
 
 
 def test_fcn_planar_frame_size_change(hip_lib):
     """One planar engine, frames of different sizes one after the other (the zero halos and the tile overhang of its activation
-    planes depend on the frame size): every pass within 1e-4 of the oracle, and the first size again gives its first result bit for bit."""
+    planes depend on the frame size): every pass within 5e-4 of the oracle (the shipped format assignment; bar 1e-3), and the first size again gives its first result bit for bit."""
     import torch
     from lecturemath_amd import fcn
     from oracle import fcn as ofcn
@@ -285,7 +299,7 @@ def test_fcn_planar_frame_size_change(hip_lib):
         out, text, rec = (x.cpu().numpy() for x in eng.forward(rgb))
         with torch.no_grad():
             o, t, r = ofcn.forward(sd, ofcn.prepare_image(rgb))
-        assert np.abs(out - o[0, 0].numpy()).max() <= 1e-4 and np.abs(text - t[0, 0].numpy()).max() <= 1e-4 and np.abs(rec - r[0].numpy()).max() <= 1e-4, (h, w)
+        assert np.abs(out - o[0, 0].numpy()).max() <= 5e-4 and np.abs(text - t[0, 0].numpy()).max() <= 5e-4 and np.abs(rec - r[0].numpy()).max() <= 5e-4, (h, w)
         if k == 0:
             first = out
     assert (first == out).all()
@@ -295,7 +309,7 @@ def test_fcn_planar_frame_size_change(hip_lib):
 @pytest.mark.parametrize("precision", ["mixed", "f16x3"])
 def test_fcn_two_engines_on_two_streams(hip_lib, fcn_1080p_oracle, precision):
     """Two engines fed from two HIP streams at 1080p, their forward passes really overlapping on the device (nothing in the
-    library serialises them), give the single-pass logits -- themselves within 1e-4 of the oracle -- bit for bit, pass after
+    library serialises them), give the single-pass logits -- themselves within 2.5e-4 (mixed) / 1e-4 of the oracle -- bit for bit, pass after
     pass.  Round 1 saw sporadic 1e-3..2e-2 errors in the one-channel heads here (packed-fp32 code)."""
     import torch
     from lecturemath_amd import fcn
@@ -308,7 +322,8 @@ def test_fcn_two_engines_on_two_streams(hip_lib, fcn_1080p_oracle, precision):
         engines.append(e)
     d = torch.from_numpy(rgb).cuda()
     gold = [x.clone() for x in engines[0].forward(d)]
-    assert float(np.abs(gold[0].cpu().numpy() - o).max()) <= 1e-4 and float(np.abs(gold[1].cpu().numpy() - t).max()) <= 1e-4
+    tol = 2.5e-4 if precision == "mixed" else 1e-4
+    assert float(np.abs(gold[0].cpu().numpy() - o).max()) <= tol and float(np.abs(gold[1].cpu().numpy() - t).max()) <= tol
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     torch.cuda.synchronize()
     for _ in range(10):

@@ -173,10 +173,16 @@ def test_fcn_golden_tiny(emu_lib, precision):
     assert lm_checks.check_fcn_golden(emu_lib, "k7_70x94", precision=precision) < 1e-4
 
 
+@pytest.mark.parametrize("precision,tol", [("mixed", 5e-4), ("planar-f16x3", 1e-5)])
+def test_fcn_golden_planar_engine_emulated(emu_lib, precision, tol):
+    """the planar engine's kernels (CPU emulation of the same sources) against the REFERENCE module's outputs (G5 wide case)"""
+    assert lm_checks.check_fcn_golden(emu_lib, "k7_66x130_wide", tol=tol, precision=precision, require_planar=True) <= tol
+
+
 PLANAR_TINY_WIDTHS = (16, 32, 16, 16, 16, 32, 32, 16, 16, 16, 16, 16, 16, 48, 16, 32, 32, 16)       # channel blocks of 1, 2 and 3 tiles; one merged-dx transposed conv
 
 
-@pytest.mark.parametrize("precision,tol", [("mixed", 1e-4), ("planar-f16x3", 1e-5)])
+@pytest.mark.parametrize("precision,tol", [("mixed", 5e-4), ("planar-f16x3", 1e-5)])
 def test_fcn_planar_tiny_vs_oracle(emu_lib, precision, tol):
     """The planar FCN engine (csrc/lm_fcn2.hip: gather-GEMM on 16x16x32 MFMA tiles, planar f16 activations, LDS-DMA staging, pair
     planes) on the CPU emulator against the torch oracle: an odd-sized frame (every output_size border, floor pooling), then a
@@ -241,7 +247,7 @@ def test_emulated_library_under_asan_ubsan(oracle_built, tmp_path):
         "assert eng2.planar\n"
         "eng2.load_state_dict({k[3:]: p[k] for k in p.files if k.startswith('sd.')})\n"
         "out, text, rec = eng2.forward(g['rgb'])\n"
-        "assert np.abs(out - p['out']).max() < 1e-4 and np.abs(text - p['text']).max() < 1e-4 and np.abs(rec - p['rec']).max() < 1e-4\n"
+        "assert np.abs(out - p['out']).max() < 5e-4 and np.abs(text - p['text']).max() < 5e-4 and np.abs(rec - p['rec']).max() < 5e-4\n"
         "lm_checks.check_stream_large_components(lib, n_frames=4)\n"
         "lm_checks.check_grouping_oracle(lib, lm_checks.dot_grid_stream(n_frames=4, h=40, w=520))\n"
         "print('sanitized run ok')\n" % (os.path.dirname(os.path.dirname(d)), os.path.dirname(d), os.path.join(d, "liblecturemath_emu_asan.so"), fx,

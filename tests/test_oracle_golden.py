@@ -151,3 +151,24 @@ def test_g6b_lanczos():
     g = np.load(os.path.join(GOLD, "g6b_lanczos.npz"))
     for i, (h, w, oh, ow) in enumerate(g["cases"]):
         assert (resize.resize_lanczos(g["in%d" % i], int(ow), int(oh)) == g["out%d" % i]).all(), i
+
+
+@pytest.mark.parametrize("name", ["k7_70x94", "k3_135x240", "k7_66x130_wide"])
+def test_g5_fcn(name):
+    """oracle/fcn.py (the torch fp32 restatement every HIP FCN test is measured against) vs the REFERENCE module's outputs (G5,
+    tests/golden/make_golden_fcn.py): forward() logits / text logits / reconstruction, the x_up1 intermediate, and binarize()'s three
+    byte images.  Same torch build, same operators in the same order: the bar is exact equality; 1e-6 is allowed for a torch
+    whose conv kernels reassociate differently."""
+    import torch
+    from oracle import fcn as ofcn
+    g = np.load(os.path.join(GOLD, "g5_fcn_%s.npz" % name))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    rgb = g["rgb"]
+    with torch.no_grad():
+        out, text, rec, inter = ofcn.forward(sd, ofcn.prepare_image(rgb), return_intermediates=True)
+    assert np.abs(out.numpy() - g["out"]).max() <= 1e-6
+    assert np.abs(text.numpy() - g["text"]).max() <= 1e-6
+    assert np.abs(rec.numpy() - g["rec"]).max() <= 1e-6
+    assert np.abs(inter["up1"].numpy() - g["x_up1"]).max() <= 1e-6
+    b, t, r = ofcn.binarize(sd, rgb)
+    assert (b == g["binary"]).all() and (t == g["text_mask"]).all() and (r == g["rec_img"]).all()
