@@ -176,12 +176,20 @@ def measure_fcn(a, lib, H, W, n_frames, with_oracle):
     return res, eng, sd
 
 
-def measure_e2e_rgb(a, lib, eng, H, W, n_frames):
+def measure_e2e_rgb(a, lib, eng, H, W, n_frames, sd=None):
     """RGB uint8 frames resident in HBM -> FCN logits -> threshold+invert -> label/records/matching -> step 03 -> all frames
-    reconstructed.  Random-init weights: the binarization is whatever the network emits (CC counts are reported)."""
+    reconstructed.  Random-init weights: the binarization is whatever the network emits (CC counts are reported).
+    The frames are dealt to TWO engines on two HIP streams (the layers below 1/8 resolution launch 288-480 workgroups on 256 CUs: a
+    second forward pass in flight fills what one leaves idle; profiles/r04_fcn_two_streams.txt: 437 -> 475 frames/s)."""
     import torch
-    from lecturemath_amd import _lib, device, synth
+    from lecturemath_amd import _lib, device, fcn, synth
     fh, fw = fcn_frame_size(H, W)
+    engines = [eng]
+    if sd is not None and eng.planar and not os.environ.get("LM_BENCH_ONE_FCN_STREAM"):
+        e2 = fcn.FcnEngine(eng.widths, eng.pk, eng.kk, fh, fw, lib, precision=a.fcn_precision)
+        e2.load_state_dict(sd)
+        engines.append(e2)
+    side = [torch.cuda.Stream() for _ in engines[1:]]
     big = (fh, fw) != (H, W)
     if big:
         n_frames = min(n_frames, 32)
@@ -210,8 +218,14 @@ def measure_e2e_rgb(a, lib, eng, H, W, n_frames):
                 n = min(a.batch, n_frames - f0)
                 lib.check(lib.lm_stream_push(fs.handle, binary[f0:f0 + n].data_ptr(), n, labels.data_ptr(), st))
         else:
+            main = torch.cuda.current_stream()
+            for sx in side:
+                sx.wait_stream(main)
             for i in range(n_frames):
-                eng.forward_raw(rgb[i].data_ptr(), H, W, logits[i].data_ptr(), None, None, st)
+                k = i % len(engines)
+                engines[k].forward_raw(rgb[i].data_ptr(), H, W, logits[i].data_ptr(), None, None, st if k == 0 else side[k - 1].cuda_stream)
+            for sx in side:
+                main.wait_stream(sx)
             lib.check(lib.lm_stream_run_logits(fs.handle, logits.data_ptr(), n_frames, min(a.batch, n_frames), None, labels.data_ptr(), 128, 1, 0, st, st))
         gr = device.Grouping(fs, max_gap=85, min_times=3, t_window=5, min_recall=0.5, img_threshold=0.5, reconstruct=True)
         gr.render(0, n_frames, clean)
@@ -232,11 +246,14 @@ def measure_e2e_rgb(a, lib, eng, H, W, n_frames):
                             "matching -> step 03 -> %d reconstructed frames" % (n_frames, W, H, "LANCZOS 1/2 (device) -> " if big else "", a.fcn_precision,
                                                                                 " at %dx%d" % (fw, fh) if big else "", "NEAREST x2 (device) -> " if big else "", n_frames),
                 "frames": n_frames, "value": round(n_frames / dt, 2), "unit": "frames/s", "ms_per_frame": round(dt / n_frames * 1e3, 3),
+                "fcn_engines_in_flight": 1 if big else len(engines),
                 "stream": {"n_cc": k["n_cc"], "n_unique": k["n_unique"], "n_groups": int(sc[2])}}
     except _lib.LecturemathError as e:
         return {"error": str(e)}
     finally:
         fs.close()
+        for e in engines[1:]:
+            e.close()
 
 
 def main_fcn(a):
@@ -375,13 +392,11 @@ def main_sharded(a, torch, dist, lib, world, rank, rehearse, logits, gen_s):
         dg = digests.from_device(info["gs"], info["gr"])
         k1 = info["gs"].counters()
         parity = {"digests": dg, "counters": {k: k1[k] for k in ("n_cc", "n_unique", "tempo_count")}, "n_groups": info["scalars"][2], "reference": None, "match": None}
-        gpath = os.path.join(ROOT, "tests", "golden", "g9_stream1080p_digests.json")
-        if os.path.exists(gpath) and (W, H, a.seed) == (1920, 1080, 20213):
-            ref = json.load(open(gpath)).get(str(F))
-            if ref:
-                keys = [k for k in dg if k in ref]
-                parity["reference"] = "tests/golden/g9_stream1080p_digests.json[%d]" % F
-                parity["match"] = bool(all(dg[k] == ref[k] for k in keys) and ref["tempo_count"] == k1["tempo_count"] and ref["n_cc"] == k1["n_cc"])
+        ref, gname = golden_digests(W, H, a.seed, F)
+        if ref:
+            keys = [k for k in dg if k in ref]
+            parity["reference"] = "%s[%d]" % (gname, F)
+            parity["match"] = bool(all(dg[k] == ref[k] for k in keys) and ref["tempo_count"] == k1["tempo_count"] and ref["n_cc"] == k1["n_cc"])
         info["gr"].close()
     steps_all = [collect(per_step, r) for r in range(world)]
     parity = collect(parity, sh.group_rank)
@@ -453,6 +468,17 @@ def main_sharded(a, torch, dist, lib, world, rank, rehearse, logits, gen_s):
         print(json.dumps(out))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def golden_digests(W, H, seed, F):
+    """(digests of the reference / the oracle for this stream, file name) or (None, None): 1080p and 4K streams of the bench's generator"""
+    name = {(1920, 1080): "g9_stream1080p_digests.json", (3840, 2160): "g9_stream4k_digests.json"}.get((W, H))
+    if name is None or seed != 20213:
+        return None, None
+    path = os.path.join(ROOT, "tests", "golden", name)
+    if not os.path.exists(path):
+        return None, None
+    return json.load(open(path)).get(str(F)), "tests/golden/" + name
 
 
 def self_launch(a):
@@ -788,15 +814,13 @@ def main():
 
     parity = {"digests": dg[0] if dg else None, "all_slots_identical": all(core(d) == core(dg[0]) for d in dg),
               "counters": {k: k1[k] for k in ("n_cc", "n_unique", "tempo_count")}, "reference": None, "match": None}
-    gpath = os.path.join(ROOT, "tests", "golden", "g9_stream1080p_digests.json")
-    if os.path.exists(gpath) and (W, H, a.seed) == (1920, 1080, 20213) and dg:
-        ref = json.load(open(gpath)).get(str(F))
-        if ref:
-            keys = [k for k in dg[0] if k in ref]
-            parity["reference"] = ("tests/golden/g9_stream1080p_digests.json[%d] (%s run on the same stream in the build container)"
-                                   % (F, "the oracle, itself pinned to the reference on the first 1,000 frames," if ref.get("produced_by") == "oracle" else "the reference"))
-            parity["match"] = bool(all(dg[0][k] == ref[k] for k in keys) and ref["tempo_count"] == k1["tempo_count"] and ref["n_cc"] == k1["n_cc"])
-            parity["compared"] = keys + ["tempo_count", "n_cc"]
+    ref, gname = golden_digests(W, H, a.seed, F) if dg else (None, None)
+    if ref:
+        keys = [k for k in dg[0] if k in ref]
+        parity["reference"] = ("%s[%d] (%s run on the same stream in the build container)"
+                               % (gname, F, "the oracle, itself pinned to the reference on the first 1,000 frames of the 1080p stream," if ref.get("produced_by") == "oracle" else "the reference"))
+        parity["match"] = bool(all(dg[0][k] == ref[k] for k in keys) and ref["tempo_count"] == k1["tempo_count"] and ref["n_cc"] == k1["n_cc"])
+        parity["compared"] = keys + ["tempo_count", "n_cc"]
     if parity["match"] is False or not parity["all_slots_identical"]:
         sys.stderr.write("bench.py: digests differ (reference match: %r, slots identical: %r) -- the rate below is NOT a valid result\n"
                          % (parity["match"], parity["all_slots_identical"]))
@@ -879,10 +903,10 @@ def main():
         for sl in slots:
             sl["fs"].close()
         torch.cuda.empty_cache()
-        res, eng, _ = measure_fcn(a, lib, H, W, a.fcn_frames, not a.no_fcn_oracle)
+        res, eng, fsd = measure_fcn(a, lib, H, W, a.fcn_frames, not a.no_fcn_oracle)
         out["fcn"] = res
         if a.e2e_frames > 0:
-            out["e2e_rgb"] = measure_e2e_rgb(a, lib, eng, H, W, a.e2e_frames)
+            out["e2e_rgb"] = measure_e2e_rgb(a, lib, eng, H, W, a.e2e_frames, sd=fsd)
         eng.close()
     print(json.dumps(out))
     if world > 1:

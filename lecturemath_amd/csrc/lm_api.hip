@@ -169,7 +169,7 @@ extern "C" LmCtx* lm_ctx_create(int width, int height, int max_batch)
     c->g.H = height;
     c->g.WW = (width + 63) / 64;
     c->band_rows = (c->g.WW > 32) ? 16 : LM_BAND_ROWS_MAX;
-    if (const char* e = getenv("LM_BAND_ROWS")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32) c->band_rows = v; }      // tuning experiments
+    if (const char* e = getenv("LM_BAND_ROWS")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) c->band_rows = v; }      // tuning experiments
     c->nbands = (height + c->band_rows - 1) / c->band_rows;
     c->slot = ((c->band_rows * ((width + 1) / 2)) + 63) & ~63;       // worst-case runs of one band, multiple of 64
     c->g.cap = c->nbands * c->slot;
@@ -279,6 +279,9 @@ struct LmLabelSrc {
     const float* logits; float edge; unsigned flip; uint8_t* d_binary_out;
 };
 
+// runs of a band's union-find forest kept in LDS: 4,096 (16 KB) for bands of up to 32 rows, 8,192 for 64-row bands
+static inline int lm_band_lds_runs(int band_rows) { return band_rows > 32 ? 2 * LM_BAND_LDS : LM_BAND_LDS; }
+
 // phase: 0 = the whole sequence, 1 = the row packing only, 2 = everything behind it
 static int lm_label_launch(LmCtx* c, const LmLabelSrc& src, int f0, int n, int32_t* d_labels, hipStream_t st, int phase = 0)
 {
@@ -286,7 +289,8 @@ static int lm_label_launch(LmCtx* c, const LmLabelSrc& src, int f0, int n, int32
     const LmGeom g = c->g;
     const int nbands = c->nbands, slot = c->slot;
     const int capw = g.cap / 64;
-    const size_t band_smem = (size_t)c->band_rows * g.WW * 18 + LM_BAND_LDS * 4 + (65 + 64) * 4 + 64;
+    const int band_lds = lm_band_lds_runs(c->band_rows);
+    const size_t band_smem = (size_t)c->band_rows * g.WW * 18 + (size_t)band_lds * 4 + (65 + 64) * 4 + 64;
     const unsigned long long magic_ww = ((1ull << 40) / (unsigned)g.WW) + 1;
     const long long R = (long long)n * g.H;
     const size_t px = (size_t)g.W * g.H, r0 = (size_t)f0 * g.H, w0 = r0 * g.WW, b0 = (size_t)f0 * nbands, c0 = (size_t)f0 * g.cap, cw0 = (size_t)f0 * capw;
@@ -302,7 +306,7 @@ rest:
     static const int band_threads = [] { const char* e = getenv("LM_BAND_THREADS"); const int v = e ? atoi(e) : 512; return (v == 128 || v == 256 || v == 512) ? v : 512; }();
     hipLaunchKernelGGL(lm_k_band, dim3(nbands, n), dim3(band_threads), band_smem, st, c->bits + w0, c->starts + w0, c->prefix + w0, c->rowcnt + r0,
                        c->rowoff + r0, c->band_runs + b0, c->parent + c0, c->band_fallback + b0, g.H, g.WW, slot, g.cap, lm_debug_band_phases(), magic_ww,
-                       c->band_rows, f0 == 0 ? lm_debug_band_stamps(nbands, n) : nullptr);
+                       c->band_rows, f0 == 0 ? lm_debug_band_stamps(nbands, n) : nullptr, band_lds);
     const LmStatInit si = {c->st_min_y + c0, c->st_max_y + c0, c->st_min_x + c0, c->st_max_x + c0, c->st_count + c0, g.W, g.H};
     static const int fused_middle = [] { const char* e = getenv("LM_LABEL_FUSED_MIDDLE"); return e ? atoi(e) : LM_LABEL_FUSED_MIDDLE_DEFAULT; }();
 #if !LM_HIP_EMULATED
@@ -356,7 +360,7 @@ static int lm_label_batch_src(LmCtx* c, const LmLabelSrc& src, int n_frames, int
     {
         // per call: the attribute belongs to the (function, device) pair and the call is cheap; a process-wide "already configured"
         // flag would skip it on a second device or race between caller threads
-        const size_t band_smem = (size_t)c->band_rows * g.WW * 18 + LM_BAND_LDS * 4 + (65 + 64) * 4 + 64;
+        const size_t band_smem = (size_t)c->band_rows * g.WW * 18 + (size_t)lm_band_lds_runs(c->band_rows) * 4 + (65 + 64) * 4 + 64;
         LM_HIP(hipFuncSetAttribute((const void*)lm_k_band, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_smem));
     }
 #endif

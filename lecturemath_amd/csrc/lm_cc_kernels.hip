@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(512) lm_k_band(const uint64_t* __restrict__ bi
                                                  const uint16_t* __restrict__ prefix, const uint32_t* __restrict__ rowcnt,
                                                  uint32_t* __restrict__ rowoff, int32_t* __restrict__ band_runs, int32_t* __restrict__ parent,
                                                  uint8_t* __restrict__ band_fallback, int H, int WW, int slot, int cap, int phases,
-                                                 unsigned long long magic_ww, int brows, unsigned long long* __restrict__ stamps)
+                                                 unsigned long long magic_ww, int brows, unsigned long long* __restrict__ stamps, int lds_runs)
 {
     LM_DYN_SMEM(smem);
     const int b = blockIdx.y, band = blockIdx.x, nbands = gridDim.x;
@@ -420,8 +420,8 @@ __global__ void __launch_bounds__(512) lm_k_band(const uint64_t* __restrict__ bi
     const long long row0 = (long long)b * H + y0;
     unsigned long long* s_bits = (unsigned long long*)smem;                   // [brows][WW]
     unsigned long long* s_starts = s_bits + brows * WW;                       // [brows][WW]
-    int32_t* s_par = (int32_t*)(s_starts + brows * WW);                       // [LM_BAND_LDS]
-    unsigned* s_rowoff = (unsigned*)(s_par + LM_BAND_LDS);                    // [65]
+    int32_t* s_par = (int32_t*)(s_starts + brows * WW);                       // [lds_runs]
+    unsigned* s_rowoff = (unsigned*)(s_par + lds_runs);                       // [65]
     unsigned* s_rowcnt = s_rowoff + 65;                                       // [64]
     uint16_t* s_prefix = (uint16_t*)(s_rowcnt + 64);                          // [brows][WW]
     const int lane = lm_lane(), wave = (int)(threadIdx.x >> 6);
@@ -451,10 +451,10 @@ __global__ void __launch_bounds__(512) lm_k_band(const uint64_t* __restrict__ bi
     int32_t* par_g = parent + (long long)b * cap + (long long)band * slot;
     if (threadIdx.x == 0) {
         band_runs[b * nbands + band] = n;
-        band_fallback[b * nbands + band] = (n > LM_BAND_LDS) ? 1 : 0;
+        band_fallback[b * nbands + band] = (n > lds_runs) ? 1 : 0;
     }
     if (n == 0) return;
-    if (n > LM_BAND_LDS || phases == 2) {      // too many runs for the LDS forest (phases == 2: profiling aid, unions left to L2): identity parents, lm_k_band_union_global does the unions
+    if (n > lds_runs || phases == 2) {      // too many runs for the LDS forest (phases == 2: profiling aid, unions left to L2): identity parents, lm_k_band_union_global does the unions
         for (int i = threadIdx.x; i < n; i += blockDim.x) par_g[i] = band * slot + i;
         return;
     }

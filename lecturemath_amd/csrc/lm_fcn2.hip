@@ -829,6 +829,7 @@ static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor*
     static const int ring_env = [] { const char* e = getenv("LM_FCN2_RING"); return e ? atoi(e) : 0; }();
     int ring = l.ngroups > 2 ? 3 : (l.ngroups > 1 ? 2 : 1);
     if (ring == 3 && fixed + 3 * (size_t)l.wbuf_bytes > 80 * 1024 && fixed + 2 * (size_t)l.wbuf_bytes <= 80 * 1024) ring = 2;
+    if (ring == 3 && fixed + 3 * (size_t)l.wbuf_bytes > 160 * 1024) ring = 2;
     if (ring_env == 2 && ring == 3) ring = 2;
     a.wring = ring < 2 ? 2 : ring;
     const size_t smem = fixed + (size_t)ring * l.wbuf_bytes;

@@ -111,7 +111,9 @@ def build(w_list, chunks, kh, kw, terms, mt, epi, gsize=None, pdouble=None, lds_
     if gsize is None:
         gsize = 1
         for cand in range(2, 17):
-            if lds_bytes(kh, kw, terms, npc, nslices, pdouble, cand * per_slice, 2, nc) <= lds_target:
+            # two weight buffers within the target for the layers that share a CU's LDS between two workgroups (the run-time ring takes a
+            # third when it fits 80 KB); three where a workgroup has the CU to itself
+            if lds_bytes(kh, kw, terms, npc, nslices, pdouble, cand * per_slice * (3 if lds_target > LDS_TWO_WORKGROUPS else 2) // 2, 2, nc) <= lds_target:
                 gsize = cand
     groups = []
     s = 0
@@ -195,10 +197,13 @@ def conv_layer(w, inputs, terms, tiles, mt=None, nc=1, loader=0, lds_target=LDS_
     return best[1]
 
 
-def pixel_chunks(feat_tensor, nf, dp_tensor, kh_total, kw_total):
+def pixel_chunks(feat_tensor, nf, dp_tensor, kh_total, kw_total, octets=2):
     """(diff, features) input of the 7x7 pixel branch / the output row convolution: chunks of two feature octets + the diff pair plane;
     the pair plane's taps (kernel columns 0, 2, 4, 6: a slot covers two) are spread over the chunks' last slices.
-    Weight input axis: 0..2 diff, 3.. features (cat((diff, features)), FCN_lecturenet.py:383-395)."""
+    Weight input axis: 0..2 diff, 3.. features (cat((diff, features)), FCN_lecturenet.py:383-395).
+    octets = 1: chunks of ONE feature octet + the pair plane (half the patch bytes in LDS: a 16 x 32 tile of a split format fits)."""
+    if octets == 1:
+        return pixel_chunks_1(feat_tensor, nf, dp_tensor, kh_total, kw_total)
     assert nf % 2 == 0
     nch = nf // 2
     dp_taps = list(range(0, kw_total, 2))
@@ -216,6 +221,20 @@ def pixel_chunks(feat_tensor, nf, dp_tensor, kh_total, kw_total):
             row += [pairplane_pair(2, dy, dx, 0, kw_total) for dx in share[c]]
             pairs += row
         chunks.append({"planes": [(feat_tensor, 2 * c), (feat_tensor, 2 * c + 1), (dp_tensor, 0)], "pairs": pairs})
+    return chunks
+
+
+def pixel_chunks_1(feat_tensor, nf, dp_tensor, kh_total, kw_total):
+    """one feature octet per chunk: per kernel row its kw taps, then the chunk's share of the pair plane's taps"""
+    dp_taps = list(range(0, kw_total, 2))
+    share = [dp_taps[i * len(dp_taps) // nf:(i + 1) * len(dp_taps) // nf] for i in range(nf)]
+    chunks = []
+    for c in range(nf):
+        pairs = []
+        for dy in range(kh_total):
+            pairs += [octet_pair(0, dy, dx, 3 + 8 * c) for dx in range(kw_total)]
+            pairs += [pairplane_pair(1, dy, dx, 0, kw_total) for dx in share[c]]
+        chunks.append({"planes": [(feat_tensor, c), (dp_tensor, 0)], "pairs": pairs})
     return chunks
 
 

@@ -6,6 +6,7 @@ it keeps every CC object of every frame with its uint8 mask plus ~19 GB of group
 first 1,000 frames of this very stream (g9_stream1080p_digests.json["1000"], produced by the reference).
 
     python tests/golden/make_oracle_stream1080p_digests.py [n_frames]        # default 10000; tens of minutes, ~30 GB
+    python tests/golden/make_oracle_stream1080p_digests.py --4k 1024         # configs[4]: 3840 x 2160 -> g9_stream4k_digests.json
 
 Writes g9_stream1080p_digests.json["<n>"] with "produced_by": "oracle"; group images and reconstructed frames are not
 produced (the oracle's numpy version of them needs the same tens of GB)."""
@@ -24,6 +25,10 @@ from oracle import grouping as og  # noqa: E402
 
 OUT = os.path.join(HERE, "g9_stream1080p_digests.json")
 H, W, SEED = 1080, 1920, 20213
+if "--4k" in sys.argv:          # BASELINE configs[4]: the same generator at 3840 x 2160 (bench.py --height 2160 --width 3840 --frames N)
+    sys.argv.remove("--4k")
+    OUT = os.path.join(HERE, "g9_stream4k_digests.json")
+    H, W = 2160, 3840
 
 
 def run(n):

@@ -27,27 +27,36 @@ GOLD = json.load(open(os.path.join(lm_checks.GOLD, "g9_stream1080p_digests.json"
 DIGEST_KEYS = ("unique_cc_frames", "cc_idx_per_frame", "cc_groups", "group_ages", "groups_per_frame", "group_boundaries")
 
 
-def run_stream(lib, n_frames, batch=64):
-    """The stream through the device path exactly as bench.py drives it: logits -> threshold+invert per batch -> push."""
+def run_stream(lib, n_frames, batch=64, schedule=0, chunk=256):
+    """The stream through the PRODUCTION loop, as bench.py drives it: fp32 logits resident on the device -> lm_stream_run_logits (per batch:
+    fused threshold + row packing -> labelling -> statistics -> records / crops on the wide stream, temporal matching on a second stream
+    behind an event per batch; schedule 0 = free, 1 = gated).  The logits are generated a chunk of frames at a time (the library call
+    appends to the stream, as lecturemath_amd.sharded does per piece); the int32 label image is written for every batch."""
     import torch
+    from lecturemath_amd import _lib
     fs = device.FrameStream(W, H, n_frames, 0.85, 0.85, 85, 20, max_batch=batch, max_ccs=n_frames * 4096, max_crop_words=n_frames * (1 << 17), lib=lib)
     labels = torch.empty((batch, H, W), dtype=torch.int32, device="cuda")
-    buf = []
+    s_match = torch.cuda.Stream()
+    ws = torch.cuda.current_stream().cuda_stream
+    buf, keep = [], []
 
     def flush():
         if buf:
             mask = torch.from_numpy(np.stack(buf)).cuda()
             logits = torch.where(mask > 0, -4.0, 4.0) + (torch.rand(mask.shape, device="cuda") - 0.5)     # ink <=> negative logit
-            binary = fs.labeler.threshold_invert(logits)
-            assert bool((binary == mask).all())
-            fs.push(binary, labels[:len(buf)])
+            lib.check(lib.lm_stream_run_logits(fs.handle, _lib.ptr(logits), len(buf), batch, None, _lib.ptr(labels), 128, 1, schedule, ws, s_match.cuda_stream))
+            keep.append(logits)             # the matching stream may still be behind: the chunk's logits live until the end
+            if len(keep) > 2:
+                torch.cuda.synchronize()
+                del keep[:-1]
             buf.clear()
 
     for f in synth.binary_stream(n_frames, H, W, seed=SEED):
         buf.append(f)
-        if len(buf) == batch:
+        if len(buf) == chunk:
             flush()
     flush()
+    torch.cuda.synchronize()
     return fs
 
 
@@ -85,7 +94,7 @@ def check_against_reference(fs, n_frames, with_frames):
 
 def test_first_1000_frames_vs_oracle_and_reference(hip_lib, oracle_built):
     n = 1000
-    fs = run_stream(hip_lib, n)
+    fs = run_stream(hip_lib, n, schedule=1)        # the gated schedule; the 10,000-frame test runs the free one (bench.py's default)
     try:
         st = oracle_built.Stability(W, H, 0.85, 0.85, 85)
         for f in synth.binary_stream(n, H, W, seed=SEED):

@@ -13,20 +13,18 @@ from oracle import fcn as ofcn
 from oracle import cc as occ
 
 D1, U1, TXT, PX1, PX2, OUT = 0, 15, 16, 18, 19, 20
-ASSIGN = {
+ASSIGN = {       # overrides on top of precision="mixed" (fcn.FcnEngine.MIXED_FORMATS: conv_up_1, text / rec heads, conv_pixels_1 on w2 since round 4)
     "mixed": {},
-    "up1=w2": {U1: "w2"},
-    "up1=a2": {U1: "a2"},
-    "px1=w2": {PX1: "w2"},
+    "r3-mixed (all six f16x3)": {U1: "f16x3", TXT: "f16x3", PX1: "f16x3"},
+    "up1=w2": {TXT: "f16x3", PX1: "f16x3"},
+    "up1,px1=w2": {TXT: "f16x3"},
     "px1=a2": {PX1: "a2"},
-    "up1,px1=w2": {U1: "w2", PX1: "w2"},
-    "up1,px1=a2": {U1: "a2", PX1: "a2"},
-    "up1,px1,px2=w2": {U1: "w2", PX1: "w2", PX2: "w2"},
-    "up1,px1,txt=w2": {U1: "w2", PX1: "w2", TXT: "w2"},
-    "up1,px1,px2,txt=w2": {U1: "w2", PX1: "w2", PX2: "w2", TXT: "w2"},
-    "up1,px1,px2,txt,d1=w2": {U1: "w2", PX1: "w2", PX2: "w2", TXT: "w2", D1: "w2"},
-    "all6=w2": {U1: "w2", PX1: "w2", PX2: "w2", TXT: "w2", D1: "w2", OUT: "w2"},
-    "up1=f16,px1=w2": {U1: "f16", PX1: "w2"},
+    "px2=a2": {PX2: "a2"},
+    "px2=w2": {PX2: "w2"},
+    "px1=a2,px2=a2": {PX1: "a2", PX2: "a2"},
+    "out=a2": {OUT: "a2"},
+    "d1=w2": {D1: "w2"},
+    "px2=a2,out=a2,d1=w2": {PX2: "a2", OUT: "a2", D1: "w2"},
     "planar-f16": None,
 }
 out_path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/fcn_formats.json"
