@@ -493,7 +493,13 @@ def self_launch(a):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.exit(subprocess.call(cmd, env=env))
+    # the ranks' stdout is relayed line by line: the JSON line to stdout, anything else a library printed there (gloo's connection
+    # notes in the one-GPU rehearsal) to stderr, so that stdout carries the ONE line the contract asks for
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    sys.exit(proc.wait())
 
 
 def label_traffic(W, H, fused, frames_per_launch):
