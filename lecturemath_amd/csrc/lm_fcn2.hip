@@ -603,7 +603,7 @@ struct LmF2Tensor {
 };
 
 struct LmF2Layer {
-    int kh = 0, kw = 0, terms = 0, mt = 0, epi = 0, nchunks = 0, npc = 0, ngroups = 0, nslices = 0, pdouble = 0, wbuf_bytes = 0, cout = 0, nc = 1, loader = 0;
+    int kh = 0, kw = 0, terms = 0, mt = 0, epi = 0, nchunks = 0, npc = 0, ngroups = 0, nslices = 0, pdouble = 0, wbuf_bytes = 0, cout = 0, nc = 1, loader = 0, lds_kb = 0;
     std::vector<int> planes;            // [nchunks * npc][2] tensor id, octet
     long long wblock_bytes = 0;
     char* d_w = nullptr; float* d_bias = nullptr;
@@ -684,7 +684,7 @@ extern "C" LmFcn2* lm_fcn2_create(const int32_t* widths18, const int32_t* lo25, 
 }
 
 // One layer's recipe (lecturemath_amd/fcn2.py builds it and documents the layout).  desc: kh, kw, terms, mt, epi, nchunks, npc, ngroups,
-// nslices, flags (bits 0-3: column tiles per wave, 1 or 2; bit 8: loader wave), pdouble, wbuf_bytes, cout, then planes [nchunks * npc][2], groups [ngroups][3], slice table [nslices][4].
+// nslices, flags (bits 0-3: column tiles per wave, 1 or 2; bit 8: loader wave; bits 16-23: LDS target in KB), pdouble, wbuf_bytes, cout, then planes [nchunks * npc][2], groups [ngroups][3], slice table [nslices][4].
 // HOST pointers.  wblocks = channel blocks (x 4 parities for a transposed convolution) of wbytes / wblocks bytes each.
 extern "C" int lm_fcn2_set_layer(LmFcn2* f, int layer, const int32_t* desc, int ndesc, const void* h_w, int64_t wbytes, int wblocks, const float* h_bias,
                                  int nbias)
@@ -697,7 +697,7 @@ extern "C" int lm_fcn2_set_layer(LmFcn2* f, int layer, const int32_t* desc, int 
     for (void* p : {(void*)l.d_w, (void*)l.d_bias, (void*)l.d_groups, (void*)l.d_t4, (void*)l.d_psrc}) if (p) (void)hipFree(p);
     l = LmF2Layer();
     l.kh = desc[0]; l.kw = desc[1]; l.terms = desc[2]; l.mt = desc[3]; l.epi = desc[4]; l.nchunks = desc[5]; l.npc = desc[6]; l.ngroups = desc[7];
-    l.nslices = desc[8]; l.nc = (desc[9] & 15) ? (desc[9] & 15) : 1; l.loader = (desc[9] >> 8) & 1; l.pdouble = desc[10]; l.wbuf_bytes = desc[11]; l.cout = desc[12];
+    l.nslices = desc[8]; l.nc = (desc[9] & 15) ? (desc[9] & 15) : 1; l.loader = (desc[9] >> 8) & 1; l.lds_kb = (desc[9] >> 16) & 0xff; l.pdouble = desc[10]; l.wbuf_bytes = desc[11]; l.cout = desc[12];
     const long long need = 13 + (long long)l.nchunks * l.npc * 2 + (long long)l.ngroups * 3 + (long long)l.nslices * 4;
     if (l.nchunks <= 0 || l.npc <= 0 || l.ngroups <= 0 || l.nslices <= 0 || need != ndesc || wbytes % wblocks || wbytes >= (1ll << 31) || l.nc < 1 || l.nc > 2) {
         lm_set_error("lm_fcn2_set_layer: inconsistent recipe for layer %d", layer);
@@ -765,7 +765,7 @@ template <int KH, int KW, int TERMS, int MT, int EPI, int NC, int LOADER> static
 
 // The instances that exist (each is a kernel of its own in the code object; lecturemath_amd/fcn2.py only asks for these):
 //   variant 0 = 16 x 16 tile, four waves;  1 = 16 x 16 tile + loader wave;  2 = 16 x 32 tile, four waves
-//   3 x 3 convolutions: formats 1 / 3 / 4, 1..4 channel tiles (loader: <= 2 tiles, formats 1 / 4; wide: <= 3 tiles)
+//   3 x 3 convolutions: formats 1 / 3 / 4, 1..4 channel tiles (loader: <= 2 tiles, formats 1 / 4; wide: <= 3 tiles on f16, <= 2 on a split format)
 //   7 x 7 convolutions: formats 1..4, 1..2 channel tiles, all variants;  1 x 7 head rows: formats 1..4, variants 0 and 2
 //   transposed convolutions: formats 1 / 3, 1..4 channel tiles, variant 0
 #define LM_G2_TRY(KH, KW, T, M, E, N, L) \
@@ -779,8 +779,8 @@ static int lm_g2_launch(const LmF2Layer& l, const LmG2Args& a, dim3 grid, size_t
         LM_G2_TRY_MT4(3, 3, 1, LM_G2_EPI_PO, 1, 0) LM_G2_TRY_MT4(3, 3, 3, LM_G2_EPI_PO, 1, 0) LM_G2_TRY_MT4(3, 3, 4, LM_G2_EPI_PO, 1, 0)
         LM_G2_TRY(3, 3, 1, 1, LM_G2_EPI_PO, 1, 1) LM_G2_TRY(3, 3, 1, 2, LM_G2_EPI_PO, 1, 1) LM_G2_TRY(3, 3, 4, 1, LM_G2_EPI_PO, 1, 1) LM_G2_TRY(3, 3, 4, 2, LM_G2_EPI_PO, 1, 1)
         LM_G2_TRY(3, 3, 1, 1, LM_G2_EPI_PO, 2, 0) LM_G2_TRY(3, 3, 1, 2, LM_G2_EPI_PO, 2, 0) LM_G2_TRY(3, 3, 1, 3, LM_G2_EPI_PO, 2, 0)
-        LM_G2_TRY(3, 3, 3, 1, LM_G2_EPI_PO, 2, 0) LM_G2_TRY(3, 3, 3, 2, LM_G2_EPI_PO, 2, 0) LM_G2_TRY(3, 3, 3, 3, LM_G2_EPI_PO, 2, 0)
-        LM_G2_TRY(3, 3, 4, 1, LM_G2_EPI_PO, 2, 0) LM_G2_TRY(3, 3, 4, 2, LM_G2_EPI_PO, 2, 0) LM_G2_TRY(3, 3, 4, 3, LM_G2_EPI_PO, 2, 0)
+        LM_G2_TRY(3, 3, 3, 1, LM_G2_EPI_PO, 2, 0) LM_G2_TRY(3, 3, 3, 2, LM_G2_EPI_PO, 2, 0)       // (three tiles of a split format spill)
+        LM_G2_TRY(3, 3, 4, 1, LM_G2_EPI_PO, 2, 0) LM_G2_TRY(3, 3, 4, 2, LM_G2_EPI_PO, 2, 0)
     } else if (shape == 11 && (l.epi == LM_G2_EPI_TC || l.epi == LM_G2_EPI_TC2)) {
         if (l.epi == LM_G2_EPI_TC2 && l.mt != 4) { lm_set_error("lm_fcn2: the merged transposed convolution runs four channel tiles per workgroup"); return LM_ERR_ARG; }
         LM_G2_TRY_MT4(1, 1, 1, LM_G2_EPI_TC, 1, 0) LM_G2_TRY_MT4(1, 1, 3, LM_G2_EPI_TC, 1, 0)
@@ -828,7 +828,8 @@ static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor*
     const size_t fixed = (size_t)(((l.nslices + 2) * 16 + 255) & ~255) + (size_t)(l.pdouble ? 2 : 1) * l.npc * nhl * PLS;
     static const int ring_env = [] { const char* e = getenv("LM_FCN2_RING"); return e ? atoi(e) : 0; }();
     int ring = l.ngroups > 2 ? 3 : (l.ngroups > 1 ? 2 : 1);
-    if (ring == 3 && fixed + 3 * (size_t)l.wbuf_bytes > 80 * 1024 && fixed + 2 * (size_t)l.wbuf_bytes <= 80 * 1024) ring = 2;
+    const size_t lds_limit = (size_t)(l.lds_kb ? l.lds_kb : 80) * 1024;     // what the recipe was sized for (80 KB: two workgroups per CU)
+    if (ring == 3 && fixed + 3 * (size_t)l.wbuf_bytes > lds_limit && fixed + 2 * (size_t)l.wbuf_bytes <= lds_limit) ring = 2;
     if (ring == 3 && fixed + 3 * (size_t)l.wbuf_bytes > 160 * 1024) ring = 2;
     if (ring_env == 2 && ring == 3) ring = 2;
     a.wring = ring < 2 ? 2 : ring;

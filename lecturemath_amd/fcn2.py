@@ -53,7 +53,7 @@ def have_instance(kh, kw, terms, mt, epi, nc=1, loader=0):
             return terms in (1, 3, 4) and 1 <= mt <= 4
         if v == (1, 1):
             return terms in (1, 4) and mt in (1, 2)
-        return v == (2, 0) and terms in (1, 3, 4) and 1 <= mt <= 3
+        return v == (2, 0) and terms in (1, 3, 4) and 1 <= mt <= (3 if terms == 1 else 2)
     if (kh, kw) == (1, 1) and epi in (EPI_TC, EPI_TC2):
         return v == (1, 0) and terms in (1, 3) and 1 <= mt <= 4
     if (kh, kw) == (1, 7) and epi == EPI_T:
@@ -144,7 +144,8 @@ def build(w_list, chunks, kh, kw, terms, mt, epi, gsize=None, pdouble=None, lds_
         packed.append(np.stack(parts, axis=3).reshape(nblocks, nslices, mt, nwl, 64, 8))
     wpk = np.ascontiguousarray(np.stack(packed))                    # [parity][block]...
     planes = [v for ch in chunks for pl in ch["planes"] for v in pl]
-    desc = [kh, kw, terms, mt, epi, len(chunks), npc, len(groups), nslices, nc | (loader << 8), 1 if pdouble else 0, wbuf, cout]
+    # flags: bits 0-3 column tiles, bit 8 loader wave, bits 16.. the LDS target in KB (the run-time weight ring stays inside it)
+    desc = [kh, kw, terms, mt, epi, len(chunks), npc, len(groups), nslices, nc | (loader << 8) | ((lds_target // 1024) << 16), 1 if pdouble else 0, wbuf, cout]
     desc += planes + [v for g in groups for v in g] + [v for s_ in slices for v in s_[0]]
     need = lds_bytes(kh, kw, terms, npc, nslices, pdouble, wbuf, len(groups), nc)
     return np.asarray(desc, np.int32), wpk, len(w_list) * nblocks, need
