@@ -285,9 +285,11 @@ int lm_upsample_nearest_u8(const uint8_t* d_in, int in_h, int in_w, int channels
 typedef struct LmFcn2 LmFcn2;
 LmFcn2* lm_fcn2_create(const int32_t* widths18, const int32_t* lo25, int max_h, int max_w);
 void lm_fcn2_destroy(LmFcn2* f);
-/* desc: kh, kw, terms, mt, epilogue, nchunks, planes per chunk, ngroups, nslices, npatterns, double-buffered planes, LDS bytes of
- * a weight buffer, outputs; then planes [nchunks * npc][tensor, octet], weight groups [ngroups][first slice, slices, chunk],
- * slices [nslices][LDS offset, pattern], patterns [npat][4].  HOST pointers. */
+/* desc: kh, kw, operand format (1 = f16, 2 = activations hi + lo, 3 = both split, 4 = weights hi + lo), mt, epilogue, nchunks, planes
+ * per chunk, ngroups, nslices, flags (bits 0-3: column tiles of 16 pixels per wave row group, 1 or 2; bit 8: loader wave; bits 16-23: LDS
+ * target in KB), double-buffered planes, LDS bytes of a weight buffer, outputs; then planes [nchunks * npc][tensor, octet], weight groups
+ * [ngroups][first slice, slices, chunk], slice table [nslices][4] (LDS byte offsets of the four k-groups' (plane, tap) pairs inside the
+ * patch buffer).  HOST pointers.  Fails for a variant the library holds no kernel instance of (lecturemath_amd/fcn2.py: have_instance). */
 int lm_fcn2_set_layer(LmFcn2* f, int layer, const int32_t* desc, int ndesc, const void* h_w, int64_t wbytes, int wblocks,
                       const float* h_bias, int nbias);
 /* same contract as lm_fcn_forward */

@@ -7,7 +7,7 @@
 //
 // Activations in HBM ("planar octets"): a tensor of C channels is C/8 planes of [Hp][Wp] slots of 16 bytes = 8 consecutive channels
 // of one pixel as f16 (the hi parts), followed -- when a consumer runs a split format -- by C/8 planes of the lo parts
-// (lo = f16(x - hi), so hi + lo carries ~22 bits).  Hp x Wp = the image rounded up to whole 16 x 16 tiles plus a zero halo as wide
+// (lo = f16(x - hi), so hi + lo carries ~22 bits).  Hp x Wp = the image rounded up to whole tiles (16 rows, 32 columns) plus a zero halo as wide
 // as the largest padding of any consumer: a convolution's input patch is then a plain rectangle of every plane, no bounds checks.
 // A producer converts ONCE per value in its epilogue (lm_fcn.hip converted fp32 -> f16 hi / lo in every consuming workgroup: 12-24
 // times per value in the deep layers) and every load of the engine is a 16-byte LDS-DMA (global_load_lds_dwordx4).
