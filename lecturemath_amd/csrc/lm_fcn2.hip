@@ -74,6 +74,9 @@ LM_DEV void lm_vmwait(int n)
 #ifndef LM_G2_STAMPS
 #define LM_G2_STAMPS 0
 #endif
+#ifndef LM_G2_CUT           // timing-only diagnostic builds (wrong results): 1 = no weight fetches after the first groups, 2 = no activation, 4 = no epilogue
+#define LM_G2_CUT 0
+#endif
 #if LM_G2_STAMPS && !LM_HIP_EMULATED
 #define LM_G2_NSTAMP 12
 #define LM_G2_STAMP_WAVES (8192 * 4 * 2)
@@ -202,6 +205,9 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 ||
     };
     // returns the number of DMA instructions THIS wave issued (a group is a whole number of 1-KB fragments)
     auto issue_weights = [&](const int4 g4, int buf) -> int {
+#if LM_G2_CUT == 1      // timing-only build: weights fetched for the first groups only (later groups read what is there)
+        if (g4.x > 8) return 0;
+#endif
         const unsigned src = wsrc + (unsigned)g4.w;
         char* const dst = s_w0 + buf * a.wbuf_bytes;
         const int n = g4.y * (MT * NWL);
@@ -354,7 +360,24 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 ||
         }
     }
     if (!computes) return;
+#if LM_G2_CUT == 4      // timing-only build: no epilogue (one value per lane keeps the MFMAs alive)
+    {
+        float sum = 0.0f;
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int n = 0; n < NT; n++) sum += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+        if (sum == 12345.678f) a.tout[threadIdx.x] = sum;
+        return;
+    }
+#endif
 
+#if LM_G2_CUT == 3      // timing-only build: everything of the epilogue but the stores (their values and addresses feed a checksum)
+    unsigned lm_cut_chk = 0;
+#define LM_G2_STORE(T, addr, val) do { T v_ = (val); unsigned w_[sizeof(T) / 4]; __builtin_memcpy(w_, &v_, sizeof(T)); for (unsigned q_ = 0; q_ < sizeof(T) / 4; q_++) lm_cut_chk ^= w_[q_]; lm_cut_chk += (unsigned)(size_t)(addr); } while (0)
+#else
+#define LM_G2_STORE(T, addr, val) (*(T*)(addr) = (val))
+#endif
     // ---------------------------------------------------------------- epilogues
     // D[row = 4 * kg + r][col]: row = channel of the tile, col = pixel `col` of the wave's row r in column tile c
     const int y0 = ty * 16 + wave * 4;
@@ -368,7 +391,7 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 ||
             for (int n = 0; n < 4; n++) {
                 const int y = y0 + n;
                 const lm_f32x4 v = acc[0][c * 4 + n];
-                if (y < a.H) *(float4*)(a.tout + ((long long)y * a.W + x) * a.ts + 4 * kg) = make_float4(v[0], v[1], v[2], v[3]);
+                if (y < a.H) LM_G2_STORE(float4, a.tout + ((long long)y * a.W + x) * a.ts + 4 * kg, make_float4(v[0], v[1], v[2], v[3]));
             }
         }
     } else {
@@ -392,7 +415,11 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 ||
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const float t = acc[2 * q + (j >> 2)][c * 4 + n][j & 3] + bb[j];
+#if LM_G2_CUT == 2      // timing-only build: no activation
+                    v[n][j] = t;
+#else
                     v[n][j] = gelu ? lm_gelu(t) : t;
+#endif
                 }
 #pragma unroll
             for (int n = 0; n < 4; n++) {
@@ -402,8 +429,8 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 ||
 #pragma unroll
                 for (int j = 0; j < 8; j++) { hi[j] = (_Float16)v[n][j]; lo[j] = (_Float16)(v[n][j] - (float)hi[j]); }
                 const long long so = oplane + ((long long)(sc * y + dy + a.halo_out) * a.Wp_out + sc * x + dxq + a.halo_out) * 16;
-                *(lm_h8*)(a.out_hi + so) = hi;
-                if (a.out_lo) *(lm_h8*)(a.out_lo + so) = lo;
+                LM_G2_STORE(lm_h8, a.out_hi + so, hi);
+                if (a.out_lo) LM_G2_STORE(lm_h8, a.out_lo + so, lo);
             }
             if constexpr (EPI == LM_G2_EPI_PO) {
                 if (a.pool_hi) {        // 2x2 / stride 2 max pooling (floor): rows (n, n + 1), columns (col, col ^ 1)
@@ -419,8 +446,8 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 ||
                         const int py = (y0 + n) >> 1, px = x >> 1;
                         if (!(col & 1) && py < (a.H >> 1) && px < (a.W >> 1)) {
                             const long long so = (long long)(ch >> 3) * a.pool_plane + ((long long)(py + a.halo_pool) * a.Wp_pool + px + a.halo_pool) * 16;
-                            *(lm_h8*)(a.pool_hi + so) = ph;
-                            if (a.pool_lo) *(lm_h8*)(a.pool_lo + so) = pl;
+                            LM_G2_STORE(lm_h8, a.pool_hi + so, ph);
+                            if (a.pool_lo) LM_G2_STORE(lm_h8, a.pool_lo + so, pl);
                         }
                     }
                 }
@@ -449,8 +476,8 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 ||
 #pragma unroll
                 for (int j = 0; j < 4; j++) { hi[j] = (_Float16)v[n][j]; lo[j] = (_Float16)(v[n][j] - (float)hi[j]); }
                 const long long so = oplane + ((long long)(sc * y + dy + a.halo_out) * a.Wp_out + sc * x + dx + a.halo_out) * 16;
-                *(lm_h4*)(a.out_hi + so) = hi;
-                if (a.out_lo) *(lm_h4*)(a.out_lo + so) = lo;
+                LM_G2_STORE(lm_h4, a.out_hi + so, hi);
+                if (a.out_lo) LM_G2_STORE(lm_h4, a.out_lo + so, lo);
             }
             if constexpr (EPI == LM_G2_EPI_PO) {
                 if (a.pool_hi) {
@@ -466,8 +493,8 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 ||
                         const int py = (y0 + n) >> 1, px = x >> 1;
                         if (!(col & 1) && py < (a.H >> 1) && px < (a.W >> 1)) {
                             const long long so = (long long)(ch >> 3) * a.pool_plane + (kg & 1) * 8 + ((long long)(py + a.halo_pool) * a.Wp_pool + px + a.halo_pool) * 16;
-                            *(lm_h4*)(a.pool_hi + so) = ph;
-                            if (a.pool_lo) *(lm_h4*)(a.pool_lo + so) = pl;
+                            LM_G2_STORE(lm_h4, a.pool_hi + so, ph);
+                            if (a.pool_lo) LM_G2_STORE(lm_h4, a.pool_lo + so, pl);
                         }
                     }
                 }
@@ -475,6 +502,10 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 ||
         }
     }
     }
+#if LM_G2_CUT == 3
+    if (lm_cut_chk == 0x12345678u) a.tout[threadIdx.x] = 1.0f;
+#endif
+#undef LM_G2_STORE
 #if LM_G2_STAMPS && !LM_HIP_EMULATED
     if (a.stamp && lane == 0) {
         const unsigned long long t_loop = st_mark;

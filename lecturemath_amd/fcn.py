@@ -127,6 +127,9 @@ class FcnEngine:
     # kernel variant per layer, (column tiles per wave, loader wave), measured per layer at 1920x1080 (profiles/r04_variants_*.txt): 16 x 32
     # tiles where the weights are re-fetched per tile at full resolution and the instance keeps two workgroups per CU; the loader wave
     # in the two layers with one workgroup per CU and two channel tiles
+    # {layer: channel tiles per workgroup} where fcn2.pick_mt's rule is not the fastest (profiles/r04_mt_{default,a,b}.txt: conv_down_1 on ONE
+    # tile = 24,480 small workgroups at 114 VGPRs, 139 -> 124-130 us -- it is a 250 MB store; every other layer is fastest on pick_mt's choice)
+    DEFAULT_MT = {L_DOWN: 1}
     DEFAULT_LDS = {}        # {layer: LDS bytes a workgroup may take}; default 80 KB = two workgroups per CU
     DEFAULT_VARIANTS = {L_UPC + 4: (2, 0), L_TEXT: (2, 0), L_PX1: (2, 0), L_PX2: (2, 0), L_MID: (1, 1), L_UPC: (1, 1)}
 
@@ -224,6 +227,10 @@ class FcnEngine:
 
         def LDS(layer, default=f2.LDS_TWO_WORKGROUPS):
             return lds_over.get(layer, default)
+        mt_over = {}
+        if os.environ.get("LM_FCN2_MT"):                                   # experiments: channel tiles per workgroup, "0=1,10=2"
+            mt_over = {int(k): int(v) for k, v in (kv.split("=") for kv in os.environ["LM_FCN2_MT"].split(","))}
+        mt_over = {**self.DEFAULT_MT, **mt_over}
         recipes = {}
         # feature octets per chunk of conv_pixels_2: one, so that the 16 x 32 tile's patch planes of the split format leave room for two
         # workgroups per CU (two octets: 88 KB of LDS, one workgroup, 757 us; one octet: 76 KB, 338 us; 16 x 16 tiles: 364 us)
@@ -235,13 +242,13 @@ class FcnEngine:
         # encoder: layer 1 reads the input pair plane (3 channels, two horizontal taps per slot)
         w, b = conv_bn("conv_down_block_1")
         pairs = [f2.pairplane_pair(0, dy, dx, 0, 3) for dy in range(3) for dx in (0, 2)]
-        recipes[L_DOWN] = (f2.build([w], [{"planes": [(f2.T_X0P, 0)], "pairs": pairs}], 3, 3, T(L_DOWN), f2.pick_mt(d1, tiles(0) // V(L_DOWN)["nc"]), f2.EPI_PO, lds_target=LDS(L_DOWN), **V(L_DOWN)), b)
+        recipes[L_DOWN] = (f2.build([w], [{"planes": [(f2.T_X0P, 0)], "pairs": pairs}], 3, 3, T(L_DOWN), mt_over.get(L_DOWN) or f2.pick_mt(d1, tiles(0) // V(L_DOWN)["nc"]), f2.EPI_PO, lds_target=LDS(L_DOWN), **V(L_DOWN)), b)
         cin = [3] + downs
         for n in range(1, 5):
             w, b = conv_bn("conv_down_block_%d" % (n + 1))
-            recipes[L_DOWN + n] = (f2.conv_layer(w, [(f2.T_POOL0 + n - 1, cin[n] // 8)], T(L_DOWN + n), tiles(n), lds_target=LDS(L_DOWN + n, lds_for(tiles(n), downs[n])), **V(L_DOWN + n)), b)
+            recipes[L_DOWN + n] = (f2.conv_layer(w, [(f2.T_POOL0 + n - 1, cin[n] // 8)], T(L_DOWN + n), tiles(n), mt=mt_over.get(L_DOWN + n), lds_target=LDS(L_DOWN + n, lds_for(tiles(n), downs[n])), **V(L_DOWN + n)), b)
         w, b = conv_bn("mid_block")
-        recipes[L_MID] = (f2.conv_layer(w, [(f2.T_POOL0 + 4, d5 // 8)], T(L_MID), tiles(5), lds_target=LDS(L_MID, lds_for(tiles(5), mid, 2)), **V(L_MID)), b)
+        recipes[L_MID] = (f2.conv_layer(w, [(f2.T_POOL0 + 4, d5 // 8)], T(L_MID), tiles(5), mt=mt_over.get(L_MID), lds_target=LDS(L_MID, lds_for(tiles(5), mid, 2)), **V(L_MID)), b)
         ups = {5: (mid, u5, c5, d5), 4: (c5, u4, c4, d4), 3: (c4, u3, c3, d3), 2: (c3, u2, c2, d2), 1: (c2, u1, c1, d1)}
         for i, lvl in enumerate((5, 4, 3, 2, 1)):
             tin, u, c, skip = ups[lvl]
@@ -252,7 +259,7 @@ class FcnEngine:
             n8 = tin // 8
             co = 8 if n8 % 8 == 0 else (4 if n8 % 4 == 0 else 2)
             chunks = f2.conv_chunks([(src, n8)], 1, 1, co)
-            if u % 32 == 0:
+            if u % 32 == 0 and not mt_over.get(L_UPT + i):
                 # both dx of a 32-channel block in one workgroup: per dy a virtual output axis [block][dx][32 channels]
                 w2 = []
                 for dy in (0, 1):
@@ -261,9 +268,9 @@ class FcnEngine:
                 recipes[L_UPT + i] = (f2.build(w2, chunks, 1, 1, T(L_UPT + i), 4, f2.EPI_TC2), bt)
             else:
                 w4 = [np.ascontiguousarray(wt[:, :, dy, dx].T)[:, :, None, None] for dy in (0, 1) for dx in (0, 1)]
-                recipes[L_UPT + i] = (f2.build(w4, chunks, 1, 1, T(L_UPT + i), f2.pick_mt(u, tiles(lvl)), f2.EPI_TC), bt)
+                recipes[L_UPT + i] = (f2.build(w4, chunks, 1, 1, T(L_UPT + i), mt_over.get(L_UPT + i) or f2.pick_mt(u, tiles(lvl)), f2.EPI_TC), bt)
             w, b = conv_bn("conv_up_block_%d" % lvl)                                      # input = cat(up, skip_pre)
-            recipes[L_UPC + i] = (f2.conv_layer(w, [(f2.T_UPT0 + i, u // 8), (f2.T_PRE0 + lvl - 1, skip // 8)], T(L_UPC + i), tiles(lvl - 1), lds_target=LDS(L_UPC + i, lds_for(tiles(lvl - 1), c, 2 if i == 0 else 4)), **V(L_UPC + i)), b)
+            recipes[L_UPC + i] = (f2.conv_layer(w, [(f2.T_UPT0 + i, u // 8), (f2.T_PRE0 + lvl - 1, skip // 8)], T(L_UPC + i), tiles(lvl - 1), mt=mt_over.get(L_UPC + i), lds_target=LDS(L_UPC + i, lds_for(tiles(lvl - 1), c, 2 if i == 0 else 4)), **V(L_UPC + i)), b)
         # heads
         wt, bt = conv_bn("conv_text_mask_out")
         wr, br = conv_bn("conv_reconstruct")
