@@ -88,9 +88,33 @@ __device__ unsigned long long lm_g2_stamp_buf[LM_G2_STAMP_WAVES * LM_G2_NSTAMP];
 #define LM_STAMP_REAL() 0ull
 #endif
 
+// nn.GELU (erf form) as lm_gelu (lm_fcn.hip: erfc by Abramowitz & Stegun 7.1.26, |error| <= 3.3e-7), arranged without fmaxf / fabsf calls:
+// gelu(x) = (x + |x| (1 - q)) / 2 with q = erfc(|x| / sqrt 2): for x >= 0 that is x - x q / 2, for x < 0 it is x q / 2.  (fmaxf compiles to
+// two v_max_f32 per value -- one only canonicalises a NaN; with 32-128 values per lane the epilogues are VALU bound.)
+LM_DEV float lm_gelu_fast(float x)
+{
+    const float ax = __builtin_fabsf(x), z = ax * 0.70710678118654752440f;
+#if LM_HIP_EMULATED
+    const float t = 1.0f / fmaf(0.3275911f, z, 1.0f);
+    const float e = exp2f(-(z * z) * 1.4426950408889634f);
+#else
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(-(z * z) * 1.4426950408889634f);
+#endif
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    return 0.5f * fmaf(ax, 1.0f - p * t * e, x);
+}
+
 #define LM_G2_EPI_PO 0      // planar-octet output (+ optional lo planes, + optional 2x2 max-pooled copy), GELU or none
 #define LM_G2_EPI_T 1       // fp32 [pixel][TS] rows of the head row convolutions (lm_k_vsum2_*), no activation
 #define LM_G2_EPI_TC 2      // transposed 2x2 / stride 2, one (dy, dx) parity per workgroup: output pixel (2y + dy, 2x + dx), planar octets
+#define LM_G2_EPI_V 4       // head row convolution + the vertical sum of its rows in ONE kernel (kernel template EPI_V, LmG2Args::vmode: 1 = text mask +
+                            // reconstruction + diff pair plane, 2 = output logit): tiles of 16 computed rows give 10 finished rows; the fp32
+                            // row buffer [pixel][16] (133 + 66 MB written and read back per 1080p frame) stays in LDS
+#define LM_G2_V_ROWS 10
 #define LM_G2_EPI_TC2 3     // the same with BOTH dx of a 32-channel block in one workgroup (tile pair 0 = dx 0, pair 1 = dx 1): a lane writes the
                             // two neighbouring output slots (32 contiguous bytes) instead of 16 bytes at a 32-byte stride; kernel template EPI_TC
 
@@ -120,7 +144,15 @@ struct LmG2Args {
     char* pool_hi; char* pool_lo; long long pool_plane; int Wp_pool, halo_pool;     // EPI_PO: 2x2 max-pooled copy, null when absent
     // EPI_T
     float* tout; int ts, tn;        // [pixel][ts] floats, the first tn of the 16 rows are stored
+    int tile_rows;                  // image rows from one tile row to the next: 16, LM_G2_V_ROWS for EPI_V
+    // EPI_V
+    int vmode;
+    const float* vbias;             // vmode 1: [0] text, [1..3] reconstruction; vmode 2: [0] the output logit
+    const char* x0_hi; const char* x0_lo; char* dp_hi; char* dp_lo; int Wp_v, halo_v;      // the network input and the diff, pair planes
+    float* v_text; float* v_rec4; float* v_out;
 };
+
+LM_DEV void lm_pair_store(char* hi_plane, char* lo_plane, int Wp, int halo, int y, int x, float v0, float v1, float v2);
 
 // one tile of 16 rows x 16 * NC columns x MT channel tiles; see the header comment.
 //   NC      column tiles of 16 pixels per wave row group: the wave's 4 rows x NC x 16 pixels share every weight fragment (2 = a 16 x 32
@@ -188,7 +220,7 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 ||
         gval[j] = slot < NSLOT;
     }
     // byte offsets below 4 GB: the arena's size is checked by lm_fcn2_create, a layer's packed weights by lm_fcn2_set_layer
-    const unsigned tile_org = (unsigned)(((long long)(ty * 16) * a.Wp_in + tx * TW + a.org_in) * 16);
+    const unsigned tile_org = (unsigned)(((long long)(ty * a.tile_rows) * a.Wp_in + tx * TW + a.org_in) * 16);
     const unsigned wsrc = (unsigned)(((long long)par * a.cblocks + cby) * a.wblock_bytes);
     const LmRsrc r_arena = LM_MAKE_RSRC(a.arena), r_w = LM_MAKE_RSRC(a.wpk);
 
@@ -372,6 +404,52 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 ||
     }
 #endif
 
+    if constexpr (EPI == LM_G2_EPI_V) {
+        // The wave's rows of the row convolution go to LDS (the loop's last barrier has freed the patch and weight buffers), then the
+        // workgroup's threads finish LM_G2_V_ROWS x TW pixels: row oy of the result sums computed rows oy .. oy + 6 (text, output logit:
+        // kernel row kh from computed row oy + kh) or oy + 2 .. oy + 4 (reconstruction, 3 x 3), exactly as lm_k_vsum2_text_rec / lm_k_vsum
+        // do from the global row buffer (FCN_lecturenet.py:366-379, 395-403).  Computed rows outside the image come from zero planes.
+        static_assert(MT == 1 && !LOADER, "the fused head runs one channel tile on four waves");
+        float* const s_T = (float*)smem;                            // [16 rows][TW][16]
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                const lm_f32x4 v = acc[0][c * 4 + n];
+                *(float4*)(s_T + (((wave * 4 + n) * TW + c * 16 + col) * 16 + 4 * kg)) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        lm_lds_barrier();
+        const int yb = ty * LM_G2_V_ROWS, xb = tx * TW;
+        for (int p = (int)threadIdx.x; p < LM_G2_V_ROWS * TW; p += NTHR) {
+            const int oy = p / TW, px = p - oy * TW, y = yb + oy, x = xb + px;
+            if (y >= a.H || x >= a.W) continue;
+            const long long pi = (long long)y * a.W + x;
+            if (a.vmode == 2) {
+                float v = 0.f;
+#pragma unroll
+                for (int kh = 0; kh < 7; kh++) v += s_T[((oy + kh) * TW + px) * 16 + kh];
+                a.v_out[pi] = v + a.vbias[0];
+                continue;
+            }
+            float t = a.vbias[0], r0 = a.vbias[1], r1 = a.vbias[2], r2 = a.vbias[3];
+#pragma unroll
+            for (int kh = 0; kh < 7; kh++) t += s_T[((oy + kh) * TW + px) * 16 + kh];
+#pragma unroll
+            for (int kh = 0; kh < 3; kh++) {
+                const float* q = s_T + ((oy + 2 + kh) * TW + px) * 16 + 7 + kh * 3;
+                r0 += q[0]; r1 += q[1]; r2 += q[2];
+            }
+            r0 = tanhf(r0); r1 = tanhf(r1); r2 = tanhf(r2);
+            const float m = 1.0f / (1.0f + expf(-t));
+            const long long so = ((long long)(y + a.halo_v) * a.Wp_v + x + a.halo_v) * 16;
+            const lm_h4 xh = *(const lm_h4*)(a.x0_hi + so), xl4 = *(const lm_h4*)(a.x0_lo + so);
+            const float x0 = (float)xh[0] + (float)xl4[0], x1 = (float)xh[1] + (float)xl4[1], x2 = (float)xh[2] + (float)xl4[2];
+            a.v_text[pi] = t;
+            if (a.v_rec4) *(float4*)(a.v_rec4 + pi * 4) = make_float4(r0, r1, r2, 0.f);
+            lm_pair_store(a.dp_hi, a.dp_lo, a.Wp_v, a.halo_v, y, x, (x0 - r0) * m, (x1 - r1) * m, (x2 - r2) * m);
+        }
+        return;
+    }
 #if LM_G2_CUT == 3      // timing-only build: everything of the epilogue but the stores (their values and addresses feed a checksum)
     unsigned lm_cut_chk = 0;
 #define LM_G2_STORE(T, addr, val) do { T v_ = (val); unsigned w_[sizeof(T) / 4]; __builtin_memcpy(w_, &v_, sizeof(T)); for (unsigned q_ = 0; q_ < sizeof(T) / 4; q_++) lm_cut_chk ^= w_[q_]; lm_cut_chk += (unsigned)(size_t)(addr); } while (0)
@@ -395,11 +473,18 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 ||
             }
         }
     } else {
+        // PO / TC epilogues: bias, GELU (every planar-output layer of the network has it; lm_f2_run refuses anything else), f16 hi (+ lo),
+        // whole-octet stores.  Kept lean on the VALU -- timing-only builds (profiles/r04_cuts_*.txt) put the epilogues at 27 % of the frame,
+        // 0.26 ms of it the stores themselves and the rest vector instructions: one base address per (column tile, channel pair) and a
+        // scalar row stride, no per-value select on the activation, no fmaxf (two v_max_f32 per value for its NaN canonicalisation).
         const bool merged = (EPI == LM_G2_EPI_TC) && a.tc_merged;
         const int cb = merged ? cby * 32 : cby * (MT * 16);                  // first channel of the workgroup
-        const bool gelu = a.act == LM_ACT_GELU;
         const int dy = merged ? par : (par >> 1), dx = par & 1;
-        const int sc = (EPI == LM_G2_EPI_TC) ? 2 : 1;
+        constexpr int sc = (EPI == LM_G2_EPI_TC) ? 2 : 1;
+        const bool has_lo = a.out_lo != nullptr;
+        const long long lo_delta = has_lo ? (long long)(a.out_lo - a.out_hi) : 0;
+        const long long rstride = (long long)sc * a.Wp_out * 16;             // bytes between the wave's output rows
+        const bool xin = x < a.W;
         // pairs of tiles: the host packs tile 2q with the channels 32q + 8kg + (0..3) in rows 4kg + (0..3) and tile 2q + 1 with
         // 32q + 8kg + 4 + (0..3), so a lane holds one whole octet of its pixel: one 16-byte store per part
 #pragma unroll
@@ -408,29 +493,26 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 ||
             const int dxq = merged ? q : dx;
             const float4 b0 = *(const float4*)(t_bias + ch), b1 = *(const float4*)(t_bias + ch + 4);
             const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            const long long oplane = (long long)(ch >> 3) * a.out_plane;
+            char* const obase = a.out_hi + (long long)(ch >> 3) * a.out_plane + ((long long)(sc * y0 + dy + a.halo_out) * a.Wp_out + sc * x + dxq + a.halo_out) * 16;
             float v[4][8];
 #pragma unroll
             for (int n = 0; n < 4; n++)
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float t = acc[2 * q + (j >> 2)][c * 4 + n][j & 3] + bb[j];
-#if LM_G2_CUT == 2      // timing-only build: no activation
-                    v[n][j] = t;
-#else
-                    v[n][j] = gelu ? lm_gelu(t) : t;
-#endif
-                }
+                for (int j = 0; j < 8; j++) v[n][j] = lm_gelu_fast(acc[2 * q + (j >> 2)][c * 4 + n][j & 3] + bb[j]);
 #pragma unroll
             for (int n = 0; n < 4; n++) {
-                const int y = y0 + n;
-                if (y >= a.H || x >= a.W) continue;
-                lm_h8 hi, lo;
+                if (!xin || y0 + n >= a.H) continue;
+                lm_h8 hi;
 #pragma unroll
-                for (int j = 0; j < 8; j++) { hi[j] = (_Float16)v[n][j]; lo[j] = (_Float16)(v[n][j] - (float)hi[j]); }
-                const long long so = oplane + ((long long)(sc * y + dy + a.halo_out) * a.Wp_out + sc * x + dxq + a.halo_out) * 16;
-                LM_G2_STORE(lm_h8, a.out_hi + so, hi);
-                if (a.out_lo) LM_G2_STORE(lm_h8, a.out_lo + so, lo);
+                for (int j = 0; j < 8; j++) hi[j] = (_Float16)v[n][j];
+                char* const o = obase + n * rstride;
+                LM_G2_STORE(lm_h8, o, hi);
+                if (has_lo) {
+                    lm_h8 lo;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) lo[j] = (_Float16)(v[n][j] - (float)hi[j]);
+                    LM_G2_STORE(lm_h8, o + lo_delta, lo);
+                }
             }
             if constexpr (EPI == LM_G2_EPI_PO) {
                 if (a.pool_hi) {        // 2x2 / stride 2 max pooling (floor): rows (n, n + 1), columns (col, col ^ 1)
@@ -439,8 +521,9 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 ||
                         lm_h8 ph, pl;
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
-                            const float m2 = fmaxf(v[n][j], v[n + 1][j]);
-                            const float m4 = fmaxf(m2, __shfl_xor(m2, 1));
+                            const float m2 = v[n][j] > v[n + 1][j] ? v[n][j] : v[n + 1][j];
+                            const float m3 = __shfl_xor(m2, 1);
+                            const float m4 = m2 > m3 ? m2 : m3;
                             ph[j] = (_Float16)m4; pl[j] = (_Float16)(m4 - (float)ph[j]);
                         }
                         const int py = (y0 + n) >> 1, px = x >> 1;
@@ -459,25 +542,26 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 ||
             const int ch = cb + 16 * m + 4 * kg;
             const float4 b0 = *(const float4*)(t_bias + ch);
             const float bb[4] = {b0.x, b0.y, b0.z, b0.w};
-            const long long oplane = (long long)(ch >> 3) * a.out_plane + (kg & 1) * 8;
+            char* const obase = a.out_hi + (long long)(ch >> 3) * a.out_plane + (kg & 1) * 8 + ((long long)(sc * y0 + dy + a.halo_out) * a.Wp_out + sc * x + dx + a.halo_out) * 16;
             float v[4][4];
 #pragma unroll
             for (int n = 0; n < 4; n++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const float t = acc[m][c * 4 + n][j] + bb[j];
-                    v[n][j] = gelu ? lm_gelu(t) : t;
-                }
+                for (int j = 0; j < 4; j++) v[n][j] = lm_gelu_fast(acc[m][c * 4 + n][j] + bb[j]);
 #pragma unroll
             for (int n = 0; n < 4; n++) {
-                const int y = y0 + n;
-                if (y >= a.H || x >= a.W) continue;
-                lm_h4 hi, lo;
+                if (!xin || y0 + n >= a.H) continue;
+                lm_h4 hi;
 #pragma unroll
-                for (int j = 0; j < 4; j++) { hi[j] = (_Float16)v[n][j]; lo[j] = (_Float16)(v[n][j] - (float)hi[j]); }
-                const long long so = oplane + ((long long)(sc * y + dy + a.halo_out) * a.Wp_out + sc * x + dx + a.halo_out) * 16;
-                LM_G2_STORE(lm_h4, a.out_hi + so, hi);
-                if (a.out_lo) LM_G2_STORE(lm_h4, a.out_lo + so, lo);
+                for (int j = 0; j < 4; j++) hi[j] = (_Float16)v[n][j];
+                char* const o = obase + n * rstride;
+                LM_G2_STORE(lm_h4, o, hi);
+                if (has_lo) {
+                    lm_h4 lo;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) lo[j] = (_Float16)(v[n][j] - (float)hi[j]);
+                    LM_G2_STORE(lm_h4, o + lo_delta, lo);
+                }
             }
             if constexpr (EPI == LM_G2_EPI_PO) {
                 if (a.pool_hi) {
@@ -486,8 +570,9 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 ||
                         lm_h4 ph, pl;
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
-                            const float m2 = fmaxf(v[n][j], v[n + 1][j]);
-                            const float m4 = fmaxf(m2, __shfl_xor(m2, 1));
+                            const float m2 = v[n][j] > v[n + 1][j] ? v[n][j] : v[n + 1][j];
+                            const float m3 = __shfl_xor(m2, 1);
+                            const float m4 = m2 > m3 ? m2 : m3;
                             ph[j] = (_Float16)m4; pl[j] = (_Float16)(m4 - (float)ph[j]);
                         }
                         const int py = (y0 + n) >> 1, px = x >> 1;
@@ -659,7 +744,8 @@ static void lm_f2_geometry(LmFcn2* f, int h, int w)
 {
     for (auto& t : f->t) {
         t.H = h >> t.level; t.W = w >> t.level; t.halo = lm_f2_halo(t.level);
-        t.Hp = ((t.H + 15) & ~15) + 2 * t.halo; t.Wp = ((t.W + 31) & ~31) + 2 * t.halo;     // whole 16 x 32 tiles
+        t.Hp = ((t.H + 15) & ~15) + 2 * t.halo + (t.level == 0 ? 16 : 0);      // whole tiles; full resolution: + the overhang of the fused heads' 10-row tile pitch
+        t.Wp = ((t.W + 31) & ~31) + 2 * t.halo;
         t.plane = (long long)t.Hp * t.Wp * 16;
     }
 }
@@ -797,7 +883,8 @@ template <int KH, int KW, int TERMS, int MT, int EPI, int NC, int LOADER> static
 // The instances that exist (each is a kernel of its own in the code object; lecturemath_amd/fcn2.py only asks for these):
 //   variant 0 = 16 x 16 tile, four waves;  1 = 16 x 16 tile + loader wave;  2 = 16 x 32 tile, four waves
 //   3 x 3 convolutions: formats 1 / 3 / 4, 1..4 channel tiles (loader: <= 2 tiles, formats 1 / 4; wide: <= 3 tiles on f16, <= 2 on a split format)
-//   7 x 7 convolutions: formats 1..4, 1..2 channel tiles, all variants;  1 x 7 head rows: formats 1..4, variants 0 and 2
+//   7 x 7 convolutions: formats 1..4, 1..2 channel tiles, all variants;  1 x 7 head rows: formats 1..4, variants 0 and 2; fused with their
+//   vertical sums (EPI_V): formats 3 / 4, variants 0 and 2
 //   transposed convolutions: formats 1 / 3, 1..4 channel tiles, variant 0
 #define LM_G2_TRY(KH, KW, T, M, E, N, L) \
     if (l.terms == T && l.mt == M && l.nc == N && l.loader == L) return lm_g2_launch_t<KH, KW, T, M, E, N, L>(a, grid, smem, st);
@@ -818,6 +905,8 @@ static int lm_g2_launch(const LmF2Layer& l, const LmG2Args& a, dim3 grid, size_t
     } else if (shape == 17 && l.epi == LM_G2_EPI_T) {
         LM_G2_TRY(1, 7, 1, 1, LM_G2_EPI_T, 1, 0) LM_G2_TRY(1, 7, 2, 1, LM_G2_EPI_T, 1, 0) LM_G2_TRY(1, 7, 3, 1, LM_G2_EPI_T, 1, 0) LM_G2_TRY(1, 7, 4, 1, LM_G2_EPI_T, 1, 0)
         LM_G2_TRY(1, 7, 1, 1, LM_G2_EPI_T, 2, 0) LM_G2_TRY(1, 7, 2, 1, LM_G2_EPI_T, 2, 0) LM_G2_TRY(1, 7, 3, 1, LM_G2_EPI_T, 2, 0) LM_G2_TRY(1, 7, 4, 1, LM_G2_EPI_T, 2, 0)
+    } else if (shape == 17 && l.epi == LM_G2_EPI_V) {
+        LM_G2_TRY(1, 7, 3, 1, LM_G2_EPI_V, 1, 0) LM_G2_TRY(1, 7, 4, 1, LM_G2_EPI_V, 1, 0) LM_G2_TRY(1, 7, 3, 1, LM_G2_EPI_V, 2, 0) LM_G2_TRY(1, 7, 4, 1, LM_G2_EPI_V, 2, 0)
     } else if (shape == 77 && l.epi == LM_G2_EPI_PO) {
 #define LM_G2_TRY77(N, L) \
         LM_G2_TRY(7, 7, 1, 1, LM_G2_EPI_PO, N, L) LM_G2_TRY(7, 7, 2, 1, LM_G2_EPI_PO, N, L) LM_G2_TRY(7, 7, 3, 1, LM_G2_EPI_PO, N, L) LM_G2_TRY(7, 7, 4, 1, LM_G2_EPI_PO, N, L) \
@@ -832,7 +921,9 @@ static int lm_g2_launch(const LmF2Layer& l, const LmG2Args& a, dim3 grid, size_t
 #undef LM_G2_TRY_MT4
 
 // launches layer `li`: input planes per the recipe; `out` (EPI_PO / EPI_TC) with an optional pooled copy, or the T rows (EPI_T)
-static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor* pool, int act, float* tout, int ts, int tn, hipStream_t st)
+// EPI_V layers: vmode 1 (text mask + reconstruction + diff; rec4 may be null) or 2 (output logit)
+static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor* pool, int act, float* tout, int ts, int tn, hipStream_t st, int vmode = 0,
+                     float* rec4 = nullptr)
 {
     const LmF2Layer& l = f->layer[li];
     if (!l.set) { lm_set_error("lm_fcn2_forward: layer %d has no weights (call lm_fcn2_set_layer)", li); return LM_ERR_STATE; }
@@ -846,6 +937,7 @@ static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor*
     a.H = in.H; a.W = in.W;         // a convolution's output grid is its input grid; EPI_TC bounds its stores by the input grid
     a.tiles_x = (in.W + 16 * l.nc - 1) / (16 * l.nc);
     a.act = act;
+    if ((l.epi == LM_G2_EPI_PO || l.epi == LM_G2_EPI_TC || l.epi == LM_G2_EPI_TC2) && act != LM_ACT_GELU) { lm_set_error("lm_fcn2: the planar-output epilogues apply GELU"); return LM_ERR_ARG; }
     if (out) {
         a.out_hi = f->arena + out->off; a.out_lo = out->lo ? a.out_hi + (long long)out->c8 * out->plane : nullptr;
         a.out_plane = out->plane; a.Wp_out = out->Wp; a.halo_out = out->halo;
@@ -853,6 +945,19 @@ static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor*
     }
     if (pool) { a.pool_hi = f->arena + pool->off; a.pool_lo = pool->lo ? a.pool_hi + (long long)pool->c8 * pool->plane : nullptr; a.pool_plane = pool->plane; a.Wp_pool = pool->Wp; a.halo_pool = pool->halo; }
     a.tout = tout; a.ts = ts; a.tn = tn;
+    a.tile_rows = 16;
+    if (l.epi == LM_G2_EPI_V) {
+        // 16 computed rows per tile starting 3 above the tile's first finished row: plane row (halo - 3) + ty * 10
+        if (vmode != 1 && vmode != 2) { lm_set_error("lm_fcn2_forward: layer %d is a fused head", li); return LM_ERR_STATE; }
+        const LmF2Tensor &x0 = f->t[LM_F2_X0P], &dp = f->t[LM_F2_DP];
+        a.tile_rows = LM_G2_V_ROWS;
+        a.org_in = (in.halo - 3) * in.Wp + in.halo - (l.kw - 1) / 2;
+        a.vmode = vmode; a.vbias = l.d_bias + 16;
+        a.x0_hi = f->arena + x0.off; a.x0_lo = a.x0_hi + x0.plane; a.dp_hi = f->arena + dp.off; a.dp_lo = a.dp_hi + dp.plane;
+        a.Wp_v = dp.Wp; a.halo_v = dp.halo;
+        a.v_text = f->text; a.v_rec4 = rec4; a.v_out = f->outl;
+        if (in.halo < 3 || x0.Wp != dp.Wp || x0.halo != dp.halo) { lm_set_error("lm_fcn2_forward: pair planes of different geometry"); return LM_ERR_STATE; }
+    }
     const int nhl = (l.terms == 2 || l.terms == 3) ? 2 : 1;
     const int PW = 16 * l.nc + l.kw - 1, PH = 16 + l.kh - 1, PLS = (PH * PW * 16 + 255) & ~255;
     // weight ring: three buffers when they fit beside two resident workgroups (or the layer cannot have two anyway), else two
@@ -864,9 +969,10 @@ static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor*
     if (ring == 3 && fixed + 3 * (size_t)l.wbuf_bytes > 160 * 1024) ring = 2;
     if (ring_env == 2 && ring == 3) ring = 2;
     a.wring = ring < 2 ? 2 : ring;
-    const size_t smem = fixed + (size_t)ring * l.wbuf_bytes;
+    size_t smem = fixed + (size_t)ring * l.wbuf_bytes;
+    if (l.epi == LM_G2_EPI_V && smem < (size_t)16 * 16 * l.nc * 16 * 4) smem = (size_t)16 * 16 * l.nc * 16 * 4;        // the computed rows, [16][TW][16] floats
     if (smem > 160 * 1024) { lm_set_error("lm_fcn2_forward: layer %d needs %zu bytes of LDS", li, smem); return LM_ERR_STATE; }
-    a.tiles_y = (in.H + 15) / 16;
+    a.tiles_y = (in.H + a.tile_rows - 1) / a.tile_rows;
     const int tiles = a.tiles_x * a.tiles_y;
     const int blocks = l.cout / (16 * l.mt);
     if (blocks * 16 * l.mt != l.cout) { lm_set_error("lm_fcn2_forward: layer %d: %d outputs are not whole blocks of %d tiles", li, l.cout, l.mt); return LM_ERR_STATE; }
@@ -938,8 +1044,9 @@ extern "C" int lm_fcn2_forward(LmFcn2* f, const uint8_t* d_rgb, int h, int w, fl
         if ((rc = lm_f2_run(f, 11 + n, n < 4 ? &T[LM_F2_CU0 + n] : &T[LM_F2_XUP], nullptr, LM_ACT_GELU, nullptr, 0, 0, st))) return rc;
     }
     // ---- heads
-    if ((rc = lm_f2_run(f, 16, nullptr, nullptr, LM_ACT_NONE, f->tbuf, 16, 16, st))) return rc;
-    {
+    const bool fused16 = f->layer[16].epi == LM_G2_EPI_V, fused20 = f->layer[20].epi == LM_G2_EPI_V;
+    if ((rc = lm_f2_run(f, 16, nullptr, nullptr, LM_ACT_NONE, f->tbuf, 16, 16, st, fused16 ? 1 : 0, d_rec ? f->rec4 : nullptr))) return rc;
+    if (!fused16) {
         const LmF2Tensor &x0 = T[LM_F2_X0P], &dp = T[LM_F2_DP];
         const int tiles = ((w + 31) / 32) * ((h + 15) / 16);
         hipLaunchKernelGGL(lm_k_vsum2_text_rec, dim3(tiles), dim3(256), 0, st, f->tbuf, h, w, f->layer[16].d_bias + 16, f->arena + x0.off,
@@ -947,8 +1054,8 @@ extern "C" int lm_fcn2_forward(LmFcn2* f, const uint8_t* d_rgb, int h, int w, fl
     }
     if ((rc = lm_f2_run(f, 18, &T[LM_F2_P1], nullptr, LM_ACT_GELU, nullptr, 0, 0, st))) return rc;
     if ((rc = lm_f2_run(f, 19, &T[LM_F2_P2], nullptr, LM_ACT_GELU, nullptr, 0, 0, st))) return rc;
-    if ((rc = lm_f2_run(f, 20, nullptr, nullptr, LM_ACT_NONE, f->tbuf, 8, 8, st))) return rc;
-    {
+    if ((rc = lm_f2_run(f, 20, nullptr, nullptr, LM_ACT_NONE, f->tbuf, 8, 8, st, fused20 ? 2 : 0))) return rc;
+    if (!fused20) {
         const int tiles = ((w + 31) / 32) * ((h + 15) / 16);
         hipLaunchKernelGGL((lm_k_vsum<7, 1, 8, false>), dim3(tiles), dim3(256), 0, st, f->tbuf, h, w, f->layer[20].d_bias + 16, LM_ACT_NONE, f->outl, 1,
                            nullptr, nullptr, nullptr);

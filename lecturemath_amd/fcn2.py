@@ -10,7 +10,7 @@ fetched as weight GROUPS.  A pair plane (network input, diff) holds {c0 c1 c2 0 
 """
 import numpy as np
 
-EPI_PO, EPI_T, EPI_TC, EPI_TC2 = 0, 1, 2, 3
+EPI_PO, EPI_T, EPI_TC, EPI_TC2, EPI_V = 0, 1, 2, 3, 4      # EPI_V: a head's row convolution fused with its vertical sum
 T_X0P, T_PRE0, T_POOL0, T_MID, T_UPT0, T_CU0, T_XUP, T_DP, T_P1, T_P2, N_TENSORS = 0, 1, 6, 11, 12, 17, 21, 22, 23, 24, 25
 LDS_TWO_WORKGROUPS = 80 * 1024        # a workgroup's LDS for two of them to share a CU's 160 KB
 
@@ -40,7 +40,7 @@ def pairplane_pair(plane, dy, dx, cbase, kw_total):
 
 def row_channel(mt, m, r, epi):
     """channel (relative to the workgroup's first) held by row r of channel tile m -- lm_k_g2's epilogues"""
-    if epi != EPI_T and m < 2 * (mt // 2):
+    if epi not in (EPI_T, EPI_V) and m < 2 * (mt // 2):
         return 32 * (m // 2) + 8 * (r >> 2) + 4 * (m & 1) + (r & 3)
     return 16 * m + r
 
@@ -58,6 +58,8 @@ def have_instance(kh, kw, terms, mt, epi, nc=1, loader=0):
         return v == (1, 0) and terms in (1, 3) and 1 <= mt <= 4
     if (kh, kw) == (1, 7) and epi == EPI_T:
         return v in ((1, 0), (2, 0)) and 1 <= terms <= 4 and mt == 1
+    if (kh, kw) == (1, 7) and epi == EPI_V:
+        return v in ((1, 0), (2, 0)) and terms in (3, 4) and mt == 1
     if (kh, kw) == (7, 7) and epi == EPI_PO:
         return v in ((1, 0), (1, 1), (2, 0)) and 1 <= terms <= 4 and mt in (1, 2)
     return False
@@ -77,6 +79,8 @@ def build(w_list, chunks, kh, kw, terms, mt, epi, gsize=None, pdouble=None, lds_
     """w_list: one [cout][cin][KH][KW] float32 array (or four, one per (dy, dx) of a transposed convolution).
     chunks: [{"planes": [(tensor, octet), ...], "pairs": [pair, ...]}], every chunk with the same number of planes.
     Returns (desc int32 array for lm_fcn2_set_layer, packed weights as bytes array, wblocks)."""
+    if epi == EPI_V and not have_instance(kh, kw, terms, mt, epi, nc, loader):       # no fused instance for this format: rows + vertical-sum kernel
+        epi = EPI_T
     if not have_instance(kh, kw, terms, mt, epi, nc, loader):       # a variant the library does not hold: the plain one
         nc, loader = 1, 0
     pw, ph, pls, nhl = geom(kh, kw, terms, nc)
