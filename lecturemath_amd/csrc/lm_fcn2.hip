@@ -163,7 +163,7 @@ LM_DEV void lm_pair_store(char* hi_plane, char* lo_plane, int Wp, int halo, int 
 //           the deep layers and 15-25 % at full resolution, all of it in front of the MFMAs of the same wave.  The fifth wave costs
 //           registers: with two workgroups per CU one SIMD hosts three waves (<= 168 VGPRs), so the widest instances keep LOADER = 0.
 template <int KH, int KW, int TERMS, int MT, int EPI, int NC, int LOADER>
-__global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 || (MT >= 3 && TERMS != 1)) ? 2 : 3) : 2)
+__global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? (((TERMS != 1 && MT * NC >= 4) || (TERMS == 3 && MT >= 3)) ? 2 : 3) : 2)
     lm_k_g2(const LmG2Args a, const long long* __restrict__ t_psrc, const int4* __restrict__ t_groups, const int4* __restrict__ t_t4,
             const float* __restrict__ t_bias)
 {
@@ -352,13 +352,13 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? ((MT * NC >= 4 ||
                 LM_SCHED_BARRIER();
                 mma(f1);
             }
-            if (sl + 1 < ns) {
-                load(o1, sl + 1, f1);
-                LM_SCHED_BARRIER();
-                mma(f0);
-                mma(f1);
-            } else
-                mma(f0);
+            // one or two slices are left.  (An if / else with the MFMAs in both arms made the compiler accumulate into fresh registers in
+            // either arm and copy all accumulators back at the merge: 32 v_mov_b64 per group at two channel tiles on 16 x 32 tiles.)
+            const bool two = sl + 1 < ns;
+            if (two) load(o1, sl + 1, f1);
+            LM_SCHED_BARRIER();
+            mma(f0);
+            if (two) mma(f1);
         }
 #if LM_G2_STAMPS && !LM_HIP_EMULATED
         { const unsigned long long t = LM_STAMP_NOW(); st_compute += t - st_mark; st_mark = t; }
@@ -882,7 +882,7 @@ template <int KH, int KW, int TERMS, int MT, int EPI, int NC, int LOADER> static
 
 // The instances that exist (each is a kernel of its own in the code object; lecturemath_amd/fcn2.py only asks for these):
 //   variant 0 = 16 x 16 tile, four waves;  1 = 16 x 16 tile + loader wave;  2 = 16 x 32 tile, four waves
-//   3 x 3 convolutions: formats 1 / 3 / 4, 1..4 channel tiles (loader: <= 2 tiles, formats 1 / 4; wide: <= 3 tiles on f16, <= 2 on a split format)
+//   3 x 3 convolutions: formats 1 / 3 / 4, 1..4 channel tiles (loader: format 1, format 4 with <= 2 tiles; wide: <= 3 tiles on f16, <= 2 on a split format)
 //   7 x 7 convolutions: formats 1..4, 1..2 channel tiles, all variants;  1 x 7 head rows: formats 1..4, variants 0 and 2; fused with their
 //   vertical sums (EPI_V): formats 3 / 4, variants 0 and 2
 //   transposed convolutions: formats 1 / 3, 1..4 channel tiles, variant 0
@@ -895,7 +895,7 @@ static int lm_g2_launch(const LmF2Layer& l, const LmG2Args& a, dim3 grid, size_t
     if (l.terms < 1 || l.terms > 4) { lm_set_error("lm_fcn2: operand formats are 1 (f16), 2 (activations split), 3 (both split) or 4 (weights split)"); return LM_ERR_ARG; }
     if (shape == 33 && l.epi == LM_G2_EPI_PO) {
         LM_G2_TRY_MT4(3, 3, 1, LM_G2_EPI_PO, 1, 0) LM_G2_TRY_MT4(3, 3, 3, LM_G2_EPI_PO, 1, 0) LM_G2_TRY_MT4(3, 3, 4, LM_G2_EPI_PO, 1, 0)
-        LM_G2_TRY(3, 3, 1, 1, LM_G2_EPI_PO, 1, 1) LM_G2_TRY(3, 3, 1, 2, LM_G2_EPI_PO, 1, 1) LM_G2_TRY(3, 3, 4, 1, LM_G2_EPI_PO, 1, 1) LM_G2_TRY(3, 3, 4, 2, LM_G2_EPI_PO, 1, 1)
+        LM_G2_TRY_MT4(3, 3, 1, LM_G2_EPI_PO, 1, 1) LM_G2_TRY(3, 3, 4, 1, LM_G2_EPI_PO, 1, 1) LM_G2_TRY(3, 3, 4, 2, LM_G2_EPI_PO, 1, 1)
         LM_G2_TRY(3, 3, 1, 1, LM_G2_EPI_PO, 2, 0) LM_G2_TRY(3, 3, 1, 2, LM_G2_EPI_PO, 2, 0) LM_G2_TRY(3, 3, 1, 3, LM_G2_EPI_PO, 2, 0)
         LM_G2_TRY(3, 3, 3, 1, LM_G2_EPI_PO, 2, 0) LM_G2_TRY(3, 3, 3, 2, LM_G2_EPI_PO, 2, 0)       // (three tiles of a split format spill)
         LM_G2_TRY(3, 3, 4, 1, LM_G2_EPI_PO, 2, 0) LM_G2_TRY(3, 3, 4, 2, LM_G2_EPI_PO, 2, 0)

@@ -52,7 +52,7 @@ def have_instance(kh, kw, terms, mt, epi, nc=1, loader=0):
         if v == (1, 0):
             return terms in (1, 3, 4) and 1 <= mt <= 4
         if v == (1, 1):
-            return terms in (1, 4) and mt in (1, 2)
+            return (terms == 1 and 1 <= mt <= 4) or (terms == 4 and mt in (1, 2))
         return v == (2, 0) and terms in (1, 3, 4) and 1 <= mt <= (3 if terms == 1 else 2)
     if (kh, kw) == (1, 1) and epi in (EPI_TC, EPI_TC2):
         return v == (1, 0) and terms in (1, 3) and 1 <= mt <= 4

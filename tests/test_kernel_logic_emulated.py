@@ -173,7 +173,7 @@ def test_fcn_golden_tiny(emu_lib, precision):
     assert lm_checks.check_fcn_golden(emu_lib, "k7_70x94", precision=precision) < 1e-4
 
 
-@pytest.mark.parametrize("precision,tol", [("mixed", 5e-4), ("planar-f16x3", 1e-5)])
+@pytest.mark.parametrize("precision,tol", [("mixed", 5e-4)])       # (planar-f16x3: on the GPU, test_fcn_golden_planar_engine)
 def test_fcn_golden_planar_engine_emulated(emu_lib, precision, tol):
     """the planar engine's kernels (CPU emulation of the same sources) against the REFERENCE module's outputs (G5 wide case)"""
     assert lm_checks.check_fcn_golden(emu_lib, "k7_66x130_wide", tol=tol, precision=precision, require_planar=True) <= tol
