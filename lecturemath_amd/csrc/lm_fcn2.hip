@@ -149,7 +149,7 @@ struct LmG2Args {
     int vmode;
     const float* vbias;             // vmode 1: [0] text, [1..3] reconstruction; vmode 2: [0] the output logit
     const char* x0_hi; const char* x0_lo; char* dp_hi; char* dp_lo; int Wp_v, halo_v;      // the network input and the diff, pair planes
-    float* v_text; float* v_rec4; float* v_out;
+    float* v_text; float* v_rec4; float* v_out;      // v_rec4: [3][H][W] (the fused head writes the caller's image directly), may be null
 };
 
 LM_DEV void lm_pair_store(char* hi_plane, char* lo_plane, int Wp, int halo, int y, int x, float v0, float v1, float v2);
@@ -445,7 +445,10 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? (((TERMS != 1 && 
             const lm_h4 xh = *(const lm_h4*)(a.x0_hi + so), xl4 = *(const lm_h4*)(a.x0_lo + so);
             const float x0 = (float)xh[0] + (float)xl4[0], x1 = (float)xh[1] + (float)xl4[1], x2 = (float)xh[2] + (float)xl4[2];
             a.v_text[pi] = t;
-            if (a.v_rec4) *(float4*)(a.v_rec4 + pi * 4) = make_float4(r0, r1, r2, 0.f);
+            if (a.v_rec4) {         // the caller's [3][H][W] reconstruction image
+                const long long npx = (long long)a.H * a.W;
+                a.v_rec4[pi] = r0; a.v_rec4[npx + pi] = r1; a.v_rec4[2 * npx + pi] = r2;
+            }
             lm_pair_store(a.dp_hi, a.dp_lo, a.Wp_v, a.halo_v, y, x, (x0 - r0) * m, (x1 - r1) * m, (x2 - r2) * m);
         }
         return;
@@ -923,7 +926,7 @@ static int lm_g2_launch(const LmF2Layer& l, const LmG2Args& a, dim3 grid, size_t
 // launches layer `li`: input planes per the recipe; `out` (EPI_PO / EPI_TC) with an optional pooled copy, or the T rows (EPI_T)
 // EPI_V layers: vmode 1 (text mask + reconstruction + diff; rec4 may be null) or 2 (output logit)
 static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor* pool, int act, float* tout, int ts, int tn, hipStream_t st, int vmode = 0,
-                     float* rec4 = nullptr)
+                     float* rec4 = nullptr, float* text = nullptr, float* outl = nullptr)
 {
     const LmF2Layer& l = f->layer[li];
     if (!l.set) { lm_set_error("lm_fcn2_forward: layer %d has no weights (call lm_fcn2_set_layer)", li); return LM_ERR_STATE; }
@@ -955,7 +958,7 @@ static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor*
         a.vmode = vmode; a.vbias = l.d_bias + 16;
         a.x0_hi = f->arena + x0.off; a.x0_lo = a.x0_hi + x0.plane; a.dp_hi = f->arena + dp.off; a.dp_lo = a.dp_hi + dp.plane;
         a.Wp_v = dp.Wp; a.halo_v = dp.halo;
-        a.v_text = f->text; a.v_rec4 = rec4; a.v_out = f->outl;
+        a.v_text = text ? text : f->text; a.v_rec4 = rec4; a.v_out = outl ? outl : f->outl;
         if (in.halo < 3 || x0.Wp != dp.Wp || x0.halo != dp.halo) { lm_set_error("lm_fcn2_forward: pair planes of different geometry"); return LM_ERR_STATE; }
     }
     const int nhl = (l.terms == 2 || l.terms == 3) ? 2 : 1;
@@ -1045,24 +1048,25 @@ extern "C" int lm_fcn2_forward(LmFcn2* f, const uint8_t* d_rgb, int h, int w, fl
     }
     // ---- heads
     const bool fused16 = f->layer[16].epi == LM_G2_EPI_V, fused20 = f->layer[20].epi == LM_G2_EPI_V;
-    if ((rc = lm_f2_run(f, 16, nullptr, nullptr, LM_ACT_NONE, f->tbuf, 16, 16, st, fused16 ? 1 : 0, d_rec ? f->rec4 : nullptr))) return rc;
+    // the two logit images go straight into the caller's buffers when it gave any
+    float* const text = d_text ? d_text : f->text;
+    float* const outl = d_out ? d_out : f->outl;
+    if ((rc = lm_f2_run(f, 16, nullptr, nullptr, LM_ACT_NONE, f->tbuf, 16, 16, st, fused16 ? 1 : 0, fused16 ? d_rec : nullptr, text))) return rc;
     if (!fused16) {
         const LmF2Tensor &x0 = T[LM_F2_X0P], &dp = T[LM_F2_DP];
         const int tiles = ((w + 31) / 32) * ((h + 15) / 16);
         hipLaunchKernelGGL(lm_k_vsum2_text_rec, dim3(tiles), dim3(256), 0, st, f->tbuf, h, w, f->layer[16].d_bias + 16, f->arena + x0.off,
-                           f->arena + x0.off + x0.plane, f->text, f->rec4, f->arena + dp.off, f->arena + dp.off + dp.plane, dp.Wp, dp.halo);
+                           f->arena + x0.off + x0.plane, text, f->rec4, f->arena + dp.off, f->arena + dp.off + dp.plane, dp.Wp, dp.halo);
     }
     if ((rc = lm_f2_run(f, 18, &T[LM_F2_P1], nullptr, LM_ACT_GELU, nullptr, 0, 0, st))) return rc;
     if ((rc = lm_f2_run(f, 19, &T[LM_F2_P2], nullptr, LM_ACT_GELU, nullptr, 0, 0, st))) return rc;
-    if ((rc = lm_f2_run(f, 20, nullptr, nullptr, LM_ACT_NONE, f->tbuf, 8, 8, st, fused20 ? 2 : 0))) return rc;
+    if ((rc = lm_f2_run(f, 20, nullptr, nullptr, LM_ACT_NONE, f->tbuf, 8, 8, st, fused20 ? 2 : 0, nullptr, nullptr, outl))) return rc;
     if (!fused20) {
         const int tiles = ((w + 31) / 32) * ((h + 15) / 16);
-        hipLaunchKernelGGL((lm_k_vsum<7, 1, 8, false>), dim3(tiles), dim3(256), 0, st, f->tbuf, h, w, f->layer[20].d_bias + 16, LM_ACT_NONE, f->outl, 1,
+        hipLaunchKernelGGL((lm_k_vsum<7, 1, 8, false>), dim3(tiles), dim3(256), 0, st, f->tbuf, h, w, f->layer[20].d_bias + 16, LM_ACT_NONE, outl, 1,
                            nullptr, nullptr, nullptr);
     }
-    if (d_out) LM_HIP(hipMemcpyAsync(d_out, f->outl, (size_t)npx * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (d_text) LM_HIP(hipMemcpyAsync(d_text, f->text, (size_t)npx * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (d_rec) hipLaunchKernelGGL(lm_k_nhwc4_to_chw3, dim3((unsigned)std::min<long long>((npx + 255) / 256, 8192)), dim3(256), 0, st, f->rec4, d_rec, npx);
+    if (d_rec && !fused16) hipLaunchKernelGGL(lm_k_nhwc4_to_chw3, dim3((unsigned)std::min<long long>((npx + 255) / 256, 8192)), dim3(256), 0, st, f->rec4, d_rec, npx);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }
