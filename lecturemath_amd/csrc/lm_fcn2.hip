@@ -137,7 +137,6 @@ struct LmG2Args {
     int act;                        // LM_ACT_GELU or LM_ACT_NONE
     int tc_merged;                  // EPI_TC: 1 = LM_G2_EPI_TC2 (parity = dy, tile pair q = dx)
     int stamp;                      // diagnostic builds: this launch writes its stamps
-    int stagger;                    // > 0: the workgroups 256..511 (the CUs' second residents of the first round) start this many s_sleep 127 later
     // EPI_PO / EPI_TC output tensor
     char* out_hi; char* out_lo;     // plane 0 of the hi / lo parts (lo may be null)
     long long out_plane;            // bytes per plane
@@ -199,13 +198,6 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? (((TERMS != 1 && 
         const int nwg = (int)gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7, j = wg >> 3;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
-#if !LM_HIP_EMULATED
-    // Two workgroups of a CU that start together run in step -- both in their MFMA loops, both in their epilogues -- and identical
-    // workgroups stay that way for the whole launch.  Delaying the CUs' second residents of the FIRST round by about half a workgroup's
-    // lifetime puts one workgroup's prologue / epilogue beside the other's MFMA loop from then on.
-    if (a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
-        for (int i = 0; i < a.stagger; i++) __builtin_amdgcn_s_sleep(127);
-#endif
     const int tiles = a.tiles_x * a.tiles_y;
     const int cblk = wg / tiles, tile = wg - cblk * tiles;          // channel block (x parity for EPI_TC), tile
     const int cby = (EPI == LM_G2_EPI_TC) ? cblk % a.cblocks : cblk, par = (EPI == LM_G2_EPI_TC) ? cblk / a.cblocks : 0;
@@ -992,9 +984,6 @@ static int lm_f2_run(LmFcn2* f, int li, const LmF2Tensor* out, const LmF2Tensor*
     if (blocks * 16 * l.mt != l.cout) { lm_set_error("lm_fcn2_forward: layer %d: %d outputs are not whole blocks of %d tiles", li, l.cout, l.mt); return LM_ERR_STATE; }
     a.cblocks = blocks;
     a.tc_merged = l.epi == LM_G2_EPI_TC2 ? 1 : 0;
-    static const int stagger_env = [] { const char* e = getenv("LM_G2_STAGGER"); return e ? atoi(e) : 0; }();
-    static const int stagger_layer = [] { const char* e = getenv("LM_G2_STAGGER_LAYER"); return e ? atoi(e) : -1; }();
-    a.stagger = (stagger_layer < 0 || stagger_layer == li) ? stagger_env : 0;
     static const int stamp_layer = [] { const char* e = getenv("LM_G2_STAMP_LAYER"); return e ? atoi(e) : -1; }();
     a.stamp = li == stamp_layer;
     return lm_g2_launch(l, a, dim3((unsigned)tiles * blocks * (l.epi == LM_G2_EPI_TC ? 4 : (l.epi == LM_G2_EPI_TC2 ? 2 : 1))), smem, st);
