@@ -74,7 +74,7 @@ LM_DEV void lm_vmwait(int n)
 #ifndef LM_G2_STAMPS
 #define LM_G2_STAMPS 0
 #endif
-#ifndef LM_G2_CUT           // timing-only diagnostic builds (wrong results): 1 = no weight fetches after the first groups, 2 = no activation, 3 = no stores, 4 = no epilogue, 6 = no patch fetches after the first chunk
+#ifndef LM_G2_CUT           // timing-only diagnostic builds (wrong results): 1 = no weight fetches after the first groups, 2 = no activation, 3 = no stores, 4 = no epilogue, 6 = no patch fetches after the first chunk, 7 = a quarter of the pixel-fragment LDS reads
 #define LM_G2_CUT 0
 #endif
 #if LM_G2_STAMPS && !LM_HIP_EMULATED
@@ -311,6 +311,9 @@ __global__ void __launch_bounds__(LOADER ? 320 : 256, LOADER ? (((TERMS != 1 && 
                 for (int c = 0; c < NC; c++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
+#if LM_G2_CUT == 7      // timing-only build: a quarter of the pixel-fragment LDS reads (rows 1..3 reuse row 0's registers)
+                        if (r > 0) { f.bh[c * 4 + r] = f.bh[c * 4]; if (SPLIT_B) f.bl[c * 4 + r] = f.bl[c * 4]; continue; }
+#endif
                         f.bh[c * 4 + r] = *(const lm_h8*)(pa + r * (PW * 16) + c * 256);
                         if (SPLIT_B) f.bl[c * 4 + r] = *(const lm_h8*)(pa + r * (PW * 16) + c * 256 + PLS);
                     }
