@@ -182,7 +182,7 @@ def test_fcn_golden_planar_engine_emulated(emu_lib, precision, tol):
 PLANAR_TINY_WIDTHS = (16, 32, 16, 16, 16, 32, 32, 16, 16, 16, 16, 16, 16, 48, 16, 32, 32, 16)       # channel blocks of 1, 2 and 3 tiles; one merged-dx transposed conv
 
 
-@pytest.mark.parametrize("precision,tol", [("mixed", 5e-4), ("planar-f16x3", 1e-5)])
+@pytest.mark.parametrize("precision,tol", [("mixed", 5e-4)])        # (planar-f16x3 at 1e-5: on the GPU, test_fcn_shipped_config_vs_oracle / _1080p_)
 def test_fcn_planar_tiny_vs_oracle(emu_lib, precision, tol):
     """The planar FCN engine (csrc/lm_fcn2.hip: gather-GEMM on 16x16x32 MFMA tiles, planar f16 activations, LDS-DMA staging, pair
     planes) on the CPU emulator against the torch oracle: an odd-sized frame (every output_size border, floor pooling), then a
