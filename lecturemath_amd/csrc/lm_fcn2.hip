@@ -2,31 +2,36 @@
 //
 // Same network and reference lines as lm_fcn.hip (FCN_lecturenet.py:260-323 encode_decode, :364-403 forward, :607-618 prepare_image);
 // this engine runs the shipped topology (3x3 encoder / decoder, 7x7 pixel branch, every width a multiple of 16) with a per-layer
-// operand format: the layers below full resolution on plain f16 operands, the full-resolution layers on the f16 hi + lo split
-// ("f16x3": hi.hi + hi.lo + lo.hi).  profiles/r03_fcn_layer_precision.* is the measurement behind that assignment.
+// OPERAND FORMAT: 1 = f16 x f16 (the layers below full resolution); 3 = f16 hi + lo split of both operands (hi.hi + lo.hi + hi.lo);
+// 4 ("w2") = weights hi + lo x activations hi -- the input tensor then needs no lo planes; 2 ("a2") = activations hi + lo x weights hi.
+// lecturemath_amd/fcn.py holds the shipped assignment and profiles/r04_fcn_formats.* the measurement behind it (logit error AND binary flips).
 //
 // Activations in HBM ("planar octets"): a tensor of C channels is C/8 planes of [Hp][Wp] slots of 16 bytes = 8 consecutive channels
-// of one pixel as f16 (the hi parts), followed -- when a consumer runs a split format -- by C/8 planes of the lo parts
-// (lo = f16(x - hi), so hi + lo carries ~22 bits).  Hp x Wp = the image rounded up to whole tiles (16 rows, 32 columns) plus a zero halo as wide
-// as the largest padding of any consumer: a convolution's input patch is then a plain rectangle of every plane, no bounds checks.
-// A producer converts ONCE per value in its epilogue (lm_fcn.hip converted fp32 -> f16 hi / lo in every consuming workgroup: 12-24
-// times per value in the deep layers) and every load of the engine is a 16-byte LDS-DMA (global_load_lds_dwordx4).
+// of one pixel as f16 (the hi parts), followed -- when a consumer runs a format that splits the activations -- by C/8 planes of the lo
+// parts (lo = f16(x - hi), so hi + lo carries ~22 bits).  Hp x Wp = the image rounded up to whole tiles (16 rows, 32 columns) plus a zero
+// halo as wide as the largest padding of any consumer: a convolution's input patch is then a plain rectangle of every plane, no bounds
+// checks.  A producer converts ONCE per value in its epilogue (lm_fcn.hip converted fp32 -> f16 hi / lo in every consuming workgroup:
+// 12-24 times per value in the deep layers) and every load of the engine is a 16-byte LDS-DMA (buffer_load_dwordx4 ... lds).
 //
-// The kernel (lm_k_g2) is a gather-GEMM  D[channel][pixel] = sum_k A[channel][k] * B[k][pixel]  on 16 x 16 x 32 tiles:
-//   * a workgroup = 4 waves = a 16 x 16 pixel tile x MT tiles of 16 output channels; wave w owns the pixel rows 4w..4w+3 (NT = 4
-//     column tiles of 16 consecutive pixels) and all MT channel tiles: 4 * MT accumulators of 4 registers;
+// The kernel (lm_k_g2) is a gather-GEMM  D[channel][pixel] = sum_k A[channel][k] * B[k][pixel]  on 16 x 16 x 32 MFMA tiles:
+//   * a workgroup = a tile of 16 rows x 16 * NC pixels x MT tiles of 16 output channels, computed by 4 waves: wave w owns the pixel
+//     rows 4w..4w+3 (4 * NC column fragments of 16 consecutive pixels) and all MT channel tiles: 4 * NC * MT accumulators of 4 registers.
+//     NC = 2 (16 x 32 tiles) halves the weight bytes fetched and the A-fragment reads per pixel; LOADER = 1 adds a fifth wave that
+//     issues every LDS-DMA of the workgroup (the compute waves then issue no vector-memory instruction in their loop);
 //   * K is walked in SLICES of 32: the four 8-wide k-groups of a slice (lane >> 4) are four (plane, tap) pairs chosen by the HOST --
 //     four channel octets of one tap, or two octets of two taps, or taps of a "pair plane" (below) -- so a layer's K needs no padding
 //     beyond its last slice.  The B fragment of k-group g is ONE ds_read_b128 at (pair's slot of the lane's pixel); the four pairs'
 //     patch offsets of every slice sit in an LDS table (16 bytes per slice, copied once per workgroup): the slice loop issues LDS
-//     operations only, which return in order, so its waits are counted (a scalar load in the loop forced lgkmcnt(0) on every wait:
-//     each slice then paid a full LDS round trip -- 620 cycles per 128 cycles of MFMAs in the deep layers, profiles/r04_fcn_stamps_*);
+//     operations only, which return in order, so its waits are counted;
 //   * weights are the A operand, packed by the host in fragment order per (channel block, weight group, slice, tile, hi | lo);
-//   * staging: the chunk's planes (double-buffered when a layer has several chunks and LDS allows) and the next weight group are
-//     fetched by LDS-DMA while the current group's MFMAs run; one "vmcnt(0) + barrier" per weight group.
+//   * staging: the chunk's planes (double-buffered when a layer has several chunks and LDS allows) and the weight groups (a ring of
+//     two or three LDS buffers) are fetched by LDS-DMA while the current group's MFMAs run; one counted vmcnt + barrier per group;
+//   * epilogues: bias + GELU + f16 hi (+ lo) as whole-octet stores (+ the 2x2 max-pooled copy), the four parities of a transposed
+//     convolution, fp32 rows of a head's row convolution, or (EPI_V) the head's row convolution AND its vertical sums in one kernel.
 // Pair planes: a 3-channel input (the RGB frame, the diff of the pixel branch) is stored as ONE plane whose slot x holds
 // {c0 c1 c2 0 of pixel x | c0 c1 c2 0 of pixel x + 1}: one k-group covers two horizontal taps, so a 7-tap kernel row of the 3-channel
 // part costs 4 k-groups instead of 7 x a zero-padded 16-channel chunk (lm_fcn.hip), and conv_down_1's K = 27 fits two slices.
+// What round 4 measured about this kernel (stamps, timing-only cut builds, variants) is in DESIGN.md section 4.5 and profiles/r04_*.
 #include "lm_common.h"
 
 #if LM_HIP_EMULATED
