@@ -31,6 +31,9 @@ class FCN_LectureNet:
         self._sd = dict(state_dict)
         if self._engine is not None:
             self._engine.load_state_dict(self._sd)
+        if getattr(self, "_engine2", None) is not None:         # the second engine of binarize_frames_device is rebuilt on next use
+            self._engine2.close()
+            self._engine2 = None
 
     def eval(self):
         return self
@@ -86,18 +89,45 @@ class FCN_LectureNet:
         eng = self._get_engine(nh, nw)
         lib, be = eng.lib, eng.be
         out = be.empty((n, h, w), np.uint8)
-        small = be.empty((nh, nw), np.uint8) if big else None
-        for i in range(n):
+        # Two engines on two HIP streams, frames dealt alternately: the layers below 1/8 resolution launch 288-480 workgroups on 256 CUs and a
+        # second forward pass in flight fills what one leaves idle (profiles/r04_fcn_two_streams.txt: 437 -> 475 frames/s).  Each engine has
+        # its own activation arena; everything a frame touches is enqueued on its engine's stream.
+        engines, streams = [eng], [None]
+        if be.device and n >= 2 and eng.planar:
+            torch = be.torch
+            if getattr(self, "_engine2", None) is None or self._engine2_hw != self._engine_hw:
+                if getattr(self, "_engine2", None) is not None:
+                    self._engine2.close()
+                self._engine2 = fcn.FcnEngine(self.widths, self.pixel_kernel_size, self.kernel_size, self._engine_hw[0], self._engine_hw[1])
+                self._engine2.load_state_dict(self._sd)
+                self._engine2_hw = self._engine_hw
+            if getattr(self, "_side_stream", None) is None:
+                self._side_stream = torch.cuda.Stream()
+            self._side_stream.wait_stream(torch.cuda.current_stream())
+            engines.append(self._engine2)
+            streams.append(self._side_stream)
+
+        def one(i, e):
+            small = be.empty((nh, nw), np.uint8) if big else None
             frame = rgb_frames[i] if not isinstance(rgb_frames, np.ndarray) else be.from_host(rgb_frames[i])
             if big:
                 frame, _, _ = self._halve_on_device(frame, w, h)
-            logits, _, _ = eng.forward(frame)
+            logits, _, _ = e.forward(frame)
             dst = out[i] if be.device else out[i:i + 1]
             if big:
                 lib.check(lib.lm_threshold_invert(_lib.ptr(logits), _lib.ptr(small), nh * nw, int(binary_threshold), be.stream()))
                 lib.check(lib.lm_upsample_nearest_u8(_lib.ptr(small), nh, nw, 1, _lib.ptr(dst), h, w, be.stream()))
             else:
                 lib.check(lib.lm_threshold_invert(_lib.ptr(logits), _lib.ptr(dst), h * w, int(binary_threshold), be.stream()))
+        for i in range(n):
+            k = i % len(engines)
+            if streams[k] is None:
+                one(i, engines[k])
+            else:
+                with be.torch.cuda.stream(streams[k]):
+                    one(i, engines[k])
+        if len(engines) > 1:
+            be.torch.cuda.current_stream().wait_stream(self._side_stream)
         return out
 
     def binarize(self, PIL_image, return_others=False, force_binary=False, binary_treshold=128, apply_sigmoid=True):
