@@ -394,3 +394,24 @@ def test_e2e_rgb_binarization_and_cc_sets(hip_lib, oracle_built, fcn_1080p_oracl
     assert total_flips <= 1200, total_flips
     fs.close()
     eng.close()
+
+
+@pytest.mark.parametrize("fused", ["0", "3"])
+def test_fcn_head_variants_vs_oracle(hip_lib, monkeypatch, fused):
+    """The heads' other code paths (default: text / rec head fused with its vertical sums, output head as rows + lm_k_vsum): nothing fused
+    (row buffer + lm_k_vsum2_text_rec + lm_k_vsum) and both fused, on an odd-sized frame (tiles of 10 finished rows against a height that
+    is no multiple of 10 or 16) against the torch oracle."""
+    import torch
+    from lecturemath_amd import fcn
+    from oracle import fcn as ofcn
+    monkeypatch.setenv("LM_FCN2_FUSED_HEADS", fused)
+    sd = ofcn.random_state_dict(ofcn.SHIPPED_WIDTHS, pixel_kernel=7, seed=2)
+    rgb, _ = synth.whiteboard_rgb(203, 331, n_glyphs=80, seed=6)
+    eng = fcn.FcnEngine(ofcn.SHIPPED_WIDTHS, 7, 3, 203, 331, hip_lib)
+    eng.load_state_dict(sd)
+    assert eng.planar and (eng.recipes[16]["epilogue"] == 4) == (fused == "3") and (eng.recipes[20]["epilogue"] == 4) == (fused == "3")
+    out, text, rec = (t.cpu().numpy() for t in eng.forward(rgb))
+    eng.close()
+    with torch.no_grad():
+        o, t, r = ofcn.forward(sd, ofcn.prepare_image(rgb))
+    assert np.abs(out - o[0, 0].numpy()).max() <= 5e-4 and np.abs(text - t[0, 0].numpy()).max() <= 5e-4 and np.abs(rec - r[0].numpy()).max() <= 5e-4
