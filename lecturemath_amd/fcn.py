@@ -231,6 +231,9 @@ class FcnEngine:
         if os.environ.get("LM_FCN2_MT"):                                   # experiments: channel tiles per workgroup, "0=1,10=2"
             mt_over = {int(k): int(v) for k, v in (kv.split("=") for kv in os.environ["LM_FCN2_MT"].split(","))}
         mt_over = {**self.DEFAULT_MT, **mt_over}
+        gs_over = {}
+        if os.environ.get("LM_FCN2_GSIZE"):                                # experiments: slices per weight group, "18=2,15=3"
+            gs_over = {int(k): int(v) for k, v in (kv.split("=") for kv in os.environ["LM_FCN2_GSIZE"].split(","))}
         recipes = {}
         # feature octets per chunk of conv_pixels_2: one, so that the 16 x 32 tile's patch planes of the split format leave room for two
         # workgroups per CU (two octets: 88 KB of LDS, one workgroup, 757 us; one octet: 76 KB, 338 us; 16 x 16 tiles: 364 us)
@@ -270,7 +273,7 @@ class FcnEngine:
                 w4 = [np.ascontiguousarray(wt[:, :, dy, dx].T)[:, :, None, None] for dy in (0, 1) for dx in (0, 1)]
                 recipes[L_UPT + i] = (f2.build(w4, chunks, 1, 1, T(L_UPT + i), mt_over.get(L_UPT + i) or f2.pick_mt(u, tiles(lvl)), f2.EPI_TC), bt)
             w, b = conv_bn("conv_up_block_%d" % lvl)                                      # input = cat(up, skip_pre)
-            recipes[L_UPC + i] = (f2.conv_layer(w, [(f2.T_UPT0 + i, u // 8), (f2.T_PRE0 + lvl - 1, skip // 8)], T(L_UPC + i), tiles(lvl - 1), mt=mt_over.get(L_UPC + i), lds_target=LDS(L_UPC + i, lds_for(tiles(lvl - 1), c, 2 if i == 0 else 4)), **V(L_UPC + i)), b)
+            recipes[L_UPC + i] = (f2.conv_layer(w, [(f2.T_UPT0 + i, u // 8), (f2.T_PRE0 + lvl - 1, skip // 8)], T(L_UPC + i), tiles(lvl - 1), mt=mt_over.get(L_UPC + i), gsize=gs_over.get(L_UPC + i), lds_target=LDS(L_UPC + i, lds_for(tiles(lvl - 1), c, 2 if i == 0 else 4)), **V(L_UPC + i)), b)
         # heads: the text + reconstruction row convolution is fused with its vertical sums (EPI_V; 56 + 77 -> 93 us: the 133 MB fp32 row buffer
         # is neither written nor read back); the output logit's is not (62 + 20 -> 87 us fused: its tiles of 10 finished rows cost more
         # row-convolution work than its 66 MB of rows; profiles/r04_heads_*.txt).  LM_FCN2_FUSED_HEADS: bit 0 = text / rec, bit 1 = output.
@@ -282,9 +285,9 @@ class FcnEngine:
         recipes[L_TEXT] = (f2.build([rows], f2.conv_chunks([(f2.T_XUP, c1 // 8)], 1, 7, c1 // 8), 1, 7, T(L_TEXT), 1, head_epi, lds_target=LDS(L_TEXT), **V(L_TEXT)),
                            np.concatenate([np.zeros(16, np.float32), bt, br]))
         w, b = conv_bn("conv_pixels_1")
-        recipes[L_PX1] = (f2.build([w], f2.pixel_chunks(f2.T_XUP, c1 // 8, f2.T_DP, 7, 7), 7, 7, T(L_PX1), 2 if pm1 % 32 == 0 else 1, f2.EPI_PO, pdouble=False, lds_target=LDS(L_PX1), **V(L_PX1)), b)
+        recipes[L_PX1] = (f2.build([w], f2.pixel_chunks(f2.T_XUP, c1 // 8, f2.T_DP, 7, 7), 7, 7, T(L_PX1), 2 if pm1 % 32 == 0 else 1, f2.EPI_PO, pdouble=False, gsize=gs_over.get(L_PX1), lds_target=LDS(L_PX1), **V(L_PX1)), b)
         w, b = conv_bn("conv_pixels_2")
-        recipes[L_PX2] = (f2.build([w], f2.pixel_chunks(f2.T_P1, pm1 // 8, f2.T_DP, 7, 7, octets=px_octets), 7, 7, T(L_PX2), 2 if pm2 % 32 == 0 else 1, f2.EPI_PO, pdouble=False, lds_target=LDS(L_PX2), **V(L_PX2)), b)
+        recipes[L_PX2] = (f2.build([w], f2.pixel_chunks(f2.T_P1, pm1 // 8, f2.T_DP, 7, 7, octets=px_octets), 7, 7, T(L_PX2), 2 if pm2 % 32 == 0 else 1, f2.EPI_PO, pdouble=False, gsize=gs_over.get(L_PX2), lds_target=LDS(L_PX2), **V(L_PX2)), b)
         w, b = conv_bn("conv_out")
         recipes[L_OUT] = (f2.build([f2.out_rows(w)], f2.pixel_chunks(f2.T_P2, pm2 // 8, f2.T_DP, 1, 7), 1, 7, T(L_OUT), 1, out_epi, pdouble=False, lds_target=LDS(L_OUT), **V(L_OUT)),
                           np.concatenate([np.zeros(16, np.float32), b]))

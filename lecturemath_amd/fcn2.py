@@ -182,7 +182,7 @@ def pick_mt(cout, tiles, prefer=(4, 3, 2)):
     return ok[-1]
 
 
-def conv_layer(w, inputs, terms, tiles, mt=None, nc=1, loader=0, lds_target=LDS_TWO_WORKGROUPS):
+def conv_layer(w, inputs, terms, tiles, mt=None, nc=1, loader=0, lds_target=LDS_TWO_WORKGROUPS, gsize=None):
     """tiles: 16 x 16 pixel tiles of the layer's grid (a 16 x 32 tile counts as two)"""
     cout, _, kh, kw = w.shape
     if not have_instance(kh, kw, terms, mt or pick_mt(cout, tiles // nc), EPI_PO, nc, loader):
@@ -195,7 +195,7 @@ def conv_layer(w, inputs, terms, tiles, mt=None, nc=1, loader=0, lds_target=LDS_
             continue
         chunks = conv_chunks(inputs, kh, kw, co)
         pd = len(chunks) > 1
-        r = build([w], chunks, kh, kw, terms, mt, EPI_PO, pdouble=pd, nc=nc, loader=loader, lds_target=lds_target)
+        r = build([w], chunks, kh, kw, terms, mt, EPI_PO, pdouble=pd, nc=nc, loader=loader, lds_target=lds_target, gsize=gsize)
         key = (r[3] > lds_target, int(r[0][8]))      # room for two workgroups per CU first, then the fewest slices
         if best is None or key < best[0]:
             best = (key, r)
