@@ -285,9 +285,11 @@ class FcnEngine:
         recipes[L_TEXT] = (f2.build([rows], f2.conv_chunks([(f2.T_XUP, c1 // 8)], 1, 7, c1 // 8), 1, 7, T(L_TEXT), 1, head_epi, lds_target=LDS(L_TEXT), **V(L_TEXT)),
                            np.concatenate([np.zeros(16, np.float32), bt, br]))
         w, b = conv_bn("conv_pixels_1")
-        recipes[L_PX1] = (f2.build([w], f2.pixel_chunks(f2.T_XUP, c1 // 8, f2.T_DP, 7, 7), 7, 7, T(L_PX1), 2 if pm1 % 32 == 0 else 1, f2.EPI_PO, pdouble=False, gsize=gs_over.get(L_PX1), lds_target=LDS(L_PX1), **V(L_PX1)), b)
+        px1_octets = int(os.environ.get("LM_FCN2_PX1_OCTETS", "2"))                     # experiments: feature octets per chunk of conv_pixels_1
+        px_pdouble = [bool(int(v)) for v in os.environ.get("LM_FCN2_PX_PDOUBLE", "0,0").split(",")]      # ... double-buffered patch planes (px1, px2)
+        recipes[L_PX1] = (f2.build([w], f2.pixel_chunks(f2.T_XUP, c1 // 8, f2.T_DP, 7, 7, octets=px1_octets), 7, 7, T(L_PX1), 2 if pm1 % 32 == 0 else 1, f2.EPI_PO, pdouble=px_pdouble[0], gsize=gs_over.get(L_PX1), lds_target=LDS(L_PX1), **V(L_PX1)), b)
         w, b = conv_bn("conv_pixels_2")
-        recipes[L_PX2] = (f2.build([w], f2.pixel_chunks(f2.T_P1, pm1 // 8, f2.T_DP, 7, 7, octets=px_octets), 7, 7, T(L_PX2), 2 if pm2 % 32 == 0 else 1, f2.EPI_PO, pdouble=False, gsize=gs_over.get(L_PX2), lds_target=LDS(L_PX2), **V(L_PX2)), b)
+        recipes[L_PX2] = (f2.build([w], f2.pixel_chunks(f2.T_P1, pm1 // 8, f2.T_DP, 7, 7, octets=px_octets), 7, 7, T(L_PX2), 2 if pm2 % 32 == 0 else 1, f2.EPI_PO, pdouble=px_pdouble[1], gsize=gs_over.get(L_PX2), lds_target=LDS(L_PX2), **V(L_PX2)), b)
         w, b = conv_bn("conv_out")
         recipes[L_OUT] = (f2.build([f2.out_rows(w)], f2.pixel_chunks(f2.T_P2, pm2 // 8, f2.T_DP, 1, 7), 1, 7, T(L_OUT), 1, out_epi, pdouble=False, lds_target=LDS(L_OUT), **V(L_OUT)),
                           np.concatenate([np.zeros(16, np.float32), b]))
